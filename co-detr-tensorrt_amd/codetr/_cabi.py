@@ -1,0 +1,102 @@
+"""ctypes binding of libcodetr_hip.so (C ABI: include/codetr_hip.h).
+
+This is the only place the Python host crosses into native code.  The library is built
+in-tree next to this file (``make -C co-detr-tensorrt_amd/csrc`` or ``__graft_entry__.build()``)
+and, like the reference's ``codetr/__init__.py:8-12`` does for its CUDA extension, a missing
+``.so`` is an ImportError -- there is no CPU or PyTorch fallback behind these calls.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
+ABI_VERSION = 1
+
+_i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
+
+# name -> (restype, argtypes); mirrors include/codetr_hip.h line by line
+_MSDA_ARGS = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i32, _i64, _vp]
+SIGNATURES = {
+    "codetr_hip_abi_version": (_i32, []),
+    "codetr_hip_strerror": (_cp, [_i32]),
+    "codetr_msda_forward_f16": (_i32, _MSDA_ARGS),
+    "codetr_msda_forward_bf16": (_i32, _MSDA_ARGS),
+    "codetr_msda_forward_f32": (_i32, _MSDA_ARGS),
+    "codetr_msda_forward_f64": (_i32, _MSDA_ARGS),
+    "codetr_msda_variant": (_cp, [_i32, _i32, _i32, _i32, _i32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise ImportError (loudly) if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"HIP extension not found at {LIB_PATH}; build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C co-detr-tensorrt_amd/csrc`"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.codetr_hip_abi_version()
+    if ver != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {ver}, host expects {ABI_VERSION}; rebuild the extension")
+    _lib = lib
+    return lib
+
+
+def strerror(code: int) -> str:
+    return load().codetr_hip_strerror(code).decode()
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {strerror(code)} (code {code})")
+
+
+def current_stream_ptr(device) -> int:
+    """The raw hipStream_t of torch's current stream on `device` (plumbing only)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_MSDA_BY_DTYPE = {
+    torch.float16: ("codetr_msda_forward_f16", 2),
+    torch.bfloat16: ("codetr_msda_forward_bf16", 2),
+    torch.float32: ("codetr_msda_forward_f32", 4),
+    torch.float64: ("codetr_msda_forward_f64", 8),
+}
+
+
+def msda_variant(dtype, M, D, L, P) -> str:
+    return load().codetr_msda_variant(_MSDA_BY_DTYPE[dtype][1], M, D, L, P).decode()
+
+
+def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, out):
+    """Enqueue the MSDA forward on torch's current stream.  All tensors must already satisfy the
+    contract checked in ops.py (contiguous, on one HIP device, one float dtype, int64 shapes)."""
+    lib = load()
+    name, _ = _MSDA_BY_DTYPE[value.dtype]
+    B, S, M, D = value.shape
+    Nq, L, P = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+    rc = getattr(lib, name)(
+        current_stream_ptr(value.device),
+        value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+        sampling_loc.data_ptr(), attn_weight.data_ptr(),
+        B, S, M, D, L, Nq, P, int(im2col_step), out.data_ptr(),
+    )
+    if rc == -2:
+        # same condition and wording as the reference's AT_ASSERTM (ms_deform_attn.cu:924-926)
+        raise RuntimeError(f"batch({B}) must divide im2col_step({min(B, int(im2col_step))})")
+    check(rc, name)
+    return out

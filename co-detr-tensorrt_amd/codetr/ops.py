@@ -1,0 +1,144 @@
+"""``torch.ops.codetr.*`` on MI355X: schema, meta kernel and the HIP implementation.
+
+Host-side mirror of the reference's operator layer for the inference hot path:
+
+* schema strings are the reference's, character for character
+  (reference codetr/csrc/deformable_attention_torch.cpp:16-24);
+* the implementation is registered for dispatch key ``CUDA`` -- the key PyTorch-ROCm uses for
+  HIP tensors -- exactly as the reference registers its CUDA kernel
+  (deformable_attention_torch.cpp:28-31).  No other key is registered: calling the op with CPU
+  tensors fails in the dispatcher, as it does in the reference.  There is deliberately NO
+  PyTorch/CPU formulation of the op in this package (the reference's ``grid_sample`` version,
+  ops.py:129-186, lives only in ``oracle/`` as the parity checker);
+* the fake/meta kernel performs the reference's rank / dtype / shape checks and returns an
+  empty ``(bs, num_queries, embed_dims)`` tensor (reference codetr/ops.py:19-87);
+* the argument contract enforced before the launch is the reference's AT_ASSERTM list
+  (ms_deform_attn.cu:902-933): contiguous, on device, ``batch % min(batch, im2col_step) == 0``.
+
+Out of scope here: the backward op.  Its schema is defined so the
+namespace matches, and calling it raises.
+"""
+import torch
+from torch import Tensor
+
+from . import _cabi
+
+__all__ = ["multi_scale_deformable_attention"]
+
+_FWD_SCHEMA = (
+    "multi_scale_deformable_attention(Tensor value, Tensor spatial_shapes, "
+    "Tensor level_start_index, Tensor sampling_loc, Tensor attn_weight, "
+    "int im2col_step) -> Tensor"
+)
+_BWD_SCHEMA = (
+    "multi_scale_deformable_attention_backward(Tensor value, Tensor "
+    "spatial_shapes, Tensor level_start_index, Tensor sampling_loc, Tensor "
+    "attn_weight, Tensor grad_output, Tensor(a!) grad_value, Tensor(b!) "
+    "grad_sampling_loc, Tensor(c!) grad_attn_weight, int im2col_step) -> ()"
+)
+
+_lib = torch.library.Library("codetr", "DEF")
+_lib.define(_FWD_SCHEMA)
+_lib.define(_BWD_SCHEMA)
+
+_FLOAT_DTYPES = (torch.float16, torch.bfloat16, torch.float32, torch.float64)
+
+
+def _check_contract(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    # reference ms_deform_attn.cu:902-912 (contiguity + device), plugin.cpp:163-245 (ranks/dtypes)
+    named = (
+        ("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+        ("sampling_loc", sampling_loc), ("attn_weight", attn_weight),
+    )
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+        if t.device != value.device:
+            raise RuntimeError(f"{name} must be on the same device as value ({t.device} vs {value.device})")
+    if value.dtype not in _FLOAT_DTYPES:
+        raise RuntimeError(f"unsupported value dtype {value.dtype}")
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("value, sampling_loc and attn_weight must share one dtype")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64")
+    if value.dim() != 4 or spatial_shapes.dim() != 2 or level_start_index.dim() != 1:
+        raise RuntimeError("expected value[B,S,M,D], spatial_shapes[L,2], level_start_index[L]")
+    if sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("expected sampling_loc[B,Nq,M,L,P,2], attn_weight[B,Nq,M,L,P]")
+    B, _, M, _ = value.shape
+    L = spatial_shapes.shape[0]
+    Nq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if spatial_shapes.shape[1] != 2 or level_start_index.shape[0] != L:
+        raise RuntimeError("spatial_shapes must be [L,2] and level_start_index [L]")
+    if tuple(sampling_loc.shape) != (B, Nq, M, L, P, 2):
+        raise RuntimeError(f"sampling_loc shape {tuple(sampling_loc.shape)} != {(B, Nq, M, L, P, 2)}")
+    if tuple(attn_weight.shape) != (B, Nq, M, L, P):
+        raise RuntimeError(f"attn_weight shape {tuple(attn_weight.shape)} != {(B, Nq, M, L, P)}")
+
+
+def _msda_forward_hip(
+    value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor, sampling_loc: Tensor, attn_weight: Tensor,
+    im2col_step: int,
+) -> Tensor:
+    _check_contract(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    B, _, M, D = value.shape
+    Nq = sampling_loc.shape[1]
+    # torch.empty, not zeros: the kernel writes every element (the reference zero-fills twice,
+    # ms_deform_attn.cu:936, 968)
+    out = torch.empty((B, Nq, M * D), dtype=value.dtype, device=value.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(value.device):
+        _cabi.msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, out)
+    return out
+
+
+def _msda_backward_hip(*args, **kwargs):
+    raise NotImplementedError(
+        "codetr::multi_scale_deformable_attention_backward: training backward is outside the "
+        "inference hot path of this build (SURVEY.md 8(f)-4)"
+    )
+
+
+_lib.impl("multi_scale_deformable_attention", _msda_forward_hip, "CUDA")
+_lib.impl("multi_scale_deformable_attention_backward", _msda_backward_hip, "CUDA")
+
+
+@torch.library.register_fake("codetr::multi_scale_deformable_attention")
+def _multi_scale_deformable_attention_fake(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                           im2col_step):
+    torch._check(value.dim() == 4)
+    torch._check(spatial_shapes.dim() == 2)
+    torch._check(level_start_index.dim() == 1)
+    torch._check(sampling_loc.dim() == 6)
+    torch._check(attn_weight.dim() == 5)
+    torch._check(value.dtype == attn_weight.dtype)
+    torch._check(value.dtype == sampling_loc.dtype)
+    torch._check(spatial_shapes.dtype == torch.int64)
+    torch._check(level_start_index.dtype == torch.int64)
+    bs, _, num_heads, dim_per_head = value.shape
+    num_levels = spatial_shapes.shape[0]
+    torch._check(spatial_shapes.shape[1] == 2)
+    torch._check(level_start_index.shape[0] == num_levels)
+    torch._check(sampling_loc.shape[0] == bs)
+    num_queries = sampling_loc.shape[1]
+    torch._check(sampling_loc.shape[2] == num_heads)
+    torch._check(sampling_loc.shape[3] == num_levels)
+    num_points = sampling_loc.shape[4]
+    torch._check(sampling_loc.shape[5] == 2)
+    torch._check(attn_weight.shape[0] == bs)
+    torch._check(attn_weight.shape[1] == num_queries)
+    torch._check(attn_weight.shape[2] == num_heads)
+    torch._check(attn_weight.shape[3] == num_levels)
+    torch._check(attn_weight.shape[4] == num_points)
+    return torch.empty((bs, num_queries, num_heads * dim_per_head), dtype=value.dtype, device=value.device)
+
+
+def multi_scale_deformable_attention(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                     im2col_step=64):
+    """Convenience alias of ``torch.ops.codetr.multi_scale_deformable_attention``."""
+    return torch.ops.codetr.multi_scale_deformable_attention(
+        value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step
+    )

@@ -1,0 +1,93 @@
+/*
+ * codetr_hip.h -- C ABI of libcodetr_hip.so, the MI355X (gfx950) native library that
+ * replaces the reference's codetr/csrc for the Co-DETR inference hot path.
+ *
+ * Boundary rules (same for every entry point):
+ *   - extern "C", plain pointers and sizes; no torch / ATen types cross this line.
+ *   - every pointer named *_dev is DEVICE memory owned by the caller (in practice the
+ *     PyTorch-ROCm caching allocator); it is borrowed for the duration of the
+ *     asynchronous launch and must stay alive until the stream reaches that point.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ *     Work is enqueued and the call returns; nothing here synchronises, allocates,
+ *     or reads device data on the host, so every entry point is hipGraph-capturable.
+ *   - return value: 0 on success; a positive hipError_t value if the launch failed;
+ *     a negative CODETR_E_* value if the arguments break the reference's contract
+ *     (the reference raises c10::Error via AT_ASSERTM for those; the Python host
+ *     turns every non-zero code into a RuntimeError -- nothing fails silently).
+ *   - stateless and re-entrant.
+ *
+ * Which reference interface each entry point replaces is cited per function
+ * (paths relative to the reference tree).
+ */
+#ifndef CODETR_HIP_H_
+#define CODETR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CODETR_E_BADARG (-1)      /* null pointer / non-positive dimension                       */
+#define CODETR_E_IM2COL_STEP (-2) /* batch % min(batch, im2col_step) != 0  (ms_deform_attn.cu:924-926) */
+#define CODETR_E_TOO_LARGE (-3)   /* a per-image extent exceeds the kernel's 32-bit in-image offsets  */
+#define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
+
+/* ABI version of this header; bumped on any signature change. */
+#define CODETR_HIP_ABI_VERSION 1
+int codetr_hip_abi_version(void);
+/* Human-readable message for a code returned by any entry point (static storage). */
+const char *codetr_hip_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, forward.
+ *
+ * Replaces:  ms_deformable_im2col_cuda<T>(stream, value, spatial_shapes, level_start_index,
+ *            sampling_loc, attn_weight, batch, spatial_size, num_heads, channels, num_levels,
+ *            num_query, num_point, out)              codetr/csrc/ms_deform_attn.cu:762-779
+ *            and the argument contract of
+ *            codetr::ms_deform_attn_forward_reference codetr/csrc/ms_deform_attn.cu:899-956
+ *            (also what the TensorRT plugin's enqueue hands over,
+ *             codetr/csrc/deformable_attention_plugin.cpp:285-355).
+ *
+ *   value_dev          [B, S, M, D]          T     flattened multi-level value map
+ *   spatial_shapes_dev [L, 2]                int64 (H_l, W_l), read ON DEVICE (cu:236-239)
+ *   level_start_dev    [L]                   int64 first row of level l inside S
+ *   loc_dev            [B, Nq, M, L, P, 2]   T     (x, y) normalised to [0, 1]
+ *   weight_dev         [B, Nq, M, L, P]      T
+ *   out_dev            [B, Nq, M*D]          T     every element is written (no pre-zeroing
+ *                                                  needed; the reference zero-fills then
+ *                                                  overwrites, cu:936)
+ *   im2col_step        kept for API parity: validated exactly like cu:924-926, then the whole
+ *                      batch is processed by one launch.
+ *
+ * Semantics: out[b,q,m,c] = sum_l sum_p w[b,q,m,l,p] * bilinear(value_l[b,:,m,c], x*W_l-0.5,
+ * y*H_l-0.5) with zero padding per corner and the (-1, size) range gate (cu:31-77, 246-252).
+ * Coordinates, bilinear weights and the accumulation are fp32 for f16/bf16/f32 tensors
+ * (fp64 for f64) with one rounding at the store.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_msda_forward_f16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                            const int64_t *level_start_dev, const void *loc_dev, const void *weight_dev,
+                            int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step,
+                            void *out_dev);
+int codetr_msda_forward_bf16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                             const int64_t *level_start_dev, const void *loc_dev, const void *weight_dev,
+                             int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step,
+                             void *out_dev);
+int codetr_msda_forward_f32(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                            const int64_t *level_start_dev, const void *loc_dev, const void *weight_dev,
+                            int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step,
+                            void *out_dev);
+int codetr_msda_forward_f64(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                            const int64_t *level_start_dev, const void *loc_dev, const void *weight_dev,
+                            int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step,
+                            void *out_dev);
+
+/* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
+ * Pure host function; lets tests assert that the model shape takes the tiled path. */
+const char *codetr_msda_variant(int elem_bytes, int M, int D, int L, int P);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODETR_HIP_H_ */

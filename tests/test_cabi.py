@@ -1,0 +1,98 @@
+"""CPU: the C-ABI library loads and exports every symbol include/codetr_hip.h declares; pure-host
+entry points behave.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "codetr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(codetr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = _declared_symbols()
+    for s in ("codetr_msda_forward_f16", "codetr_msda_forward_bf16", "codetr_msda_forward_f32",
+              "codetr_msda_forward_f64", "codetr_hip_abi_version", "codetr_hip_strerror"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from codetr import _cabi
+
+    lib = ctypes.CDLL(_cabi.LIB_PATH)
+    for s in _declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/codetr_hip.h but not exported"
+    # and the ctypes table binds exactly the declared set
+    assert sorted(_cabi.SIGNATURES) == _declared_symbols()
+
+
+def test_host_only_entry_points():
+    from codetr import _cabi
+    import torch
+
+    lib = _cabi.load()
+    assert lib.codetr_hip_abi_version() == _cabi.ABI_VERSION
+    assert _cabi.strerror(0) == "success"
+    assert "im2col_step" in _cabi.strerror(-2)
+    # the model shape (M=8, D=32, L=5, P=4) must take the tiled kernel in fp16/bf16/fp32
+    assert _cabi.msda_variant(torch.float16, 8, 32, 5, 4) == "tiled_x4"
+    assert _cabi.msda_variant(torch.bfloat16, 8, 32, 5, 4) == "tiled_x4"
+    assert _cabi.msda_variant(torch.float32, 8, 32, 5, 4) == "tiled_x8"
+    assert _cabi.msda_variant(torch.float64, 8, 32, 5, 4) == "scalar"
+    assert _cabi.msda_variant(torch.float16, 2, 2, 2, 2) == "scalar"  # reference tiny case D=2
+
+
+def test_argument_validation_without_gpu():
+    """Contract errors are detected on the host before any launch, so they are testable here."""
+    from codetr import _cabi
+
+    lib = _cabi.load()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    assert lib.codetr_msda_forward_f16(null, null, one, one, one, one, 1, 1, 1, 8, 1, 1, 1, 64, one) == -1
+    assert lib.codetr_msda_forward_f16(null, one, one, one, one, one, 0, 1, 1, 8, 1, 1, 1, 64, one) == -1
+    assert lib.codetr_msda_forward_f32(null, one, one, one, one, one, 3, 1, 1, 8, 1, 1, 1, 2, one) == -2
+
+
+def test_op_is_registered_with_reference_schema():
+    import torch
+    import codetr  # noqa: F401
+
+    s = str(torch.ops.codetr.multi_scale_deformable_attention.default._schema)
+    assert s == ("codetr::multi_scale_deformable_attention(Tensor value, Tensor spatial_shapes, Tensor "
+                 "level_start_index, Tensor sampling_loc, Tensor attn_weight, int im2col_step) -> Tensor")
+
+
+def test_fake_kernel_shapes_and_checks():
+    import torch
+    import codetr  # noqa: F401
+
+    v = torch.empty(2, 21, 4, 16, device="meta", dtype=torch.float16)
+    ss = torch.empty(2, 2, device="meta", dtype=torch.int64)
+    ls = torch.empty(2, device="meta", dtype=torch.int64)
+    loc = torch.empty(2, 7, 4, 2, 3, 2, device="meta", dtype=torch.float16)
+    w = torch.empty(2, 7, 4, 2, 3, device="meta", dtype=torch.float16)
+    out = torch.ops.codetr.multi_scale_deformable_attention(v, ss, ls, loc, w, 64)
+    assert out.shape == (2, 7, 64) and out.dtype == torch.float16
+    with pytest.raises(RuntimeError):
+        torch.ops.codetr.multi_scale_deformable_attention(v, ss, ls, loc.float(), w, 64)
+
+
+def test_cpu_tensors_are_rejected_not_emulated():
+    """The product has no CPU formulation of the op: CPU tensors fail in the dispatcher."""
+    import torch
+    import codetr  # noqa: F401
+
+    v = torch.zeros(1, 4, 1, 8)
+    ss = torch.tensor([[2, 2]])
+    ls = torch.tensor([0])
+    loc = torch.zeros(1, 1, 1, 1, 1, 2)
+    w = torch.zeros(1, 1, 1, 1, 1)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.codetr.multi_scale_deformable_attention(v, ss, ls, loc, w, 64)
