@@ -314,16 +314,17 @@ def make_branches(num_pred=7, embed=256, num_classes=80):
     return cls_branches, reg_branches
 
 
-def randomize_(module: nn.Module, seed: int, scale: float = 1.0):
+def randomize_(module: nn.Module, seed: int, scale: float = 1.0, prefix: str = ""):
     """Seeded, non-degenerate parameters so every code path (bias, LN affine, rel-pos table)
-    contributes to the captured outputs.  Default mmdet init leaves many of them at 0/1."""
-    g = torch.Generator().manual_seed(seed)
+    contributes to the captured outputs (default mmdet init leaves many of them at 0/1).
+    Returns the ordered [(prefixed name, shape)] spec so a fixture can store it instead of the
+    weights; tests rebuild the same tensors with tests/helpers_model.seeded_params."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from helpers_model import seeded_params
+
+    spec = [(name, tuple(p.shape)) for name, p in module.named_parameters()]
+    vals = seeded_params(spec, seed, scale)
     with torch.no_grad():
         for name, p in module.named_parameters():
-            if p.dim() >= 2:
-                fan_in = p.shape[1] if p.dim() == 2 else p[0].numel()
-                p.copy_(torch.randn(p.shape, generator=g) * (scale / math.sqrt(max(fan_in, 1))))
-            elif name.endswith("weight"):  # norm scales
-                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
-            else:
-                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            p.copy_(vals[name])
+    return [(prefix + n, s) for n, s in spec]

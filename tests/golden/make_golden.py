@@ -126,7 +126,105 @@ def make_msda_goldens():
     )
 
 
-GROUPS = {"msda": make_msda_goldens}
+def _sd_np(module, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+sys.path.insert(0, os.path.join(HERE, ".."))
+from helpers_model import pack_param_spec  # noqa: E402
+
+
+def make_model_goldens():
+    """Module-level captures from the reference's own Python classes with seeded parameters.
+
+    Weights are NOT stored: every fixture stores the seed, and tests rebuild the identical
+    state_dict with tests/golden/_ref_import.randomize_ semantics re-stated in
+    tests/helpers_model.py (pure torch.Generator arithmetic, no reference code) -- except for the
+    small modules, whose weights are stored directly."""
+    import copy
+
+    tr = R.ref("transformer")
+    pe = R.ref("positional_encoding")
+    sw = R.ref("swin")
+    msda_mod = R.ref("multi_scale_deformable_attention")
+
+    # ---- G5: SinePositionalEncoding on a padded mask (cfg lsj:102-106) ----
+    enc = pe.SinePositionalEncoding(num_feats=128, temperature=20, normalize=True)
+    mask = torch.zeros(2, 7, 9, dtype=torch.bool)
+    mask[0, :, 7:] = True
+    mask[1, 5:, :] = True
+    mask[1, :, 8:] = True
+    _save("model_posenc", mask=mask, out=enc(mask, dtype=torch.float32))
+
+    # ---- G4: MultiScaleDeformableAttention.forward, 2-d and 4-d reference branches ----
+    torch.manual_seed(0)
+    m = msda_mod.MultiScaleDeformableAttention(embed_dims=256, num_levels=5, dropout=0.0).eval()
+    spec = R.randomize_(m, 101)
+    shapes = torch.tensor([[8, 12], [4, 6], [2, 3], [1, 2], [1, 1]])
+    S = int(shapes.prod(1).sum())
+    lsi = _lsi(shapes)
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    value = torch.randn(S, B, 256, generator=g)
+    qpos = torch.randn(S, B, 256, generator=g)
+    kpm = torch.zeros(B, S, dtype=torch.bool)
+    kpm[1, -7:] = True
+    ref2 = torch.rand(B, S, 5, 2, generator=g)
+    out2 = m(value, value=None, query_pos=qpos, key_padding_mask=kpm, reference_points=ref2, spatial_shapes=shapes,
+             level_start_index=lsi)
+    Nq = 13
+    q = torch.randn(Nq, B, 256, generator=g)
+    qp = torch.randn(Nq, B, 256, generator=g)
+    ref4 = torch.rand(B, Nq, 5, 4, generator=g) * 0.5 + 0.1
+    out4 = m(q, value=value, query_pos=qp, key_padding_mask=kpm, reference_points=ref4, spatial_shapes=shapes,
+             level_start_index=lsi)
+    _save("model_msda_module", spatial_shapes=shapes, level_start_index=lsi, value=value, query_pos=qpos,
+          key_padding_mask=kpm, ref2=ref2, out2=out2, query4=q, query_pos4=qp, ref4=ref4, out4=out4,
+          seed=np.int64(101), **pack_param_spec(spec))
+
+    # ---- G6: CoDinoTransformer (2 enc + 2 dec layers, 40 queries, FFN 64) on a 48x64-image pyramid ----
+    torch.manual_seed(0)
+    cfg = R.transformer_cfg(num_levels=5, num_layers=(2, 2), num_query=40, ffn=64)
+    t = tr.CoDinoTransformer(**copy.deepcopy(cfg)).eval()
+    t.level_embeds.data.zero_()
+    cls_b, reg_b = R.make_branches(num_pred=3, num_classes=80)
+    spec_t = R.randomize_(t, 202, prefix="query_head.transformer.")
+    spec_c = R.randomize_(cls_b, 203, prefix="query_head.cls_branches.")
+    spec_r = R.randomize_(reg_b, 204, prefix="query_head.reg_branches.")
+    g = torch.Generator().manual_seed(6)
+    shapes_l = [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]
+    B = 2
+    feats = [torch.randn(B, 256, h, w, generator=g) for h, w in shapes_l]
+    img_mask = torch.zeros(B, 48, 64)
+    img_mask[1, :, 52:] = 1  # right padding on image 1
+    img_mask[1, 40:, :] = 1  # bottom padding
+    masks = [torch.nn.functional.interpolate(img_mask[:, None], size=f.shape[-2:]).to(torch.bool).squeeze(1) for f in feats]
+    pos = [enc(mk, dtype=torch.float32) for mk in masks]
+    cap = {}
+    # capture encoder memory through a forward hook, everything else from the outputs
+    hk = t.encoder.register_forward_hook(lambda mod, a, out: cap.__setitem__("memory", out.permute(1, 0, 2)))
+    state, refs = t(feats, masks, pos, reg_branches=reg_b, cls_branches=cls_b)
+    hk.remove()
+    packed = {}
+    for tag, sp, seed in (("t", spec_t, 202), ("c", spec_c, 203), ("r", spec_r, 204)):
+        packed.update({f"{tag}.{k}": v for k, v in pack_param_spec(sp).items()})
+        packed[f"{tag}.seed"] = np.int64(seed)
+    _save("model_transformer", img_mask=img_mask, final_state=state, final_refs_unact=refs, memory=cap["memory"],
+          feat_seed=np.int64(6), **packed)
+
+    # ---- G7: Swin: tiny 2-stage backbone (C=32, heads 2/4, window 4), H/W not multiples of the window ----
+    torch.manual_seed(0)
+    s = sw.SwinTransformer(pretrain_img_size=64, embed_dims=32, depths=(2, 2), num_heads=(2, 4), window_size=4,
+                           strides=(4, 2), out_indices=(0, 1), drop_path_rate=0.0, patch_norm=True)
+    s.eval()
+    spec = R.randomize_(s, 303, scale=2.0, prefix="backbone.")
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(2, 3, 44, 58, generator=g)  # -> 11x15 tokens (pads to 12x16), then 6x8 (pads to 8x8)
+    outs = s(img)
+    _save("model_swin_tiny", img=img, out0=outs[0], out1=outs[1], seed=np.int64(303), **pack_param_spec(spec))
+
+
+GROUPS = {"msda": make_msda_goldens, "model": make_model_goldens}
 
 
 if __name__ == "__main__":
