@@ -1,0 +1,134 @@
+"""``CoDINOHead`` -- host-side mirror of reference codetr/co_dino_head.py:17-210.
+
+The reference derives from mmdet's ``DINOHead`` (third party); the parts of that constructor
+chain that matter at inference are restated here: ``num_classes``, ``cls_out_channels``
+(= num_classes for sigmoid losses), ``num_reg_fcs = 2``, ``as_two_stage``, ``test_cfg`` and the
+bias initialisation of the prediction branches.  Training-only arguments (losses' weights,
+``dn_cfg``, assigners ...) are accepted and ignored, as the reference ignores them at inference.
+"""
+import copy
+import math
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip_ops
+from .positional_encoding import SinePositionalEncoding
+from .transformer import CoDinoTransformer, run_mlp
+
+
+def bbox_cxcywh_to_xyxy(bbox):
+    """(cx, cy, w, h) -> (x1, y1, x2, y2)  (mmdet.structures.bbox.bbox_cxcywh_to_xyxy)."""
+    cx, cy, w, h = bbox.split((1, 1, 1, 1), dim=-1)
+    return torch.cat((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), dim=-1)
+
+
+class CoDINOHead(nn.Module):
+    def __init__(self, *args, num_query=900, transformer=None, in_channels=2048, max_pos_coords=300, dn_cfg=None,
+                 use_zero_padding=False,
+                 positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                 num_classes=80, embed_dims=256, num_reg_fcs=2, as_two_stage=False, sync_cls_avg_factor=False,
+                 loss_cls=dict(type="CrossEntropyLoss", use_sigmoid=False), loss_bbox=None, loss_iou=None,
+                 train_cfg=None, test_cfg=dict(max_per_img=100), init_cfg=None, **kwargs):
+        super().__init__()
+        transformer = copy.deepcopy(dict(transformer))
+        if "two_stage_num_proposals" in transformer:
+            if transformer["two_stage_num_proposals"] != num_query:
+                raise AssertionError("two_stage_num_proposals must be equal to num_query for DINO")
+        else:
+            transformer["two_stage_num_proposals"] = num_query
+        transformer["as_two_stage"] = True
+        self.num_query = num_query
+        self.num_classes = num_classes
+        self.num_reg_fcs = num_reg_fcs
+        self.as_two_stage = as_two_stage
+        self.train_cfg = train_cfg
+        self.test_cfg = dict(test_cfg) if test_cfg is not None else {}
+        self.use_sigmoid = bool(dict(loss_cls).get("use_sigmoid", False))
+        self.cls_out_channels = num_classes if self.use_sigmoid else num_classes + 1
+        if transformer.pop("type") != "CoDinoTransformer":
+            raise AssertionError("transformer must be CoDinoTransformer")
+        self.transformer = CoDinoTransformer(**transformer)
+        self.embed_dims = self.transformer.embed_dims
+        pe = dict(positional_encoding)
+        if pe.pop("type") != "SinePositionalEncoding":
+            raise AssertionError("positional_encoding must be SinePositionalEncoding")
+        self.positional_encoding = SinePositionalEncoding(**pe)
+        if self.positional_encoding.num_feats * 2 != self.embed_dims:
+            raise AssertionError(
+                f"embed_dims should be exactly 2 times of num_feats. Found {self.embed_dims} and "
+                f"{self.positional_encoding.num_feats}.")
+        self._init_layers()
+        self.max_per_img = self.test_cfg.get("max_per_img", self.num_query)
+
+    def _init_layers(self):
+        C = self.embed_dims
+        fc_cls = nn.Linear(C, self.cls_out_channels)
+        reg = []
+        for _ in range(self.num_reg_fcs):
+            reg += [nn.Linear(C, C), nn.ReLU()]
+        reg.append(nn.Linear(C, 4))
+        reg = nn.Sequential(*reg)
+        num_pred = self.transformer.decoder.num_layers + 1 if self.as_two_stage else self.transformer.decoder.num_layers
+        self.cls_branches = nn.ModuleList(copy.deepcopy(fc_cls) for _ in range(num_pred))
+        self.reg_branches = nn.ModuleList(copy.deepcopy(reg) for _ in range(num_pred))
+        # never used in forward; exists so that the published checkpoint's keys load (reference :115-118)
+        self.downsample = nn.Sequential(nn.Conv2d(C, C, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, C))
+
+    def init_weights(self):
+        """mmdet DeformableDETRHead.init_weights semantics + transformer init."""
+        self.transformer.init_weights()
+        if self.use_sigmoid:
+            prior = -math.log((1 - 0.01) / 0.01)
+            for m in self.cls_branches:
+                nn.init.constant_(m.bias, prior)
+        for m in self.reg_branches:
+            nn.init.zeros_(m[-1].weight)
+            nn.init.zeros_(m[-1].bias)
+        nn.init.constant_(self.reg_branches[0][-1].bias.data[2:], -2.0)
+        if self.as_two_stage:
+            for m in self.reg_branches:
+                nn.init.constant_(m[-1].bias.data[2:], 0.0)
+
+    def forward(self, mlvl_feats: List[torch.Tensor], img_masks: torch.Tensor, forced_topk_indices=None,
+                capture=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """mlvl_feats: list of [B,C,h,w]; img_masks [B,H,W] (0 = image, 1 = padding).
+        Returns boxes [B,K,4] (x1,y1,x2,y2 in input pixels), scores [B,K], labels [B,K] int64; K = max_per_img."""
+        Himg, Wimg = img_masks.shape[-2:]
+        masks, pos = [], []
+        m4 = img_masks.unsqueeze(1)
+        for f in mlvl_feats:
+            m = F.interpolate(m4, size=f.shape[-2:]).to(torch.bool).squeeze(1)  # nearest
+            masks.append(m)
+            pos.append(self.positional_encoding(m, dtype=f.dtype))
+        state, refs = self.transformer(mlvl_feats, masks, pos, reg_branches=self.reg_branches,
+                                       cls_branches=self.cls_branches if self.as_two_stage else None,
+                                       forced_topk_indices=forced_topk_indices, capture=capture)
+        lvl = len(self.transformer.decoder.layers) - 1
+        cls_head = self.cls_branches[lvl]
+        cls = hip_ops.linear(state, cls_head.weight, cls_head.bias)  # [B,Nq,classes]
+        tmp = run_mlp(self.reg_branches[lvl], state)
+        if refs.shape[-1] == 4:
+            tmp = tmp + refs
+        else:
+            if refs.shape[-1] != 2:
+                raise AssertionError("reference points must be 2-d or 4-d")
+            tmp = torch.cat((tmp[..., :2] + refs, tmp[..., 2:]), -1)
+        coords = tmp.sigmoid()
+        if capture is not None:
+            capture.update(final_state=state, final_refs_unact=refs, outputs_classes=cls, outputs_coords=coords)
+        B = coords.shape[0]
+        if self.use_sigmoid:
+            scores, idx = torch.topk(cls.sigmoid().view(B, -1), self.max_per_img, dim=-1)
+            labels = idx % self.num_classes
+            q = idx // self.num_classes
+        else:
+            s, labels_all = F.softmax(cls, dim=-1)[..., :-1].max(-1)
+            scores, q = torch.topk(s, self.max_per_img, dim=-1)
+            labels = torch.gather(labels_all, 1, q)
+        boxes = bbox_cxcywh_to_xyxy(torch.gather(coords, 1, q.unsqueeze(-1).expand(-1, -1, 4)))
+        scale = boxes.new_tensor([Wimg, Himg, Wimg, Himg])
+        boxes = torch.minimum((boxes * scale).clamp(min=0), scale)
+        return boxes, scores, labels

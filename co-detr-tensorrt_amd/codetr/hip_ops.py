@@ -1,0 +1,91 @@
+"""Functional compute layer of the host package: every tensor op the model modules need goes
+through one of these functions, so that "which kernel runs" is decided in exactly one place.
+
+GPU-only by design.  MSDA always runs the hand-written HIP kernel (C ABI).  The dense ops
+(linear / layer-norm / window attention / ...) run the hand-written kernels of libcodetr_hip.so
+where they exist (``NATIVE`` lists them) and PyTorch-ROCm library kernels otherwise -- PyTorch
+here is plumbing (rocBLAS / hipBLASLt / MIOpen behind ATen), used until the native kernel for
+that op lands, never as a fallback for a native kernel that exists.
+
+There is no CPU path: a CPU tensor reaching any of these functions is an error (the CPU
+formulation of the model lives in oracle/ and is test infrastructure).
+"""
+import torch
+import torch.nn.functional as F
+
+# ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
+NATIVE = {"msda"}
+
+
+def _gpu(x, what):
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"codetr.hip_ops.{what}: got a {x.device.type} tensor; this package computes on MI355X only "
+            "(the CPU formulation is the oracle in oracle/, not a fallback)"
+        )
+
+
+def linear(x, weight, bias=None, act=None, residual=None):
+    """y = act(x @ weight.T + bias) (+ residual);  act in {None, 'relu', 'gelu'}."""
+    _gpu(x, "linear")
+    y = F.linear(x, weight, bias)
+    if act == "relu":
+        y = F.relu(y, inplace=True)
+    elif act == "gelu":
+        y = F.gelu(y)
+    elif act is not None:
+        raise ValueError(act)
+    if residual is not None:
+        y = y + residual
+    return y
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    _gpu(x, "layer_norm")
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+def group_norm(x, groups, weight, bias, eps=1e-5):
+    _gpu(x, "group_norm")
+    return F.group_norm(x, groups, weight, bias, eps)
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0):
+    _gpu(x, "conv2d")
+    return F.conv2d(x, weight, bias, stride=stride, padding=padding)
+
+
+def window_attention(qkv, rel_bias, mask, num_heads):
+    """qkv [nWB, N, 3*C] (q|k|v, each head-major) ; rel_bias [nH, N, N]; mask [nW, N, N] or None.
+    Returns [nWB, N, C].  softmax((q*scale) k^T + bias (+mask)) v per window and head
+    (reference codetr/swin.py:92-112)."""
+    _gpu(qkv, "window_attention")
+    nWB, N, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // num_heads
+    qkv = qkv.view(nWB, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    attn = attn + rel_bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(nWB // nW, nW, num_heads, N, N) + mask[None, :, None]).view(nWB, num_heads, N, N)
+    attn = attn.softmax(-1)
+    return (attn @ v).transpose(1, 2).reshape(nWB, N, C)
+
+
+def mha_self_attention(q, k, v, num_heads):
+    """q,k,v [B, N, C] already projected -> [B, N, C] (dense softmax attention, 900x900 in the decoder)."""
+    _gpu(q, "mha_self_attention")
+    B, N, C = q.shape
+    hd = C // num_heads
+    sp = lambda t: t.view(B, -1, num_heads, hd).transpose(1, 2)  # noqa: E731
+    o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v))
+    return o.transpose(1, 2).reshape(B, N, C)
+
+
+def msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step):
+    """The reference's native op, hand-written HIP behind the C ABI (always native)."""
+    return torch.ops.codetr.multi_scale_deformable_attention(
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step
+    )

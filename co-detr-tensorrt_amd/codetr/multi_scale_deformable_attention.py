@@ -1,0 +1,135 @@
+"""``MultiScaleDeformableAttention`` module -- host-side mirror of the reference's
+codetr/multi_scale_deformable_attention.py:15-218 (same constructor kwargs, parameter names,
+forward signature, error behaviour), computing on MI355X through ``codetr.hip_ops``.
+
+Differences by design:
+* GPU only: the reference switches to a ``grid_sample`` formulation for CPU tensors (:207-210);
+  here a CPU tensor is an error (hip_ops), the CPU formulation is the oracle's job.
+* internally batch-first: ``forward_bf`` is what the encoder/decoder call; ``forward`` keeps the
+  reference's sequence-first default and just permutes around it.
+"""
+import math
+import warnings
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    def __init__(
+        self,
+        embed_dims: int = 256,
+        num_heads: int = 8,
+        num_levels: int = 4,
+        num_points: int = 4,
+        im2col_step: int = 64,
+        dropout: float = 0.1,
+        batch_first: bool = False,
+        norm_cfg: Optional[dict] = None,
+        init_cfg: Optional[dict] = None,
+        value_proj_ratio: float = 1.0,
+    ):
+        super().__init__()
+        if embed_dims % num_heads != 0:
+            raise ValueError(f"embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}")
+        dim_per_head = embed_dims // num_heads
+        if dim_per_head & (dim_per_head - 1):
+            warnings.warn(
+                "MultiScaleDeformableAttention: a per-head dimension that is not a power of two takes the "
+                "scalar HIP kernel instead of the tiled one"
+            )
+        self.norm_cfg = norm_cfg
+        self.init_cfg = init_cfg
+        self.dropout = nn.Dropout(dropout)  # identity at inference; kept for state/arg parity
+        self.batch_first = batch_first
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        value_proj_size = int(embed_dims * value_proj_ratio)
+        self.value_proj = nn.Linear(embed_dims, value_proj_size)
+        self.output_proj = nn.Linear(value_proj_size, embed_dims)
+        self.init_weights()
+
+    def init_weights(self) -> None:
+        """Directional grid for the offset bias, zero attention logits, Xavier projections
+        (same scheme as reference :90-115)."""
+        nn.init.zeros_(self.sampling_offsets.weight)
+        theta = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack((theta.cos(), theta.sin()), -1)
+        grid = grid / grid.abs().max(-1, keepdim=True)[0]
+        grid = grid.view(self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        grid = grid * torch.arange(1, self.num_points + 1, dtype=torch.float32).view(1, 1, -1, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid.reshape(-1))
+        nn.init.zeros_(self.attention_weights.weight)
+        nn.init.zeros_(self.attention_weights.bias)
+        for proj in (self.value_proj, self.output_proj):
+            nn.init.xavier_uniform_(proj.weight)
+            nn.init.zeros_(proj.bias)
+
+    # ------------------------------------------------------------------ batch-first core
+    def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
+                   level_start_index):
+        """query [B,Nq,C]; value [B,S,C]; returns output_proj(msda(...)) + identity, [B,Nq,C]."""
+        if query_pos is not None:
+            query = query + query_pos
+        B, Nq, _ = query.shape
+        S = value.shape[1]
+        H, L, P = self.num_heads, self.num_levels, self.num_points
+        v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias)
+        if key_padding_mask is not None:
+            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        v = v.view(B, S, H, -1)
+        offsets = hip_ops.linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias)
+        offsets = offsets.view(B, Nq, H, L, P, 2)
+        weights = hip_ops.linear(query, self.attention_weights.weight, self.attention_weights.bias)
+        weights = weights.view(B, Nq, H, L * P).softmax(-1).view(B, Nq, H, L, P)
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack((spatial_shapes[..., 1], spatial_shapes[..., 0]), -1).to(offsets.dtype)
+            loc = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            loc = (reference_points[:, :, None, :, None, :2]
+                   + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5)
+        else:
+            raise ValueError(
+                f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead."
+            )
+        out = hip_ops.msda(v.contiguous(), spatial_shapes, level_start_index, loc.contiguous(), weights.contiguous(),
+                           self.im2col_step)
+        return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
+
+    # ------------------------------------------------------------------ reference signature
+    def forward(
+        self,
+        query: torch.Tensor,
+        key: Optional[torch.Tensor] = None,
+        value: Optional[torch.Tensor] = None,
+        identity: Optional[torch.Tensor] = None,
+        query_pos: Optional[torch.Tensor] = None,
+        key_padding_mask: Optional[torch.Tensor] = None,
+        reference_points: Optional[torch.Tensor] = None,
+        spatial_shapes: Optional[torch.Tensor] = None,
+        level_start_index: Optional[torch.Tensor] = None,
+        **kwargs,
+    ) -> torch.Tensor:
+        """query ``(num_query, bs, embed_dims)`` (or batch-first if ``batch_first``), value likewise with
+        ``num_key``; reference_points ``(bs, num_query, num_levels, 2|4)``; returns query-shaped tensor
+        including the residual (``identity`` defaults to the un-positioned query)."""
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if not self.batch_first:
+            query, value, identity = query.permute(1, 0, 2), value.permute(1, 0, 2), identity.permute(1, 0, 2)
+            if query_pos is not None:
+                query_pos = query_pos.permute(1, 0, 2)
+        out = self.forward_bf(query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
+                              level_start_index)
+        return out if self.batch_first else out.permute(1, 0, 2)

@@ -1,0 +1,318 @@
+"""Swin Transformer backbone -- host-side mirror of reference codetr/swin.py:23-749 (+ the
+PatchEmbed / PatchMerging the reference imports from mmdet, equivalent source at
+codetr/transformer_mmcv.py:100-316).  Same class names, constructor kwargs and parameter names
+(``stages.{i}.blocks.{j}.attn.w_msa.qkv`` ...), eval-only, computing through ``codetr.hip_ops``.
+
+Things that depend only on shapes -- the gathered relative-position bias [nH,144,144] and the
+shifted-window mask [nW,144,144] -- are built once per (shape, dtype, device) and cached, instead
+of being rebuilt from -100 constants on every call (reference :191-222).
+"""
+import warnings
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip_ops
+from .transformer_layers import FFN, build_norm
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+class PatchEmbed(nn.Module):
+    """Non-overlapping conv patchify with bottom/right ("corner") zero padding + optional LN."""
+
+    def __init__(self, in_channels=3, embed_dims=768, conv_type="Conv2d", kernel_size=16, stride=16, padding="corner",
+                 dilation=1, bias=True, norm_cfg=None, input_size=None, init_cfg=None):
+        super().__init__()
+        if padding != "corner" or dilation != 1:
+            raise NotImplementedError("PatchEmbed: only 'corner' padding, dilation 1 (what Swin uses)")
+        self.embed_dims = embed_dims
+        self.kernel_size, self.stride = to_2tuple(kernel_size), to_2tuple(stride or kernel_size)
+        self.projection = nn.Conv2d(in_channels, embed_dims, self.kernel_size, self.stride, bias=bias)
+        self.norm = build_norm(norm_cfg, embed_dims) if norm_cfg is not None else None
+
+    def forward(self, x):
+        H, W = x.shape[-2:]
+        kh, kw = self.kernel_size
+        sh, sw = self.stride
+        ph = max((-(-H // sh) - 1) * sh + kh - H, 0)
+        pw = max((-(-W // sw) - 1) * sw + kw - W, 0)
+        if ph or pw:
+            x = F.pad(x, (0, pw, 0, ph))
+        x = hip_ops.conv2d(x, self.projection.weight, self.projection.bias, stride=self.stride)
+        hw = (x.shape[2], x.shape[3])
+        x = x.flatten(2).transpose(1, 2)
+        if self.norm is not None:
+            x = hip_ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x, hw
+
+
+class PatchMerging(nn.Module):
+    """2x2 neighbourhood -> 4C (nn.Unfold channel order: c*4 + ky*2 + kx) -> LN -> Linear(4C -> out)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=2, stride=None, padding="corner", dilation=1, bias=False,
+                 norm_cfg=dict(type="LN"), init_cfg=None):
+        super().__init__()
+        if to_2tuple(kernel_size) != (2, 2) or to_2tuple(stride or kernel_size) != (2, 2) or padding != "corner":
+            raise NotImplementedError("PatchMerging: only the 2x2 / stride-2 / corner-padded form Swin uses")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm = build_norm(norm_cfg, 4 * in_channels) if norm_cfg is not None else None
+        self.reduction = nn.Linear(4 * in_channels, out_channels, bias=bias)
+
+    def forward(self, x, input_size):
+        B, L, C = x.shape
+        H, W = input_size
+        if L != H * W:
+            raise AssertionError("input feature has wrong size")
+        x = x.view(B, H, W, C)
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        x = x.view(B, H2, 2, W2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H2 * W2, 4 * C)
+        if self.norm is not None:
+            x = hip_ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return hip_ops.linear(x, self.reduction.weight, self.reduction.bias), (H2, W2)
+
+
+class WindowMSA(nn.Module):
+    def __init__(self, embed_dims, num_heads, window_size, qkv_bias=True, qk_scale=None, attn_drop_rate=0.0,
+                 proj_drop_rate=0.0, init_cfg=None):
+        super().__init__()
+        self.embed_dims, self.window_size, self.num_heads = embed_dims, to_2tuple(window_size), num_heads
+        head_dim = embed_dims // num_heads
+        if qk_scale is not None and qk_scale != head_dim ** -0.5:
+            raise NotImplementedError("custom qk_scale")
+        self.scale = head_dim ** -0.5
+        Wh, Ww = self.window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * Wh - 1) * (2 * Ww - 1), num_heads))
+        # index (i, j) -> row of the table for offset (yi - yj + Wh - 1, xi - xj + Ww - 1)
+        coords = torch.stack(torch.meshgrid(torch.arange(Wh), torch.arange(Ww), indexing="ij")).flatten(1)
+        rel = coords[:, :, None] - coords[:, None, :]
+        index = (rel[0] + Wh - 1) * (2 * Ww - 1) + (rel[1] + Ww - 1)
+        self.register_buffer("relative_position_index", index.contiguous())
+        self.qkv = nn.Linear(embed_dims, embed_dims * 3, bias=qkv_bias)
+        self.proj = nn.Linear(embed_dims, embed_dims)
+        self._bias_cache = None
+
+    def init_weights(self):
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def relative_position_bias(self):
+        """[nH, N, N] gathered bias, cached until the table tensor changes (eval: never)."""
+        t = self.relative_position_bias_table
+        key = (t.data_ptr(), t._version, t.dtype, t.device)
+        if self._bias_cache is None or self._bias_cache[0] != key:
+            N = self.window_size[0] * self.window_size[1]
+            bias = t[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1).contiguous()
+            self._bias_cache = (key, bias.detach())
+        return self._bias_cache[1]
+
+    def forward(self, x, mask=None):
+        """x [nW*B, N, C] -> [nW*B, N, C]."""
+        qkv = hip_ops.linear(x, self.qkv.weight, self.qkv.bias)
+        o = hip_ops.window_attention(qkv, self.relative_position_bias(), mask, self.num_heads)
+        return hip_ops.linear(o, self.proj.weight, self.proj.bias)
+
+
+_MASK_CACHE = {}
+
+
+def shifted_window_mask(Hp, Wp, ws, shift, dtype, device):
+    """[nW, N, N] additive mask (0 / -100) separating the 9 regions of a cyclically shifted map."""
+    key = (Hp, Wp, ws, shift, dtype, str(device))
+    m = _MASK_CACHE.get(key)
+    if m is None:
+        region = torch.zeros(Hp, Wp, dtype=torch.float32)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                region[hs, wsl] = cnt
+                cnt += 1
+        r = region.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+        diff = r[:, None, :] - r[:, :, None]
+        m = torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).to(device=device, dtype=dtype)
+        _MASK_CACHE[key] = m
+    return m
+
+
+class ShiftWindowMSA(nn.Module):
+    def __init__(self, embed_dims, num_heads, window_size, shift_size=0, qkv_bias=True, qk_scale=None,
+                 attn_drop_rate=0, proj_drop_rate=0, dropout_layer=dict(type="DropPath", drop_prob=0.0), init_cfg=None):
+        super().__init__()
+        self.window_size, self.shift_size = window_size, shift_size
+        if not 0 <= shift_size < window_size:
+            raise AssertionError("shift_size must be in [0, window_size)")
+        self.w_msa = WindowMSA(embed_dims, num_heads, to_2tuple(window_size), qkv_bias, qk_scale, attn_drop_rate,
+                               proj_drop_rate)
+
+    def forward(self, query, hw_shape):
+        """query [B, H*W, C] (already normalised).  Padding to a multiple of the window is applied
+        here, AFTER norm1: pad tokens are exact zeros, come out of qkv as the bias and take part in
+        the softmax as ordinary keys (only the shift mask exists), then are cropped (reference :191-247)."""
+        B, L, C = query.shape
+        H, W = hw_shape
+        if L != H * W:
+            raise AssertionError("input feature has wrong size")
+        ws, sh = self.window_size, self.shift_size
+        x = query.view(B, H, W, C)
+        pad_r, pad_b = (-W) % ws, (-H) % ws
+        if pad_r or pad_b:
+            x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+        Hp, Wp = H + pad_b, W + pad_r
+        mask = None
+        if sh > 0:
+            x = torch.roll(x, shifts=(-sh, -sh), dims=(1, 2))
+            mask = shifted_window_mask(Hp, Wp, ws, sh, query.dtype, query.device)
+        win = x.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+        win = self.w_msa(win, mask)
+        x = win.view(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+        if sh > 0:
+            x = torch.roll(x, shifts=(sh, sh), dims=(1, 2))
+        if pad_r or pad_b:
+            x = x[:, :H, :W, :]
+        return x.reshape(B, H * W, C)
+
+
+class SwinBlock(nn.Module):
+    def __init__(self, embed_dims, num_heads, feedforward_channels, window_size=7, shift=False, qkv_bias=True,
+                 qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, act_cfg=dict(type="GELU"),
+                 norm_cfg=dict(type="LN"), with_cp=False, init_cfg=None):
+        super().__init__()
+        self.norm1 = build_norm(norm_cfg, embed_dims)
+        self.attn = ShiftWindowMSA(embed_dims, num_heads, window_size, window_size // 2 if shift else 0, qkv_bias,
+                                   qk_scale, attn_drop_rate, drop_rate)
+        self.norm2 = build_norm(norm_cfg, embed_dims)
+        self.ffn = FFN(embed_dims=embed_dims, feedforward_channels=feedforward_channels, num_fcs=2, ffn_drop=drop_rate,
+                       act_cfg=act_cfg, add_identity=True)
+
+    def forward(self, x, hw_shape):
+        h = hip_ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = x + self.attn(h, hw_shape)
+        h = hip_ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.ffn(h, identity=x)
+
+
+class SwinBlockSequence(nn.Module):
+    def __init__(self, embed_dims, num_heads, feedforward_channels, depth, window_size=7, qkv_bias=True, qk_scale=None,
+                 drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, downsample=None, act_cfg=dict(type="GELU"),
+                 norm_cfg=dict(type="LN"), with_cp=False, init_cfg=None):
+        super().__init__()
+        self.blocks = nn.ModuleList(
+            SwinBlock(embed_dims, num_heads, feedforward_channels, window_size, shift=bool(i % 2), qkv_bias=qkv_bias,
+                      qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate, act_cfg=act_cfg,
+                      norm_cfg=norm_cfg) for i in range(depth))
+        self.downsample = downsample
+
+    def forward(self, x, hw_shape):
+        for blk in self.blocks:
+            x = blk(x, hw_shape)
+        if self.downsample is not None:
+            x_down, down_hw = self.downsample(x, hw_shape)
+            return x_down, down_hw, x, hw_shape
+        return x, hw_shape, x, hw_shape
+
+
+class SwinTransformer(nn.Module):
+    def __init__(self, pretrain_img_size=224, in_channels=3, embed_dims=96, patch_size=4, window_size=7, mlp_ratio=4,
+                 depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), strides=(4, 2, 2, 2), out_indices=(0, 1, 2, 3),
+                 qkv_bias=True, qk_scale=None, patch_norm=True, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1,
+                 use_abs_pos_embed=False, act_cfg=dict(type="GELU"), norm_cfg=dict(type="LN"), with_cp=False,
+                 pretrained=None, convert_weights=False, frozen_stages=-1, init_cfg=None):
+        super().__init__()
+        if init_cfg and pretrained:
+            raise AssertionError("init_cfg and pretrained cannot be specified at the same time")
+        if isinstance(pretrained, str):
+            warnings.warn('DeprecationWarning: pretrained is deprecated, please use "init_cfg" instead')
+            init_cfg = dict(type="Pretrained", checkpoint=pretrained)
+        elif pretrained is not None:
+            raise TypeError("pretrained must be a str or None")
+        if use_abs_pos_embed:
+            raise NotImplementedError("absolute position embedding is not used by the Co-DETR configs")
+        self.init_cfg, self.convert_weights, self.frozen_stages = init_cfg, convert_weights, frozen_stages
+        self.out_indices = tuple(out_indices)
+        if strides[0] != patch_size:
+            raise AssertionError("Use non-overlapping patch embed.")
+        self.patch_embed = PatchEmbed(in_channels, embed_dims, "Conv2d", patch_size, strides[0],
+                                      norm_cfg=norm_cfg if patch_norm else None)
+        self.drop_after_pos = nn.Dropout(p=drop_rate)
+        self.stages = nn.ModuleList()
+        C = embed_dims
+        n = len(depths)
+        for i in range(n):
+            down = PatchMerging(C, 2 * C, stride=strides[i + 1], norm_cfg=norm_cfg if patch_norm else None) \
+                if i < n - 1 else None
+            self.stages.append(SwinBlockSequence(C, num_heads[i], mlp_ratio * C, depths[i], window_size, qkv_bias,
+                                                 qk_scale, drop_rate, attn_drop_rate, 0.0, down, act_cfg, norm_cfg))
+            if down is not None:
+                C = down.out_channels
+        self.num_features = [int(embed_dims * 2 ** i) for i in range(n)]
+        for i in self.out_indices:
+            self.add_module(f"norm{i}", build_norm(norm_cfg, self.num_features[i]))
+
+    def init_weights(self):
+        """Random init (no checkpoint): truncated-normal linears, unit LayerNorms (reference :660-667).
+        Loading published weights goes through ``codetr.checkpoint`` instead."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, WindowMSA):
+                m.init_weights()
+
+    def forward(self, x):
+        """[B,3,H,W] -> list of [B, C_i, H/2^(i+2), W/2^(i+2)] for i in out_indices."""
+        x, hw = self.patch_embed(x)
+        outs = []
+        for i, stage in enumerate(self.stages):
+            x, hw, out, out_hw = stage(x, hw)
+            if i in self.out_indices:
+                n = getattr(self, f"norm{i}")
+                out = hip_ops.layer_norm(out, n.weight, n.bias, n.eps)
+                outs.append(out.view(-1, *out_hw, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
+        return outs
+
+
+def swin_converter(ckpt):
+    """Official Swin checkpoint -> mmdet key names / unfold channel order (reference :752-803):
+    ``layers``->``stages``, ``attn.``->``attn.w_msa.``, ``mlp.fc1/fc2``->``ffn.layers.0.0/1``,
+    ``patch_embed.proj``->``projection``; PatchMerging reduction/norm channels regrouped from
+    (x0,x1,x2,x3) concatenation order to nn.Unfold's c*4 + k order."""
+    out = OrderedDict()
+
+    def regroup(t, last_dim):
+        C4 = t.shape[-1] if last_dim else t.shape[0]
+        g = t.reshape(*t.shape[:-1], 4, C4 // 4) if last_dim else t.reshape(4, C4 // 4)
+        g = g[..., [0, 2, 1, 3], :] if last_dim else g[[0, 2, 1, 3], :]
+        return g.transpose(-1, -2).reshape(t.shape)
+
+    for k, v in ckpt.items():
+        if k.startswith("head"):
+            continue
+        nk, nv = k, v
+        if k.startswith("layers"):
+            if "attn." in k:
+                nk = k.replace("attn.", "attn.w_msa.")
+            elif "mlp.fc1." in k:
+                nk = k.replace("mlp.fc1.", "ffn.layers.0.0.")
+            elif "mlp.fc2." in k:
+                nk = k.replace("mlp.fc2.", "ffn.layers.1.")
+            elif "mlp." in k:
+                nk = k.replace("mlp.", "ffn.")
+            elif "downsample" in k:
+                if "reduction." in k:
+                    nv = regroup(v, last_dim=True)
+                elif "norm." in k:
+                    nv = regroup(v, last_dim=False)
+            nk = nk.replace("layers", "stages", 1)
+        elif k.startswith("patch_embed") and "proj" in k:
+            nk = k.replace("proj", "projection")
+        out["backbone." + nk] = nv
+    return out

@@ -1,0 +1,283 @@
+"""Deformable encoder, DINO decoder and ``CoDinoTransformer`` -- host-side mirrors of reference
+codetr/transformer.py:16-93, 120-230, 280-400, 403-582 (same class names, constructor kwargs,
+parameter names and return values), batch-first inside and eval-only.
+
+Geometry that depends only on the feature-pyramid shape and the padding mask (reference points,
+proposal widths, level ids) is computed with torch on the device once per call; nothing here
+reads device data back to the host, so a whole forward is hipGraph-capturable.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops
+from .multi_scale_deformable_attention import MultiScaleDeformableAttention
+from .transformer_layers import BaseTransformerLayer, DetrTransformerDecoderLayer, build_norm
+
+
+class DetrTransformerEncoder(nn.Module):
+    def __init__(self, post_norm_cfg=dict(type="LN"), with_cp=-1, transformerlayers=None, num_layers=None,
+                 init_cfg=None):
+        super().__init__()
+        if not isinstance(transformerlayers, dict):
+            raise AssertionError("transformerlayers must be a dict")
+        layer_cfg = dict(transformerlayers)
+        if layer_cfg.pop("type") != "BaseTransformerLayer":
+            raise AssertionError("encoder layers must be BaseTransformerLayer")
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList(BaseTransformerLayer(**layer_cfg) for _ in range(num_layers))
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+        if post_norm_cfg is not None:
+            self.post_norm = build_norm(post_norm_cfg, self.embed_dims) if self.pre_norm else None
+        else:
+            if self.pre_norm:
+                raise AssertionError("pre-norm encoder needs post_norm_cfg")
+            self.post_norm = None
+
+    def forward_bf(self, query, query_pos, query_key_padding_mask, **kw):
+        for layer in self.layers:
+            query = layer.forward_bf(query, None, None, query_pos=query_pos,
+                                     query_key_padding_mask=query_key_padding_mask, **kw)
+        return query
+
+    def forward(self, query, key, value, query_pos=None, key_pos=None, attn_masks=None, query_key_padding_mask=None,
+                key_padding_mask=None, **kwargs):
+        """sequence-first in / out, as the reference (:52-92)."""
+        kwargs.pop("valid_ratios", None)
+        qp = None if query_pos is None else query_pos.transpose(0, 1)
+        return self.forward_bf(query.transpose(0, 1), qp, query_key_padding_mask, **kwargs).transpose(0, 1)
+
+
+def build_MLP(input_dim, hidden_dim, output_dim, num_layers):
+    if num_layers <= 1:
+        raise AssertionError(f"num_layers should be greater than 1 but got {num_layers}")
+    dims = [input_dim] + [hidden_dim] * (num_layers - 1)
+    layers = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        layers += [nn.Linear(a, b), nn.ReLU()]
+    layers.append(nn.Linear(hidden_dim, output_dim))
+    return nn.Sequential(*layers)
+
+
+def run_mlp(seq, x):
+    """nn.Sequential of Linear/ReLU through hip_ops (ReLU fused into the producing linear)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        fused = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        x = hip_ops.linear(x, lin.weight, lin.bias, act="relu" if fused else None)
+        i += 2 if fused else 1
+    return x
+
+
+class DinoTransformerDecoder(nn.Module):
+    def __init__(self, return_intermediate=False, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__()
+        if not isinstance(transformerlayers, dict):
+            raise AssertionError("transformerlayers must be a dict")
+        layer_cfg = dict(transformerlayers)
+        if layer_cfg.pop("type") != "DetrTransformerDecoderLayer":
+            raise AssertionError("decoder layers must be DetrTransformerDecoderLayer")
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList(DetrTransformerDecoderLayer(**layer_cfg) for _ in range(num_layers))
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+        self.return_intermediate = return_intermediate
+        self.ref_point_head = build_MLP(self.embed_dims * 2, self.embed_dims, self.embed_dims, 2)
+        self.norm = nn.LayerNorm(self.embed_dims)
+
+    @staticmethod
+    def gen_sineembed_for_position(pos_tensor, pos_feat):
+        """pos_tensor [..., 2|4] in [0,1] -> [..., len*pos_feat], blocks ordered (y, x[, w, h]),
+        temperature 10000 (reference :157-190)."""
+        i = torch.arange(pos_feat, dtype=pos_tensor.dtype, device=pos_tensor.device)
+        dim_t = 10000 ** (2 * (i // 2) / pos_feat)
+
+        def emb(c):
+            e = (c * (2 * math.pi))[..., None] / dim_t
+            return torch.stack((e[..., 0::2].sin(), e[..., 1::2].cos()), dim=-1).flatten(-2)
+
+        n = pos_tensor.size(-1)
+        if n == 2:
+            return torch.cat((emb(pos_tensor[..., 1]), emb(pos_tensor[..., 0])), dim=-1)
+        if n == 4:
+            return torch.cat((emb(pos_tensor[..., 1]), emb(pos_tensor[..., 0]), emb(pos_tensor[..., 2]),
+                              emb(pos_tensor[..., 3])), dim=-1)
+        raise ValueError(f"Unknown pos_tensor shape(-1):{n}")
+
+    def forward_bf(self, query, value, key_padding_mask, reference_points, valid_ratios, reg_branches, **kw):
+        """query [B,Nq,C], value [B,S,C], reference_points [B,Nq,4] unactivated."""
+        out = query
+        vr = torch.cat((valid_ratios, valid_ratios), -1) if reference_points.shape[-1] == 4 else valid_ratios
+        for lid, layer in enumerate(self.layers):
+            ref_in = reference_points[:, :, None].sigmoid() * vr[:, None]  # [B,Nq,L,4]
+            qpos = run_mlp(self.ref_point_head, self.gen_sineembed_for_position(ref_in[:, :, 0, :], self.embed_dims // 2))
+            out = layer.forward_bf(out, None, value, query_pos=qpos, key_padding_mask=key_padding_mask,
+                                   reference_points=ref_in, **kw)
+            if reg_branches is not None:
+                if reference_points.shape[-1] != 4:
+                    raise AssertionError("box refinement needs 4-d reference points")
+                reference_points = run_mlp(reg_branches[lid], out) + reference_points  # no detach / sigmoid
+        out = hip_ops.layer_norm(out, self.norm.weight, self.norm.bias, self.norm.eps)
+        return out, reference_points
+
+    def forward(self, query, *args, reference_points=None, valid_ratios=None, reg_branches=None, **kwargs):
+        """reference layout: query (Nq, bs, C), value kwarg (S, bs, C); returns ((bs,Nq,C), (bs,Nq,4))."""
+        value = kwargs.pop("value").transpose(0, 1)
+        kwargs.pop("key", None)
+        kwargs.pop("attn_masks", None)
+        return self.forward_bf(query.transpose(0, 1), value, kwargs.pop("key_padding_mask", None), reference_points,
+                               valid_ratios, reg_branches, **kwargs)
+
+
+# ----------------------------------------------------------------------------------------------
+# geometry helpers (reference :280-400)
+# ----------------------------------------------------------------------------------------------
+def get_valid_ratio(mask, dtype=torch.float32):
+    """mask [B,H,W] bool (True = padding) -> [B,2] (w_ratio, h_ratio)."""
+    _, H, W = mask.shape
+    vh = torch.sum(~mask[:, :, 0], 1).to(dtype) / H
+    vw = torch.sum(~mask[:, 0, :], 1).to(dtype) / W
+    return torch.stack((vw, vh), -1)
+
+
+def get_reference_points(mlvl_feats, valid_ratios, device):
+    """pixel centres of every level, normalised by the VALID extent -> [B, S, 2] (x, y)."""
+    out = []
+    for lvl, feat in enumerate(mlvl_feats):
+        B, _, H, W = feat.shape
+        ys, xs = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=feat.dtype, device=device),
+                                torch.linspace(0.5, W - 0.5, W, dtype=feat.dtype, device=device), indexing="ij")
+        y = ys.reshape(1, -1) / (valid_ratios[:, lvl, 1].reshape(B, 1) * H)
+        x = xs.reshape(1, -1) / (valid_ratios[:, lvl, 0].reshape(B, 1) * W)
+        out.append(torch.stack((x, y), -1))
+    return torch.cat(out, 1)
+
+
+def get_lvl_repeated(mlvl_masks, dtype=torch.float32):
+    return torch.cat([torch.full((m.shape[-2] * m.shape[-1],), float(lvl), dtype=dtype, device=m.device)
+                      for lvl, m in enumerate(mlvl_masks)], 0)
+
+
+def make_encoder_output_proposals_export(reference_points, mlvl_masks):
+    """[x, y, 0.05*2^lvl, 0.05*2^lvl] -> logit space, [B,S,4]."""
+    B, S = reference_points.shape[:2]
+    wh = (0.05 * (2.0 ** get_lvl_repeated(mlvl_masks, dtype=reference_points.dtype))).expand(B, S).reshape(B, S, 1)
+    prop = torch.cat((reference_points, wh, wh), dim=-1)
+    return torch.log(prop / (1 - prop))
+
+
+def make_encoder_output_proposals(reference_points, level_counts):
+    B, S = reference_points.shape[:2]
+    lvl = torch.repeat_interleave(
+        torch.arange(level_counts.shape[0], dtype=reference_points.dtype, device=reference_points.device), level_counts)
+    wh = (0.05 * (2.0 ** lvl)).expand(B, S).reshape(B, S, 1)
+    prop = torch.cat((reference_points, wh, wh), dim=-1)
+    return torch.log(prop / (1 - prop))
+
+
+def apply_mask_to_proposal_and_memory(output_proposals, memory, memory_padding_mask):
+    """proposals outside (-4.6, 4.6) or on padding -> finfo.max, their memory rows -> 0
+    (multiplicative form, as the reference :365-380)."""
+    dt = output_proposals.dtype
+    inside = ((output_proposals > -4.6) & (output_proposals < 4.6)).to(dt).prod(-1, keepdim=True)
+    keep = inside * (~memory_padding_mask).to(dt).unsqueeze(-1)
+    output_proposals = output_proposals * keep + (1.0 - keep) * torch.finfo(dt).max
+    return output_proposals, memory * keep + (1.0 - keep) * 0.0
+
+
+class CoDinoTransformer(nn.Module):
+    def __init__(self, with_pos_coord=True, with_coord_feat=True, num_co_heads=1, as_two_stage=False,
+                 num_feature_levels=4, two_stage_num_proposals=300, encoder=None, decoder=None, init_cfg=None):
+        super().__init__()
+        enc, dec = dict(encoder), dict(decoder)
+        if enc.pop("type") != "DetrTransformerEncoder":
+            raise AssertionError("encoder must be DetrTransformerEncoder")
+        if dec.pop("type") != "DinoTransformerDecoder":
+            raise AssertionError("decoder must be DinoTransformerDecoder")
+        self.encoder = DetrTransformerEncoder(**enc)
+        self.decoder = DinoTransformerDecoder(**dec)
+        self.embed_dims = self.encoder.embed_dims
+        self.with_pos_coord, self.with_coord_feat, self.num_co_heads = with_pos_coord, with_coord_feat, num_co_heads
+        self.as_two_stage = as_two_stage
+        self.num_feature_levels = num_feature_levels
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.init_layers()
+
+    def init_layers(self):
+        C = self.embed_dims
+        self.level_embeds = nn.Parameter(torch.zeros(self.num_feature_levels, C))
+        self.enc_output = nn.Linear(C, C)
+        self.enc_output_norm = nn.LayerNorm(C)
+        self.query_embed = nn.Embedding(self.two_stage_num_proposals, C)
+        # training-time aux-head position transforms: unused at inference, present so that the
+        # published checkpoint's keys load (reference :462-474)
+        if self.with_pos_coord and self.num_co_heads > 0:
+            self.aux_pos_trans = nn.ModuleList(nn.Linear(C * 2, C) for _ in range(self.num_co_heads))
+            self.aux_pos_trans_norm = nn.ModuleList(nn.LayerNorm(C) for _ in range(self.num_co_heads))
+            self.pos_feats_trans = nn.ModuleList()
+            self.pos_feats_norm = nn.ModuleList()
+            if self.with_coord_feat:
+                self.pos_feats_trans.extend(nn.Linear(C, C) for _ in range(self.num_co_heads))
+                self.pos_feats_norm.extend(nn.LayerNorm(C) for _ in range(self.num_co_heads))
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MultiScaleDeformableAttention):
+                m.init_weights()
+        nn.init.normal_(self.level_embeds)
+        nn.init.normal_(self.query_embed.weight)
+
+    def forward(self, mlvl_feats, mlvl_masks, mlvl_pos_embeds, reg_branches=None, cls_branches=None,
+                forced_topk_indices=None, capture=None, **kwargs):
+        """feats / pos_embeds: lists of [B,C,H,W]; masks: list of [B,H,W] bool.
+        Returns (final_state [B,Nq,C], final_references_unact [B,Nq,4]).
+
+        Two test hooks that do not exist in the reference: ``forced_topk_indices`` [B,Nq] replaces the
+        proposal top-k (parity checks on random weights, where top-k is unstable: reference
+        tests/test_export.py:638-655) and ``capture`` (a dict) receives intermediates."""
+        if not self.as_two_stage:
+            raise AssertionError("as_two_stage must be True for DINO")
+        dev = mlvl_feats[0].device
+        shapes = [tuple(f.shape[-2:]) for f in mlvl_feats]
+        feat = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)  # [B,S,C]
+        mask = torch.cat([m.flatten(1) for m in mlvl_masks], 1)  # [B,S]
+        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embeds[l].view(1, 1, -1)
+                         for l, p in enumerate(mlvl_pos_embeds)], 1)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=dev)
+        counts = spatial_shapes.prod(1)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), counts.cumsum(0)[:-1]))
+        valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
+        reference_points = get_reference_points(mlvl_feats, valid_ratios, device=dev)  # [B,S,2]
+        ref_by_level = reference_points[:, :, None] * valid_ratios[:, None]  # [B,S,L,2]
+
+        memory = self.encoder.forward_bf(feat, pos, mask, reference_points=ref_by_level, spatial_shapes=spatial_shapes,
+                                         level_start_index=level_start_index)
+        B = memory.shape[0]
+        proposals = make_encoder_output_proposals_export(reference_points, mlvl_masks)
+        proposals, out_mem = apply_mask_to_proposal_and_memory(proposals, memory, mask)
+        out_mem = hip_ops.linear(out_mem, self.enc_output.weight, self.enc_output.bias)
+        out_mem = hip_ops.layer_norm(out_mem, self.enc_output_norm.weight, self.enc_output_norm.bias,
+                                     self.enc_output_norm.eps)
+        last = self.decoder.num_layers  # branch index 6 = the two-stage proposal head
+        cls_head = cls_branches[last]
+        enc_cls = hip_ops.linear(out_mem, cls_head.weight, cls_head.bias)
+        enc_coord = run_mlp(reg_branches[last], out_mem) + proposals
+        if forced_topk_indices is None:
+            topk = torch.topk(enc_cls.max(-1)[0], self.two_stage_num_proposals, dim=1)[1]
+        else:
+            topk = forced_topk_indices
+        topk_coords = torch.gather(enc_coord, 1, topk.unsqueeze(-1).repeat(1, 1, 4))
+        query = self.query_embed.weight[None].expand(B, -1, -1)
+        if capture is not None:
+            capture.update(memory=memory, enc_outputs_class=enc_cls, enc_outputs_coord_unact=enc_coord,
+                           topk_indices=topk, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                           valid_ratios=valid_ratios)
+        return self.decoder.forward_bf(query, memory, mask, topk_coords, valid_ratios, reg_branches,
+                                       spatial_shapes=spatial_shapes, level_start_index=level_start_index)

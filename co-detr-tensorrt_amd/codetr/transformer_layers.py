@@ -1,0 +1,214 @@
+"""Transformer building blocks: ``FFN``, ``MultiheadAttention``, ``BaseTransformerLayer``,
+``DetrTransformerDecoderLayer`` -- host-side mirrors of reference codetr/transformer_mmcv.py:319-749
+and codetr/transformer.py:233-277 (same constructor kwargs incl. the deprecated
+``feedforward_channels`` / ``ffn_dropout`` / ``ffn_num_fcs`` spellings the configs use, same
+parameter names so mmdet checkpoints load).
+
+Internally every layer is batch-first ``[B, N, C]`` and eval-only (dropout / DropPath are the
+identity); the public ``forward`` of each class accepts the reference's sequence-first layout.
+"""
+import copy
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops
+from .multi_scale_deformable_attention import MultiScaleDeformableAttention
+
+
+def build_norm(cfg, dim):
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    cfg.pop("requires_grad", None)
+    if t == "LN":
+        return nn.LayerNorm(dim, **cfg)
+    if t == "GN":
+        return nn.GroupNorm(num_channels=dim, **cfg)
+    raise NotImplementedError(f"norm type {t}")
+
+
+def _act_name(act_cfg):
+    t = dict(act_cfg)["type"]
+    if t == "ReLU":
+        return "relu"
+    if t == "GELU":
+        return "gelu"
+    raise NotImplementedError(f"activation {t}")
+
+
+def _act_module(name):
+    return nn.ReLU(inplace=True) if name == "relu" else nn.GELU()
+
+
+class FFN(nn.Module):
+    """Linear -> act -> Linear (+ identity).  Parameter names: ``layers.0.0.*`` and ``layers.1.*``."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type="ReLU", inplace=True),
+                 ffn_drop=0.0, dropout_layer=None, add_identity=True, init_cfg=None, layer_scale_init_value=0.0):
+        super().__init__()
+        if num_fcs != 2:
+            raise NotImplementedError("only the 2-layer FFN of the Co-DETR configs is built")
+        if layer_scale_init_value > 0:
+            raise NotImplementedError("LayerScale is not used by the Co-DETR configs")
+        self.embed_dims, self.feedforward_channels, self.num_fcs = embed_dims, feedforward_channels, num_fcs
+        self.act = _act_name(act_cfg)
+        self.layers = nn.Sequential(
+            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), _act_module(self.act), nn.Dropout(ffn_drop)),
+            nn.Linear(feedforward_channels, embed_dims),
+            nn.Dropout(ffn_drop),
+        )
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        h = hip_ops.linear(x, fc1.weight, fc1.bias, act=self.act)
+        if not self.add_identity:
+            return hip_ops.linear(h, fc2.weight, fc2.bias)
+        return hip_ops.linear(h, fc2.weight, fc2.bias, residual=x if identity is None else identity)
+
+
+class MultiheadAttention(nn.Module):
+    """Self-attention with positional encodings added to q and k, residual included.
+    Parameters live in ``self.attn`` (an ``nn.MultiheadAttention``, for checkpoint key parity:
+    ``attn.in_proj_weight``, ``attn.in_proj_bias``, ``attn.out_proj.*``)."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0.0, proj_drop=0.0,
+                 dropout_layer=dict(type="Dropout", drop_prob=0.0), init_cfg=None, batch_first=False, **kwargs):
+        super().__init__()
+        if "dropout" in kwargs:  # deprecated spelling used by the configs
+            attn_drop = kwargs.pop("dropout")
+        self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)
+
+    def forward_bf(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                   key_padding_mask=None):
+        if attn_mask is not None or key_padding_mask is not None:
+            raise NotImplementedError("masked dense attention is not on the Co-DETR inference path")
+        key = query if key is None else key
+        value = key if value is None else value
+        identity = query if identity is None else identity
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        q = query + query_pos if query_pos is not None else query
+        k = key + key_pos if key_pos is not None else key
+        C = self.embed_dims
+        W, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        if q is k:
+            qk = hip_ops.linear(q, W[: 2 * C], b[: 2 * C])
+            qp, kp = qk[..., :C], qk[..., C:]
+        else:
+            qp = hip_ops.linear(q, W[:C], b[:C])
+            kp = hip_ops.linear(k, W[C: 2 * C], b[C: 2 * C])
+        vp = hip_ops.linear(value, W[2 * C:], b[2 * C:])
+        o = hip_ops.mha_self_attention(qp, kp, vp, self.num_heads)
+        return hip_ops.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, residual=identity)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                key_padding_mask=None, **kwargs):
+        if self.batch_first:
+            return self.forward_bf(query, key, value, identity, query_pos, key_pos, attn_mask, key_padding_mask)
+        t = lambda a: None if a is None else a.transpose(0, 1)  # noqa: E731
+        return self.forward_bf(t(query), t(key), t(value), t(identity), t(query_pos), t(key_pos), attn_mask,
+                               key_padding_mask).transpose(0, 1)
+
+
+class BaseTransformerLayer(nn.Module):
+    """Interpreter of an ``operation_order`` over attentions / norms / FFNs (post-norm or pre-norm)."""
+
+    def __init__(self, attn_cfgs=None,
+                 ffn_cfgs=dict(type="FFN", embed_dims=256, feedforward_channels=1024, num_fcs=2, ffn_drop=0.0,
+                               act_cfg=dict(type="ReLU", inplace=True)),
+                 operation_order=None, norm_cfg=dict(type="LN"), init_cfg=None, batch_first=False, **kwargs):
+        super().__init__()
+        ffn_cfgs = copy.deepcopy(ffn_cfgs)
+        for old, new in (("feedforward_channels", "feedforward_channels"), ("ffn_dropout", "ffn_drop"),
+                         ("ffn_num_fcs", "num_fcs")):
+            if old in kwargs:
+                ffn_cfgs[new] = kwargs[old]
+        allowed = {"self_attn", "norm", "ffn", "cross_attn"}
+        if not set(operation_order) <= allowed:
+            raise AssertionError(f"operation_order of {type(self).__name__} may only contain {sorted(allowed)}")
+        self.batch_first = batch_first
+        num_attn = operation_order.count("self_attn") + operation_order.count("cross_attn")
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(num_attn)]
+        else:
+            if num_attn != len(attn_cfgs):
+                raise AssertionError(f"{len(attn_cfgs)} attn_cfgs for {num_attn} attentions in {operation_order}")
+            attn_cfgs = [copy.deepcopy(c) for c in attn_cfgs]
+        self.num_attn = num_attn
+        self.operation_order = tuple(operation_order)
+        self.norm_cfg = norm_cfg
+        self.pre_norm = operation_order[0] == "norm"
+        self.attentions = nn.ModuleList()
+        for cfg in attn_cfgs:
+            cfg = dict(cfg)
+            cfg.setdefault("batch_first", batch_first)
+            kind = cfg.pop("type")
+            if kind == "MultiheadAttention":
+                self.attentions.append(MultiheadAttention(**cfg))
+            elif kind == "MultiScaleDeformableAttention":
+                self.attentions.append(MultiScaleDeformableAttention(**cfg))
+            else:
+                raise NotImplementedError(f"Not implemented {kind}")
+        self.embed_dims = self.attentions[0].embed_dims
+        self.ffns = nn.ModuleList()
+        for _ in range(operation_order.count("ffn")):
+            cfg = dict(copy.deepcopy(ffn_cfgs))
+            cfg.setdefault("embed_dims", self.embed_dims)
+            if cfg.pop("type", "FFN") != "FFN":
+                raise NotImplementedError("only FFN")
+            self.ffns.append(FFN(**cfg))
+        self.norms = nn.ModuleList(build_norm(norm_cfg, self.embed_dims) for _ in range(operation_order.count("norm")))
+
+    def forward_bf(self, query, key=None, value=None, query_pos=None, key_pos=None, query_key_padding_mask=None,
+                   key_padding_mask=None, **kw):
+        """batch-first walk of operation_order; `kw` carries reference_points / spatial_shapes /
+        level_start_index for the deformable attentions."""
+        ni = ai = fi = 0
+        identity = query
+        for op in self.operation_order:
+            if op in ("self_attn", "cross_attn"):
+                att = self.attentions[ai]
+                res = identity if self.pre_norm else None
+                if isinstance(att, MultiScaleDeformableAttention):
+                    val = query if op == "self_attn" else value
+                    mask = query_key_padding_mask if op == "self_attn" else key_padding_mask
+                    query = att.forward_bf(query, val, query if res is None else res, query_pos, mask,
+                                           kw["reference_points"], kw["spatial_shapes"], kw["level_start_index"])
+                else:
+                    if op == "self_attn":
+                        query = att.forward_bf(query, query, query, res, query_pos, query_pos)
+                    else:
+                        query = att.forward_bf(query, key, value, res, query_pos, key_pos)
+                ai += 1
+                identity = query
+            elif op == "norm":
+                n = self.norms[ni]
+                query = hip_ops.layer_norm(query, n.weight, n.bias, n.eps)
+                ni += 1
+            else:  # ffn
+                query = self.ffns[fi](query, identity if self.pre_norm else None)
+                fi += 1
+        return query
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        if attn_masks is not None:
+            raise NotImplementedError("attn_masks are not used on the Co-DETR inference path")
+        if self.batch_first:
+            return self.forward_bf(query, key, value, query_pos, key_pos, query_key_padding_mask, key_padding_mask,
+                                   **kwargs)
+        t = lambda a: None if a is None else a.transpose(0, 1)  # noqa: E731
+        return self.forward_bf(t(query), t(key), t(value), t(query_pos), t(key_pos), query_key_padding_mask,
+                               key_padding_mask, **kwargs).transpose(0, 1)
+
+
+class DetrTransformerDecoderLayer(BaseTransformerLayer):
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type="ReLU", inplace=True), norm_cfg=dict(type="LN"), ffn_num_fcs=2, **kwargs):
+        super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels, ffn_dropout=ffn_dropout,
+                         operation_order=operation_order, norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
+        if len(operation_order) != 6 or set(operation_order) != {"self_attn", "norm", "cross_attn", "ffn"}:
+            raise AssertionError("decoder layer needs ('self_attn','norm','cross_attn','norm','ffn','norm')")

@@ -224,7 +224,25 @@ def make_model_goldens():
     _save("model_swin_tiny", img=img, out0=outs[0], out1=outs[1], seed=np.int64(303), **pack_param_spec(spec))
 
 
-GROUPS = {"msda": make_msda_goldens, "model": make_model_goldens}
+def make_key_goldens():
+    """state_dict key names + shapes of the reference's Swin-L backbone and Co-DINO transformer built
+    from the config values (swin:10-27, lsj:58-101): the checkpoint-compatibility contract."""
+    import copy
+
+    sw = R.ref("swin")
+    tr = R.ref("transformer")
+    s = sw.SwinTransformer(pretrain_img_size=384, embed_dims=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48],
+                           window_size=12, mlp_ratio=4, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                           drop_path_rate=0.3, patch_norm=True, out_indices=(0, 1, 2, 3), with_cp=True,
+                           convert_weights=True)
+    t = tr.CoDinoTransformer(**copy.deepcopy(R.transformer_cfg()))
+    spec = [("backbone." + k, tuple(v.shape)) for k, v in s.state_dict().items()]
+    spec += [("query_head.transformer." + k, tuple(v.shape)) for k, v in t.state_dict().items()]
+    # relative_position_index VALUES of one window (the buffer is part of the checkpoint contract)
+    _save("state_dict_keys", rel_index=s.stages[0].blocks[0].attn.w_msa.relative_position_index, **pack_param_spec(spec))
+
+
+GROUPS = {"msda": make_msda_goldens, "model": make_model_goldens, "keys": make_key_goldens}
 
 
 if __name__ == "__main__":
