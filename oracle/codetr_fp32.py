@@ -428,6 +428,13 @@ def head(sd, feats, img_masks, p="query_head", num_query=900, max_per_img=300, n
     coords = (reg_branch(sd, f"{p}.reg_branches.{last}", state) + refs).sigmoid()
     if capture is not None:
         capture.update(final_state=state, final_refs_unact=refs, outputs_classes=cls, outputs_coords=coords)
+    return decode_detections(cls, coords, Himg, Wimg, max_per_img, num_classes)
+
+
+def decode_detections(cls, coords, Himg, Wimg, max_per_img=300, num_classes=80):
+    """class logits [B,Nq,C] + normalised cxcywh [B,Nq,4] -> (xyxy pixels [B,K,4], scores [B,K], labels [B,K]):
+    top-k over the flattened (query, class) sigmoid scores, label = idx % C, query = idx // C,
+    cxcywh -> xyxy, scale by (W,H), clamp to the image (reference co_dino_head.py:181-209)."""
     B = cls.shape[0]
     scores, idx = torch.topk(cls.sigmoid().view(B, -1), max_per_img, dim=-1)
     labels = idx % num_classes

@@ -19,7 +19,7 @@ def run():
     import codetr
     import codetr_fp32 as M
     import msda_oracle as O
-    from helpers_model import seeded_params
+    from helpers_model import assert_close_lowp, seeded_params
 
     assert torch.cuda.is_available(), "smoke() needs cuda:0"
     dev = "cuda:0"
@@ -40,7 +40,7 @@ def run():
     model = codetr.CoDETR(**_tiny_codetr_cfg("swin"))
     spec = [(k, tuple(v.shape)) for k, v in model.named_parameters()]
     full = dict(model.state_dict())
-    full.update(seeded_params(spec, 77, scale=1.5))
+    full.update(seeded_params(spec, 77, scale=1.0))
     model.load_state_dict(full)
     model = model.to(dev).half().eval()
     gen = torch.Generator().manual_seed(1)
@@ -56,7 +56,11 @@ def run():
                                       forced_topk_indices=cap_o["topk_indices"].to(dev), capture=cap)
     torch.cuda.synchronize()
     err = float((cap["memory"].float().cpu() - cap_o["memory"]).abs().max())
-    np.testing.assert_allclose(cap["memory"].float().cpu().numpy(), cap_o["memory"].numpy(), rtol=3e-2, atol=5e-2)
-    np.testing.assert_allclose(cap["outputs_coords"].float().cpu().numpy(), cap_o["outputs_coords"].numpy(), atol=3e-2)
+    for i, (a, b) in enumerate(zip(cap["neck_feats"], cap_o["neck_feats"])):
+        e = assert_close_lowp(a.float().cpu().numpy(), b.numpy(), 1e-2, None, f"neck level {i}")
+        print(f"[smoke]   neck level {i}: rel-L2 {e:.2e}")
+    rl2 = assert_close_lowp(cap["memory"].float().cpu().numpy(), cap_o["memory"].numpy(), 1.5e-2, 0.25, "encoder memory")
+    e = assert_close_lowp(cap["outputs_coords"].float().cpu().numpy(), cap_o["outputs_coords"].numpy(), 3e-2, 0.2, "box coords")
+    print(f"[smoke]   box coords (after 2 decoder layers): rel-L2 {e:.2e}")
     assert boxes.shape == (2, 20, 4) and scores.shape == (2, 20) and labels.dtype == torch.int64
-    print(f"[smoke] tiny CoDETR fp16 on {torch.cuda.get_device_name(0)} vs fp32 CPU oracle: encoder memory max abs err {err:.4f}")
+    print(f"[smoke] tiny CoDETR fp16 on {torch.cuda.get_device_name(0)} vs fp32 CPU oracle: encoder memory rel-L2 err {rl2:.2e}, max abs {err:.4f}")
