@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- Co-DINO Swin-L 1920x1280 fp16 inference throughput on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--res WxH]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (``CoDETR.forward``: Swin-L -> ChannelMapper -> CoDINOHead incl.
+12 MSDA HIP launches per image) over one batch of synthetic images already resident in HBM, random-init
+weights of the real architecture (no network: no checkpoint, no COCO).  Images shard across ranks
+(independent replicas, weights replicated); the only collective is one all_gather of the final detections
+[B,300,6] per step over RCCL.  Timing: W warm-up steps, then exactly K steps between
+barrier + torch.cuda.synchronize() on both sides, MAX over ranks.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line (N=1 only): ``roofline`` -- the MSDA gather kernel (the hand-written kernel
+this round) timed live with HIP events on its launch stream at the encoder shape of the same workload,
+priced with the algorithmic bytes of BASELINE.md section 3; ``cpu_baseline`` -- the fp32 CPU oracle
+(oracle/codetr_fp32.py + the C MSDA restatement) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "co-detr-tensorrt_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CFG = os.path.join(ROOT, "co-detr-tensorrt_amd", "configs", "co_dino_5scale_swin_l_16xb1_16e_o365tococo.py")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+
+
+def pyramid(h, w):
+    c = lambda a, b: -(-a // b)  # noqa: E731
+    lv = [(c(h, 4), c(w, 4)), (c(h, 8), c(w, 8)), (c(h, 16), c(w, 16)), (c(h, 32), c(w, 32))]
+    lv.append((c(lv[-1][0], 2), c(lv[-1][1], 2)))
+    return lv
+
+
+def msda_algorithmic_bytes(B, S, Nq, M=8, D=32, L=5, P=4, e=2):
+    """BASELINE.md section 3 / SURVEY.md 8(d): value + loc(2) + weight(1) + output, each touched once."""
+    return e * (B * S * M * D + 3 * B * Nq * M * L * P + B * Nq * M * D) + 24 * L
+
+
+def build_model(device, dtype, seed=42):
+    import codetr
+
+    torch.manual_seed(seed)
+    model = codetr.build_CoDETR(CFG, None, "cpu")
+    model.init_weights()  # seeded default init of every sub-module (random weights of the real architecture)
+    return model.to(device=device, dtype=dtype).eval()
+
+
+def msda_roofline(B, H, W, dtype, device, iters=30):
+    """Time the MSDA HIP kernel alone at the encoder shape (Nq = S) with HIP events on the launch stream."""
+    shapes = pyramid(H, W)
+    ss = torch.tensor(shapes, dtype=torch.int64, device=device)
+    ls = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
+    S = int(ss.prod(1).sum())
+    M, D, L, P = 8, 32, 5, 4
+    g = torch.Generator(device=device).manual_seed(0)
+    value = torch.randn(B, S, M, D, device=device, generator=g).to(dtype)
+    refs = []
+    for (h, w) in shapes:  # encoder-like sampling: own pixel centre + offsets of a few pixels
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, device=device) / h,
+                                torch.linspace(0.5, w - 0.5, w, device=device) / w, indexing="ij")
+        refs.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
+    ref = torch.cat(refs)[None, :, None, None, None, :]
+    norm = torch.stack((ss[:, 1], ss[:, 0]), -1).float()[None, None, None, :, None, :]
+    loc = (ref + torch.randn(B, S, M, L, P, 2, device=device, generator=g) * 3.0 / norm).to(dtype).contiguous()
+    w = torch.rand(B, S, M, L, P, device=device, generator=g)
+    w = (w / w.sum((-1, -2), keepdim=True)).to(dtype).contiguous()
+    op = torch.ops.codetr.multi_scale_deformable_attention
+    for _ in range(5):
+        op(value, ss, ls, loc, w, 64)
+    st = torch.cuda.current_stream(device)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(st)
+        op(value, ss, ls, loc, w, 64)
+        b.record(st)
+    torch.cuda.synchronize(device)
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    avg_s = sum(ts) / len(ts) * 1e-3
+    nbytes = msda_algorithmic_bytes(B, S, S, e=value.element_size())
+    achieved = nbytes / avg_s / 1e9
+    return {
+        "kernel": "msda_tiled_kernel<F16,4> (encoder call, Nq=S=%d, batch %d)" % (S, B),
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg_s * 1e6, 1),
+    }
+
+
+def cpu_baseline(model, H=608, W=608, full_hw=(1280, 1920)):
+    """fp32 CPU oracle on the host cores, one 608x608 image (bounded sample), scaled by pixel count."""
+    import codetr_fp32 as M
+
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    img = torch.randn(1, 3, H, W, generator=g)
+    mask = torch.zeros(1, H, W)
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        M.codetr_forward(sd, img, mask, backbone="swin", num_heads=(6, 12, 24, 48), window_size=12)
+    dt = time.perf_counter() - t0
+    scale = (H * W) / float(full_hw[0] * full_hw[1])
+    return {
+        "value": round(scale / dt, 5), "unit": "images/s", "cores": threads, "kind": "port",
+        "sample": f"1 image {W}x{H} through the fp32 CPU oracle (oracle/codetr_fp32.py + C MSDA, {threads} threads, "
+                  f"os.cpu_count()={os.cpu_count()}) took {dt:.1f} s; value = 1/t scaled by the pixel ratio "
+                  f"{scale:.3f} to {full_hw[1]}x{full_hw[0]}-equivalent images/s",
+        "seconds_for_sample": round(dt, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--res", default="1920x1280", help="WxH")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the forward from a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit(f"--gpus {a.gpus} needs the torch.distributed.run launcher (WORLD_SIZE is 1)")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[a.dtype]
+    W, H = (int(x) for x in a.res.split("x"))
+    model = build_model(device, dtype)
+    g = torch.Generator(device=device).manual_seed(42 + rank)
+    images = torch.randn(a.batch, 3, H, W, device=device, generator=g).to(dtype)  # ~ mean/std-normalised image
+    masks = torch.zeros(a.batch, H, W, device=device, dtype=dtype)
+    gathered = torch.empty(world * a.batch, 300, 6, device=device, dtype=torch.float32) if world > 1 else None
+
+    def forward():
+        with torch.no_grad():
+            boxes, scores, labels = model(images, masks)
+        return torch.cat((boxes.float(), scores.float()[..., None], labels.float()[..., None]), -1)  # [B,300,6]
+
+    static_out = None
+    graph = None
+    # eager warm-up first (builds the shape-keyed caches, lets the allocator settle)
+    for _ in range(max(2, min(a.warmup, 3))):
+        static_out = forward()
+    torch.cuda.synchronize(device)
+    if not a.no_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = forward()
+            graph.replay()
+            torch.cuda.synchronize(device)
+        except Exception as e:  # noqa: BLE001 -- report and run eagerly; the number is still valid, just launch-bound
+            if rank == 0:
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize(device)
+
+    def step():
+        nonlocal static_out
+        if graph is not None:
+            graph.replay()
+        else:
+            static_out = forward()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, static_out)
+
+    for _ in range(a.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    st = torch.cuda.current_stream(device)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    fence()
+    t0 = time.perf_counter()
+    evs[0].record(st)
+    for i in range(a.steps):
+        step()
+        evs[i + 1].record(st)
+    fence()
+    elapsed = time.perf_counter() - t0
+    per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_images = a.steps * a.batch * world
+        out = {
+            "metric": "images/sec, Co-DINO Swin-L %s %s (p50 ms/image alongside)" % (a.res, a.dtype),
+            "value": round(total_images / elapsed, 3),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "p50_ms_per_image": round(per_step_ms[len(per_step_ms) // 2] / a.batch, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[a.dtype],
+            "data": "synthetic (randn images already in HBM, zero padding masks; seeded random-init weights of the "
+                    "real architecture -- no checkpoint/COCO available offline)",
+            "config": {
+                "workload": "CoDETR.forward, Co-DINO 5-scale Swin-L, %s, batch %d per GPU, 900 queries, 300 detections"
+                            % (a.res, a.batch),
+                "global_batch": a.batch * world, "parallelism": "image-sharded replicas x%d" % world,
+                "hipgraph": graph is not None,
+                "native_kernels": sorted(__import__("codetr.hip_ops", fromlist=["NATIVE"]).NATIVE),
+            },
+            "reference_note": "reference publishes 79.5 ms/image (TensorRT fp16, RTX 4090, batch 1, README.md:33); "
+                              "not the same hardware, so vs_baseline stays null",
+        }
+        if world == 1 and not a.no_roofline:
+            out["roofline"] = msda_roofline(a.batch, H, W, dtype if dtype != torch.float32 else torch.float32, device)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,7 @@ class CoDINOHead(nn.Module):
                 f"embed_dims should be exactly 2 times of num_feats. Found {self.embed_dims} and "
                 f"{self.positional_encoding.num_feats}.")
         self._init_layers()
+        self._scale_cache = {}
         self.max_per_img = self.test_cfg.get("max_per_img", self.num_query)
 
     def _init_layers(self):
@@ -129,6 +130,9 @@ class CoDINOHead(nn.Module):
             scores, q = torch.topk(s, self.max_per_img, dim=-1)
             labels = torch.gather(labels_all, 1, q)
         boxes = bbox_cxcywh_to_xyxy(torch.gather(coords, 1, q.unsqueeze(-1).expand(-1, -1, 4)))
-        scale = boxes.new_tensor([Wimg, Himg, Wimg, Himg])
+        key = (Wimg, Himg, boxes.dtype, str(boxes.device))
+        scale = self._scale_cache.get(key)
+        if scale is None:  # built once per image size: no host->device copy in the steady state / under capture
+            scale = self._scale_cache[key] = boxes.new_tensor([Wimg, Himg, Wimg, Himg])
         boxes = torch.minimum((boxes * scale).clamp(min=0), scale)
         return boxes, scores, labels

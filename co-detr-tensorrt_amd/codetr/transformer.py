@@ -189,6 +189,22 @@ def apply_mask_to_proposal_and_memory(output_proposals, memory, memory_padding_m
     return output_proposals, memory * keep + (1.0 - keep) * 0.0
 
 
+_SHAPE_TENSORS = {}
+
+
+def _shape_tensors(shapes, device):
+    """(spatial_shapes [L,2] int64, level_start_index [L] int64) on `device`, built once per pyramid:
+    keeps host->device copies out of the steady state (and out of hipGraph capture)."""
+    key = (tuple(shapes), str(device))
+    hit = _SHAPE_TENSORS.get(key)
+    if hit is None:
+        ss = torch.as_tensor(shapes, dtype=torch.long, device=device)
+        counts = ss.prod(1)
+        hit = (ss, torch.cat((ss.new_zeros((1,)), counts.cumsum(0)[:-1])))
+        _SHAPE_TENSORS[key] = hit
+    return hit
+
+
 class CoDinoTransformer(nn.Module):
     def __init__(self, with_pos_coord=True, with_coord_feat=True, num_co_heads=1, as_two_stage=False,
                  num_feature_levels=4, two_stage_num_proposals=300, encoder=None, decoder=None, init_cfg=None):
@@ -250,9 +266,7 @@ class CoDinoTransformer(nn.Module):
         mask = torch.cat([m.flatten(1) for m in mlvl_masks], 1)  # [B,S]
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embeds[l].view(1, 1, -1)
                          for l, p in enumerate(mlvl_pos_embeds)], 1)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=dev)
-        counts = spatial_shapes.prod(1)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), counts.cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = _shape_tensors(shapes, dev)
         valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
         reference_points = get_reference_points(mlvl_feats, valid_ratios, device=dev)  # [B,S,2]
         ref_by_level = reference_points[:, :, None] * valid_ratios[:, None]  # [B,S,L,2]
