@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -26,6 +26,8 @@ SIGNATURES = {
     "codetr_msda_forward_f32": (_i32, _MSDA_ARGS),
     "codetr_msda_forward_f64": (_i32, _MSDA_ARGS),
     "codetr_msda_variant": (_cp, [_i32, _i32, _i32, _i32, _i32]),
+    "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
+    "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
 }
 
 _lib = None
@@ -100,3 +102,26 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
         raise RuntimeError(f"batch({B}) must divide im2col_step({min(B, int(im2col_step))})")
     check(rc, name)
     return out
+
+
+_ACT = {None: 0, "relu": 1, "gelu": 2}
+_LINEAR_BY_DTYPE = {torch.float16: "codetr_linear_f16", torch.bfloat16: "codetr_linear_bf16"}
+
+
+def linear_supported(x, weight) -> bool:
+    """Shapes / dtypes the native fused linear implements (K % 64 == 0, f16 / bf16)."""
+    return x.dtype in _LINEAR_BY_DTYPE and weight.dtype == x.dtype and weight.shape[1] % 64 == 0
+
+
+def linear(x2d, weight, bias, residual2d, act, out2d):
+    """Enqueue y = act(x @ w.T + b) (+ r) on torch's current stream.  x2d [M,K], weight [N,K] contiguous."""
+    lib = load()
+    M, K = x2d.shape
+    N = weight.shape[0]
+    rc = getattr(lib, _LINEAR_BY_DTYPE[x2d.dtype])(
+        current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(),
+        bias.data_ptr() if bias is not None else None,
+        residual2d.data_ptr() if residual2d is not None else None,
+        out2d.data_ptr(), M, N, K, _ACT[act])
+    check(rc, "codetr_linear")
+    return out2d

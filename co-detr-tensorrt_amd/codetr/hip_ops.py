@@ -13,8 +13,10 @@ formulation of the model lives in oracle/ and is test infrastructure).
 import torch
 import torch.nn.functional as F
 
+from . import _cabi
+
 # ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
-NATIVE = {"msda"}
+NATIVE = {"msda", "linear(f16/bf16, K%64==0)"}
 
 
 def _gpu(x, what):
@@ -28,6 +30,25 @@ def _gpu(x, what):
 def linear(x, weight, bias=None, act=None, residual=None):
     """y = act(x @ weight.T + bias) (+ residual);  act in {None, 'relu', 'gelu'}."""
     _gpu(x, "linear")
+    if _cabi.linear_supported(x, weight):
+        # hand-written MFMA GEMM with the bias / activation / residual folded into its epilogue
+        K = x.shape[-1]
+        N = weight.shape[0]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        r2 = None
+        if residual is not None:
+            r2 = residual.reshape(-1, N)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+        out = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
+        if x2.shape[0] > 0:
+            with torch.cuda.device(x.device):
+                _cabi.linear(x2, w, bias, r2, act, out)
+        return out.view(*x.shape[:-1], N)
+    # fp32 / odd-K layers (patch-embed is a conv; fp32 runs are parity runs): ATen library GEMM
     y = F.linear(x, weight, bias)
     if act == "relu":
         y = F.relu(y, inplace=True)

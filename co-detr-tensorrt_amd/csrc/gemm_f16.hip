@@ -1,0 +1,256 @@
+// Fused linear layer for MI355X (gfx950):  Y[M,N] = act(X[M,K] . W[N,K]^T + bias[N]) (+ R[M,N])
+// fp16 / bf16 storage, fp32 accumulation on the matrix cores (v_mfma_f32_16x16x32_{f16,bf16}).
+//
+// This is the GEMM behind every nn.Linear of the Co-DETR hot path (Swin qkv / proj / MLP, encoder
+// and decoder projections and FFNs, prediction heads: reference codetr/swin.py:91-115,
+// codetr/transformer_mmcv.py:484-500, codetr/multi_scale_deformable_attention.py:173-213), with the
+// bias add, ReLU/GELU and residual add that the reference runs as separate elementwise kernels
+// folded into the epilogue.
+//
+// Structure (cdna_hip_programming.md section 5, the 128x128 LDS-staged form):
+//   * one 256-thread workgroup (4 waves, 2x2) owns a 128(M) x 128(N) output tile; each wave a
+//     64x64 quadrant = 4x4 MFMA tiles of 16x16, K-step 64 (2 MFMAs deep per tile).
+//   * both operands are K-contiguous (X rows, W rows), so both tiles are staged the same way:
+//     global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), two LDS
+//     buffers, next K-tile in flight while the current one feeds the MFMAs.
+//   * LDS image = [128 rows][8 x 16-B chunks]; the DMA destination is lane-linear, so the
+//     bank-conflict swizzle is applied on the SOURCE address and undone on the fragment read:
+//     chunk position = chunk ^ ((row >> 1) & 7)  -> the 16 rows of a ds_read_b128 lane group
+//     land on 16 distinct 16-B slots of the 256-B bank row.
+//   * operands are swapped (MFMA "A" = W tile, "B" = X tile) so that the accumulator layout puts
+//     4 consecutive n of one output row m in each lane: the epilogue reads bias / residual and
+//     writes Y with 8-byte accesses, no transpose.
+//   * workgroup -> tile order is XCD-aware: each XCD walks a contiguous run of tiles, n fastest,
+//     so the X rows shared by the tiles of one m-row come from one L2.
+//
+// Requirements: K % 64 == 0, row pitches == K / N (dense row-major), 16-byte aligned bases.
+// M and N are arbitrary (edge tiles clamp their loads and mask their stores).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codetr_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kTileBytes = 128 * BK * 2;  // one operand tile: 16 KiB
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct HalfT {
+  using frag = f16x8;
+  __device__ static f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  __device__ static float to_f32(unsigned short bits) {
+    _Float16 h;
+    __builtin_memcpy(&h, &bits, 2);
+    return (float)h;
+  }
+  __device__ static unsigned short from_f32(float v) {
+    _Float16 h = (_Float16)v;
+    unsigned short bits;
+    __builtin_memcpy(&bits, &h, 2);
+    return bits;
+  }
+};
+struct BFloatT {
+  using frag = bf16x8;
+  __device__ static f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  __device__ static float to_f32(unsigned short bits) { return __uint_as_float(((unsigned)bits) << 16); }
+  __device__ static unsigned short from_f32(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+};
+
+__device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// Stage one 128 x 64 operand tile (rows row0.. of a [rows_total, K] matrix, columns k0..k0+63) into LDS.
+// 4 LDS-DMA instructions per thread; LDS 16-B unit index u = q*256 + tid -> row u/8, position u%8,
+// which holds source chunk (u%8) ^ ((row>>1)&7).
+__device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ src, int rows_total, int K, int row0, int k0,
+                                           unsigned char* lds_tile, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int u = q * kThreads + tid;
+    const int r = u >> 3, pos = u & 7;
+    const int chunk = pos ^ ((r >> 1) & 7);
+    int grow = row0 + r;
+    grow = grow < rows_total ? grow : rows_total - 1;  // edge tiles: re-read the last row, results masked later
+    const unsigned short* g = src + (size_t)grow * K + k0 + chunk * 8;
+    // wave-uniform LDS base of this instruction; the hardware adds lane*16
+    unsigned char* l = lds_tile + (q * kThreads + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  }
+}
+
+template <class T>
+__device__ __forceinline__ typename T::frag read_frag(const unsigned char* lds_tile, int row, int chunk) {
+  const int pos = chunk ^ ((row >> 1) & 7);
+  return *reinterpret_cast<const typename T::frag*>(lds_tile + row * 128 + pos * 16);
+}
+
+// ACT: 0 none, 1 relu, 2 gelu(erf)
+template <class T, int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* __restrict__ X,
+                                                          const unsigned short* __restrict__ W,
+                                                          const unsigned short* __restrict__ bias,
+                                                          const unsigned short* __restrict__ R,
+                                                          unsigned short* __restrict__ Y, int M, int N, int K,
+                                                          int tiles_n) {
+  // [buf][operand][16 KiB]; one object only (a second __shared__ object de-pipelines LDS-DMA kernels)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kTileBytes];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;  // wave quadrant inside the 128x128 tile
+
+  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x4 acc[4][4];  // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  stage_tile(W, N, K, n0, 0, lds, tid);
+  stage_tile(X, M, K, m0, 0, lds + kTileBytes, tid);
+  __syncthreads();  // (emits the vmcnt(0) that retires the LDS-DMA before the barrier)
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int cur = 0;
+  for (int t = 0; t < nk; ++t) {
+    unsigned char* bufW = lds + cur * 2 * kTileBytes;
+    unsigned char* bufX = bufW + kTileBytes;
+    if (t + 1 < nk) {
+      unsigned char* nW = lds + (cur ^ 1) * 2 * kTileBytes;
+      stage_tile(W, N, K, n0, (t + 1) * BK, nW, tid);
+      stage_tile(X, M, K, m0, (t + 1) * BK, nW + kTileBytes, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typename T::frag a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = read_frag<T>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = read_frag<T>(bufX, wm * 64 + j * 16 + frow, ks * 4 + fchunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds, for MFMA tile (i, j): n = n0 + wn*64 + i*16 + 4*(lane>>4) + r (r=0..3), m = m0 + wm*64 + j*16 + (lane&15)
+  const int ncol = 4 * (lane >> 4);
+  const bool n_vec_ok = (N & 3) == 0;  // 8-byte accesses need N % 4 == 0 (always true for row bases then)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + ncol;
+    if (n >= N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_BIAS) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) bv[r] = T::to_f32(bias[n + r]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + frow;
+      if (m >= M) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + bv[r];
+        if (ACT == 1) v[r] = fmaxf(v[r], 0.f);
+        if (ACT == 2) v[r] = gelu_erf(v[r]);
+      }
+      const size_t off = (size_t)m * N + n;
+      if (n_vec_ok && n + 3 < N) {
+        if (HAS_RES) {
+          const s16x4 rr = *reinterpret_cast<const s16x4*>(R + off);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += T::to_f32((unsigned short)rr[r]);
+        }
+        s16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (short)T::from_f32(v[r]);
+        *reinterpret_cast<s16x4*>(Y + off) = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < N) {
+            float x = v[r];
+            if (HAS_RES) x += T::to_f32(R[off + r]);
+            Y[off + r] = T::from_f32(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class T, int ACT>
+int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, int M, int N,
+               int K) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(kThreads);
+  auto x = static_cast<const unsigned short*>(X);
+  auto w = static_cast<const unsigned short*>(W);
+  auto b = static_cast<const unsigned short*>(bias);
+  auto r = static_cast<const unsigned short*>(R);
+  auto y = static_cast<unsigned short*>(Y);
+  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true>), grid, block, 0, st, x, w, b, r, y, M, N, K, tiles_n);
+  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false>), grid, block, 0, st, x, w, b, r, y, M, N, K, tiles_n);
+  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true>), grid, block, 0, st, x, w, b, r, y, M, N, K, tiles_n);
+  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false>), grid, block, 0, st, x, w, b, r, y, M, N, K, tiles_n);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+template <class T>
+int launch(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, int64_t M, int64_t N,
+           int64_t K, int act) {
+  if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return CODETR_E_BADARG;
+  if (K % BK != 0 || act < 0 || act > 2) return CODETR_E_UNSUPPORTED;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL || K > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if (((M + BM - 1) / BM) * ((N + BN - 1) / BN) > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) return CODETR_E_BADARG;
+  switch (act) {
+    case 0: return launch_act<T, 0>(st, X, W, bias, R, Y, (int)M, (int)N, (int)K);
+    case 1: return launch_act<T, 1>(st, X, W, bias, R, Y, (int)M, (int)N, (int)K);
+    default: return launch_act<T, 2>(st, X, W, bias, R, Y, (int)M, (int)N, (int)K);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_linear_f16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev, const void* residual_dev,
+                      void* y_dev, int64_t M, int64_t N, int64_t K, int act) {
+  return launch<HalfT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, M, N, K, act);
+}
+
+int codetr_linear_bf16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev,
+                       const void* residual_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act) {
+  return launch<BFloatT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, M, N, K, act);
+}
+
+}  // extern "C"

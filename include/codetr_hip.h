@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 1
+#define CODETR_HIP_ABI_VERSION 2
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -86,6 +86,32 @@ int codetr_msda_forward_f64(void *stream, const void *value_dev, const int64_t *
 /* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
  * Pure host function; lets tests assert that the model shape takes the tiled path. */
 const char *codetr_msda_variant(int elem_bytes, int M, int D, int L, int P);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused linear layer:  y[M,N] = act(x[M,K] . w[N,K]^T + bias[N]) (+ residual[M,N])
+ *
+ * Replaces, for the nn.Linear layers of the hot path, the ATen call sequence the reference runs
+ * per layer (addmm / bias add / ReLU or GELU / residual add as separate kernels):
+ *   Swin qkv / proj / MLP           codetr/swin.py:91-115, codetr/transformer_mmcv.py:484-500
+ *   MSDA value / offsets / weights / output projections
+ *                                   codetr/multi_scale_deformable_attention.py:173-213
+ *   encoder / decoder FFN, MHA projections, reference-point MLP, class / box branches
+ *                                   codetr/transformer.py:218, 551-557; codetr/co_dino_head.py:169-177
+ *
+ *   x_dev        [M, K]  row-major, dense            T (f16 / bf16)
+ *   w_dev        [N, K]  row-major (nn.Linear.weight) T
+ *   bias_dev     [N] or NULL                          T
+ *   residual_dev [M, N] or NULL (added AFTER the activation, as `identity + ffn(x)` does)   T
+ *   y_dev        [M, N]  (may alias residual_dev)     T
+ *   act          0 = none, 1 = ReLU, 2 = GELU (erf form, nn.GELU default)
+ *
+ * fp32 accumulation on the MFMA units, one rounding at the store.  K must be a multiple of 64
+ * (every Linear of the model is; CODETR_E_UNSUPPORTED otherwise); x / w 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_linear_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                      const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act);
+int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                       const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act);
 
 #ifdef __cplusplus
 }

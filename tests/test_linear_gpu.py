@@ -1,0 +1,101 @@
+"""GPU parity of the hand-written MFMA linear kernel (C ABI codetr_linear_{f16,bf16}) against a
+plain PyTorch fp32 reference of the same op:  y = act(x @ w.T + b) (+ r).
+
+Tolerance: inputs are exactly representable (fp16/bf16), accumulation is fp32 on both sides, so the
+only differences are summation order and the single output rounding: |err| <= 2^-10 |y| + K * 2^-22
+scale for fp16 (1 ulp of the rounded result + fp32 accumulation noise), 2^-7 for bf16."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(x, w, b, r, act):
+    y = x.float() @ w.float().t()
+    if b is not None:
+        y = y + b.float()
+    if act == "relu":
+        y = torch.relu(y)
+    elif act == "gelu":
+        y = torch.nn.functional.gelu(y)
+    if r is not None:
+        y = y + r.float()
+    return y
+
+
+def _check(M, N, K, dtype, bias, act, res, seed=0):
+    from codetr import hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = (torch.randn(M, K, device=DEV, generator=g)).to(dtype)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, device=DEV, generator=g).to(dtype) if bias else None
+    r = torch.randn(M, N, device=DEV, generator=g).to(dtype) if res else None
+    y = hip_ops.linear(x, w, b, act=act, residual=r)
+    torch.cuda.synchronize()
+    ref = _ref(x, w, b, r, act)
+    assert y.shape == (M, N) and y.dtype == dtype
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    tol = ulp * ref.abs() + 1e-3 * ulp * 64
+    bad = (y.float() - ref).abs() > tol + K * 2.0 ** -22
+    assert not bad.any(), f"{int(bad.sum())} / {bad.numel()} outside 1 ulp; max err {(y.float() - ref).abs().max().item()}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [
+    (128, 128, 64),        # exactly one tile, one K step
+    (256, 256, 256),
+    (1, 1, 64),            # degenerate edges
+    (130, 4, 256),         # box-regression head: N = 4
+    (900, 80, 256),        # class head: N = 80 (not a multiple of 16)
+    (333, 161, 192),       # ragged M and N, N % 4 != 0 -> scalar store path
+    (1000, 320, 256),      # sampling offsets
+    (4097, 576, 192),      # Swin stage-0 qkv shape class
+    (2880, 1536, 6144),    # Swin stage-3 fc2: long K
+])
+def test_linear_shapes(M, N, K, dtype):
+    _check(M, N, K, dtype, bias=True, act=None, res=False)
+
+
+@pytest.mark.parametrize("bias,act,res", [(False, None, False), (True, "relu", False), (True, "gelu", False),
+                                          (True, None, True), (False, "relu", True), (True, "gelu", True)])
+def test_linear_epilogues(bias, act, res):
+    _check(517, 384, 384, torch.float16, bias, act, res, seed=3)
+
+
+def test_linear_model_shape_encoder_ffn():
+    """encoder FFN at the 608x608 pyramid: M = 30785, 256 -> 2048 (ReLU) -> 256 (+ identity)."""
+    _check(30785, 2048, 256, torch.float16, True, "relu", False, seed=1)
+    _check(30785, 256, 2048, torch.float16, True, None, True, seed=2)
+
+
+def test_linear_batched_view_and_noncontiguous_input():
+    from codetr import hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(3, 50, 128, device=DEV, generator=g).half()
+    w = torch.randn(64, 128, device=DEV, generator=g).half() * 0.1
+    b = torch.randn(64, device=DEV, generator=g).half()
+    y = hip_ops.linear(x, w, b)
+    assert y.shape == (3, 50, 64)
+    torch.testing.assert_close(y.float(), _ref(x.reshape(-1, 128), w, b, None, None).view(3, 50, 64), rtol=2e-3, atol=2e-3)
+    xt = x.transpose(0, 1)  # non-contiguous view
+    yt = hip_ops.linear(xt, w, b)
+    torch.testing.assert_close(yt, y.transpose(0, 1))
+    # sliced weight (the fused q|k in-projection of nn.MultiheadAttention is passed as a row slice)
+    w2 = torch.randn(192, 128, device=DEV, generator=g).half() * 0.1
+    y2 = hip_ops.linear(x, w2[64:128], None)
+    torch.testing.assert_close(y2.float(), _ref(x.reshape(-1, 128), w2[64:128], None, None, None).view(3, 50, 64),
+                               rtol=2e-3, atol=2e-3)
+
+
+def test_linear_unsupported_k_is_loud():
+    from codetr import _cabi
+
+    x = torch.zeros(8, 48, device=DEV, dtype=torch.float16)
+    w = torch.zeros(8, 48, device=DEV, dtype=torch.float16)
+    out = torch.empty(8, 8, device=DEV, dtype=torch.float16)
+    assert not _cabi.linear_supported(x, w)
+    with pytest.raises(RuntimeError, match="outside what the kernel family implements"):
+        _cabi.linear(x, w, None, None, None, out)
