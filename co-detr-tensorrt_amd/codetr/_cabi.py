@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -28,6 +28,8 @@ SIGNATURES = {
     "codetr_msda_variant": (_cp, [_i32, _i32, _i32, _i32, _i32]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
+    "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
+    "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
 }
 
 _lib = None
@@ -124,4 +126,21 @@ def linear(x2d, weight, bias, residual2d, act, out2d):
         residual2d.data_ptr() if residual2d is not None else None,
         out2d.data_ptr(), M, N, K, _ACT[act])
     check(rc, "codetr_linear")
+    return out2d
+
+
+_LN_BY_DTYPE = {torch.float16: "codetr_layernorm_f16", torch.bfloat16: "codetr_layernorm_bf16"}
+
+
+def layernorm_supported(x, weight) -> bool:
+    C = x.shape[-1]
+    return x.dtype in _LN_BY_DTYPE and weight is not None and weight.dtype == x.dtype and C % 8 == 0 and C <= 4096
+
+
+def layernorm(x2d, weight, bias, eps, out2d):
+    rows, C = x2d.shape
+    rc = getattr(load(), _LN_BY_DTYPE[x2d.dtype])(
+        current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(), bias.data_ptr(), out2d.data_ptr(),
+        rows, C, float(eps))
+    check(rc, "codetr_layernorm")
     return out2d

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from . import _cabi
 
 # ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
-NATIVE = {"msda", "linear(f16/bf16, K%64==0)"}
+NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)"}
 
 
 def _gpu(x, what):
@@ -63,7 +63,17 @@ def linear(x, weight, bias=None, act=None, residual=None):
 
 def layer_norm(x, weight, bias, eps=1e-5):
     _gpu(x, "layer_norm")
-    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+    if _cabi.layernorm_supported(x, weight):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        out = torch.empty_like(x2)
+        if x2.shape[0] > 0:
+            with torch.cuda.device(x.device):
+                _cabi.layernorm(x2, weight, bias, eps, out)
+        return out.view(x.shape)
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)  # fp32 parity runs
 
 
 def group_norm(x, groups, weight, bias, eps=1e-5):

@@ -18,8 +18,9 @@
 //     chunk position = chunk ^ ((row >> 1) & 7)  -> the 16 rows of a ds_read_b128 lane group
 //     land on 16 distinct 16-B slots of the 256-B bank row.
 //   * operands are swapped (MFMA "A" = W tile, "B" = X tile) so that the accumulator layout puts
-//     4 consecutive n of one output row m in each lane: the epilogue reads bias / residual and
-//     writes Y with 8-byte accesses, no transpose.
+//     4 consecutive n of one output row m in each lane; the epilogue applies bias + activation on
+//     the accumulators, passes the tile through LDS once and stores whole 128-byte lines
+//     (16 B per lane) with the residual added on the way out.
 //   * workgroup -> tile order is XCD-aware: each XCD walks a contiguous run of tiles, n fastest,
 //     so the X rows shared by the tiles of one m-row come from one L2.
 //
@@ -40,6 +41,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct HalfT {
@@ -73,7 +75,21 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// nn.GELU (erf form): 0.5 x (1 + erf(x / sqrt 2)).  libm's erff costs ~50 VALU ops per element and made the
+// GELU epilogues VALU-bound; erf is evaluated with Abramowitz-Stegun 7.1.26 instead
+// (1 v_rcp + 1 v_exp + 7 FMA, |erf error| <= 1.5e-7, i.e. < 2^-22 relative on the output: three orders
+// of magnitude below the fp16/bf16 rounding of the result).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);  // erf(|x|/sqrt2)
+  const float erf_v = x < 0.f ? -e : e;
+  return 0.5f * x * (1.0f + erf_v);
+}
 
 // Stage one 128 x 64 operand tile (rows row0.. of a [rows_total, K] matrix, columns k0..k0+63) into LDS.
 // 4 LDS-DMA instructions per thread; LDS 16-B unit index u = q*256 + tid -> row u/8, position u%8,
@@ -157,9 +173,62 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
     cur ^= 1;
   }
 
-  // ---- epilogue: lane holds, for MFMA tile (i, j): n = n0 + wn*64 + i*16 + 4*(lane>>4) + r (r=0..3), m = m0 + wm*64 + j*16 + (lane&15)
+  // ---- epilogue -------------------------------------------------------------------------------
+  // accumulator layout: for MFMA tile (i, j) a lane holds n = wn*64 + i*16 + 4*(lane>>4) + r (r = 0..3),
+  // m = wm*64 + j*16 + (lane&15), i.e. 8 contiguous output bytes per lane and 32-byte row segments per
+  // store instruction.  Partial-line stores of that shape run at ~1 TB/s, so the tile goes through LDS
+  // once and leaves as whole 128-byte lines (16 B per lane): bias + activation in fp32 on the
+  // accumulators -> fp16 image of the wave's 64x64 quadrant in its private LDS region -> read back by
+  // rows, add the residual (fp16 + fp16 -> fp16, the same two roundings as `identity + linear(x)`
+  // in the reference's fp16 path) -> global_store_dwordx4.
   const int ncol = 4 * (lane >> 4);
-  const bool n_vec_ok = (N & 3) == 0;  // 8-byte accesses need N % 4 == 0 (always true for row bases then)
+  if ((N & 7) == 0) {
+    constexpr int kPitch = 64 * 2 + 16;  // bytes per staged row (+16: rows 0/8 do not share a bank pair)
+    unsigned char* stage = lds + wave * (64 * kPitch);  // main loop is done with LDS (barrier above)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + ncol;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (HAS_BIAS && n < N) {  // N % 8 == 0 and n % 4 == 0: the 4 columns are all inside or all outside
+        const s16x4 bb = *reinterpret_cast<const s16x4*>(bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = T::to_f32((unsigned short)bb[r]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][r] + bv[r];
+          if (ACT == 1) v = v < 0.f ? 0.f : v;  // NaN-propagating, like torch.relu
+          if (ACT == 2) v = gelu_erf(v);
+          o[r] = (short)T::from_f32(v);
+        }
+        *reinterpret_cast<s16x4*>(stage + (j * 16 + frow) * kPitch + (i * 16 + ncol) * 2) = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // same wave writes then reads: DS ops retire in order
+    const int srow = lane >> 3, schunk = lane & 7;
+    const int n = n0 + wn * 64 + schunk * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int ml = it * 8 + srow;
+      const int m = m0 + wm * 64 + ml;
+      if (m < M && n < N) {
+        s16x8 v = *reinterpret_cast<const s16x8*>(stage + ml * kPitch + schunk * 16);
+        const size_t off = (size_t)m * N + n;
+        if (HAS_RES) {
+          const s16x8 rr = *reinterpret_cast<const s16x8*>(R + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[e]));
+        }
+        *reinterpret_cast<s16x8*>(Y + off) = v;
+      }
+    }
+    return;
+  }
+  // ragged N (N % 8 != 0: the 4-wide box head, test shapes): direct stores from the accumulator layout
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + wn * 64 + i * 16 + ncol;
@@ -174,32 +243,16 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + wm * 64 + j * 16 + frow;
       if (m >= M) continue;
-      float v[4];
+      const size_t off = (size_t)m * N + n;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc[i][j][r] + bv[r];
-        if (ACT == 1) v[r] = fmaxf(v[r], 0.f);
-        if (ACT == 2) v[r] = gelu_erf(v[r]);
-      }
-      const size_t off = (size_t)m * N + n;
-      if (n_vec_ok && n + 3 < N) {
-        if (HAS_RES) {
-          const s16x4 rr = *reinterpret_cast<const s16x4*>(R + off);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += T::to_f32((unsigned short)rr[r]);
-        }
-        s16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (short)T::from_f32(v[r]);
-        *reinterpret_cast<s16x4*>(Y + off) = o;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r < N) {
-            float x = v[r];
-            if (HAS_RES) x += T::to_f32(R[off + r]);
-            Y[off + r] = T::from_f32(x);
-          }
+        if (n + r < N) {
+          float v = acc[i][j][r] + bv[r];
+          if (ACT == 1) v = v < 0.f ? 0.f : v;
+          if (ACT == 2) v = gelu_erf(v);
+          unsigned short h = T::from_f32(v);
+          if (HAS_RES) h = T::from_f32(T::to_f32(h) + T::to_f32(R[off + r]));
+          Y[off + r] = h;
         }
       }
     }

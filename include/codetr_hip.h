@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 2
+#define CODETR_HIP_ABI_VERSION 3
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -112,6 +112,19 @@ int codetr_linear_f16(void *stream, const void *x_dev, const void *w_dev, const 
                       const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act);
 int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                        const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension: y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta
+ *
+ * Replaces at::native::layer_norm behind every nn.LayerNorm of the hot path (built through mmcv's
+ * build_norm_layer at codetr/swin.py:331,345,627 and codetr/transformer_mmcv.py:647; nn.LayerNorm at
+ * codetr/transformer.py:153,452).  x, y [rows, C] dense row-major (y may alias x); gamma, beta [C];
+ * fp32 statistics (two-pass), one rounding at the store.  C % 8 == 0, C <= 4096.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_layernorm_f16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev, void *y_dev,
+                         int64_t rows, int64_t C, float eps);
+int codetr_layernorm_bf16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev, void *y_dev,
+                          int64_t rows, int64_t C, float eps);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ def run():
     import codetr
     import codetr_fp32 as M
     import msda_oracle as O
-    from helpers_model import assert_close_lowp, seeded_params
+    from helpers_model import assert_close_lowp, seeded_params, valid_topk
 
     assert torch.cuda.is_available(), "smoke() needs cuda:0"
     dev = "cuda:0"
@@ -48,8 +48,10 @@ def run():
     mask = torch.zeros(2, 76, 100)
     mask[1, :, 80:] = 1
     cap_o = {}
-    M.codetr_forward(full, img, mask, backbone="swin", num_heads=(1, 2, 4, 8), window_size=4, num_query=50,
-                     max_per_img=20, capture=cap_o)
+    kw = dict(backbone="swin", num_heads=(1, 2, 4, 8), window_size=4, num_query=50, max_per_img=20)
+    M.codetr_forward(full, img, mask, capture=cap_o, **kw)
+    picks = valid_topk(cap_o["enc_outputs_class"], cap_o["enc_outputs_coord_unact"], 50)
+    M.codetr_forward(full, img, mask, forced_topk=picks, capture=cap_o, **kw)
     cap = {}
     with torch.no_grad():
         boxes, scores, labels = model(img.to(dev).half(), mask.to(dev).half(),

@@ -67,3 +67,16 @@ def assert_close_lowp(actual, ref, rel_l2=1e-2, max_abs=None, what=""):
         worst = np.abs(a - r).max() / max(np.abs(r).max(), 1e-30)
         assert worst <= max_abs, f"{what}: max abs error {worst:.3e} x max|ref| > {max_abs:.1e}"
     return err
+
+
+def valid_topk(enc_cls, enc_coord, k):
+    """Proposal selection for parity runs on random weights: the reference's rule (top-k of the max class
+    logit, reference transformer.py:560) restricted to positions whose proposal is finite.  With
+    trained weights padded positions never win; with random weights they can, and their NaN box
+    (log of a negative number, reference transformer.py:338) then poisons the whole image through
+    the decoder's self-attention -- a property of random weights, not of either implementation."""
+    import torch
+
+    score = enc_cls.max(-1)[0].clone()
+    score[~torch.isfinite(enc_coord).all(-1)] = -float("inf")
+    return torch.topk(score, k, dim=1)[1]

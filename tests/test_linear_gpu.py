@@ -2,8 +2,9 @@
 plain PyTorch fp32 reference of the same op:  y = act(x @ w.T + b) (+ r).
 
 Tolerance: inputs are exactly representable (fp16/bf16), accumulation is fp32 on both sides, so the
-only differences are summation order and the single output rounding: |err| <= 2^-10 |y| + K * 2^-22
-scale for fp16 (1 ulp of the rounded result + fp32 accumulation noise), 2^-7 for bf16."""
+only differences are summation order and the output rounding: |err| <= 2^-10 |y| + K * 2^-22
+scale for fp16 (1 ulp of the rounded result + fp32 accumulation noise), 2^-7 for bf16; with a residual
+the linear output is rounded before the add (as in the reference's fp16 path), one more ulp of it."""
 import pytest
 import torch
 
@@ -38,6 +39,8 @@ def _check(M, N, K, dtype, bias, act, res, seed=0):
     assert y.shape == (M, N) and y.dtype == dtype
     ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
     tol = ulp * ref.abs() + 1e-3 * ulp * 64
+    if r is not None:  # residual is added to the ROUNDED linear output (two roundings, as `identity + linear(x)`)
+        tol = tol + ulp * (ref - r.float()).abs()
     bad = (y.float() - ref).abs() > tol + K * 2.0 ** -22
     assert not bad.any(), f"{int(bad.sum())} / {bad.numel()} outside 1 ulp; max err {(y.float() - ref).abs().max().item()}"
 

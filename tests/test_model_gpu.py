@@ -16,7 +16,7 @@ import torch
 
 import codetr_fp32 as M
 from conftest import GOLDEN, ROOT
-from helpers_model import assert_close_lowp, seeded_params, unpack_param_spec
+from helpers_model import assert_close_lowp, seeded_params, unpack_param_spec, valid_topk
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -122,7 +122,9 @@ def test_transformer_fp16_vs_oracle_forced_topk():
     masks_c = [torch.nn.functional.interpolate(img_mask[:, None], size=f.shape[-2:]).to(torch.bool).squeeze(1) for f in feats]
     pos_c = [M.sine_positional_encoding(m, torch.float32) for m in masks_c]
     cap_o = {}
-    state_o, refs_o = M.transformer(sd, feats, masks_c, pos_c, num_query=40, capture=cap_o)
+    M.transformer(sd, feats, masks_c, pos_c, num_query=40, capture=cap_o)
+    picks = valid_topk(cap_o["enc_outputs_class"], cap_o["enc_outputs_coord_unact"], 40)
+    state_o, refs_o = M.transformer(sd, feats, masks_c, pos_c, num_query=40, forced_topk=picks, capture=cap_o)
     t, cls_b, reg_b = _build_transformer(sd, torch.float16)
     pe = SinePositionalEncoding(num_feats=128, temperature=20, normalize=True)
     masks = [m.to(DEV) for m in masks_c]
@@ -202,8 +204,10 @@ def test_full_codetr_fp32_vs_oracle(backbone, hw):
     mask[1, int(H * 0.9):, :] = 1
     cap_o = {}
     kw = dict(num_heads=(1, 2, 4, 8), window_size=4) if backbone == "swin" else {}
+    M.codetr_forward(full, img, mask, backbone=backbone, num_query=50, max_per_img=20, capture=cap_o, **kw)
+    picks = valid_topk(cap_o["enc_outputs_class"], cap_o["enc_outputs_coord_unact"], 50)
     boxes_o, scores_o, labels_o = M.codetr_forward(full, img, mask, backbone=backbone, num_query=50, max_per_img=20,
-                                                   capture=cap_o, **kw)
+                                                   forced_topk=picks, capture=cap_o, **kw)
     cap = {}
     with torch.no_grad():
         boxes, scores, labels = model(img.to(DEV), mask.to(DEV), forced_topk_indices=cap_o["topk_indices"].to(DEV),
