@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -30,6 +30,7 @@ SIGNATURES = {
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
     "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
+    "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
 }
 
 _lib = None
@@ -144,3 +145,16 @@ def layernorm(x2d, weight, bias, eps, out2d):
         rows, C, float(eps))
     check(rc, "codetr_layernorm")
     return out2d
+
+
+def window_attention_supported(qkv, num_heads, window_size) -> bool:
+    C = qkv.shape[-1] // 3
+    return qkv.dtype == torch.float16 and C == num_heads * 32 and window_size in (4, 7, 8, 12)
+
+
+def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_size, shift):
+    rc = load().codetr_window_attention_f16(
+        current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(), rel_bias.data_ptr(), out.data_ptr(),
+        B, H, W, num_heads, 32, window_size, shift)
+    check(rc, "codetr_window_attention_f16")
+    return out

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from . import _cabi
 
 # ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
-NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)"}
+NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_window_attention(f16, head_dim 32)"}
 
 
 def _gpu(x, what):
@@ -103,6 +103,30 @@ def window_attention(qkv, rel_bias, mask, num_heads):
         attn = (attn.view(nWB // nW, nW, num_heads, N, N) + mask[None, :, None]).view(nWB, num_heads, N, N)
     attn = attn.softmax(-1)
     return (attn @ v).transpose(1, 2).reshape(nWB, N, C)
+
+
+def swin_window_attention_supported(qkv, num_heads, window_size):
+    return qkv.is_cuda and _cabi.window_attention_supported(qkv, num_heads, window_size)
+
+
+def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_size, shift):
+    """Fused (shifted-)window attention on the UNPADDED spatial token map.
+    qkv [B, H*W, 3C] (output of the qkv Linear on real tokens only), qkv_bias [3C] or None,
+    rel_bias [nH, N, N] -> [B, H*W, C].  Pad / roll / partition / softmax / reverse are all inside
+    the kernel (reference codetr/swin.py:191-252, 92-112)."""
+    _gpu(qkv, "swin_window_attention")
+    B, L, C3 = qkv.shape
+    H, W = hw_shape
+    if L != H * W:
+        raise AssertionError("input feature has wrong size")
+    if not qkv.is_contiguous():
+        qkv = qkv.contiguous()
+    if qkv_bias is None:
+        qkv_bias = torch.zeros(C3, dtype=qkv.dtype, device=qkv.device)
+    out = torch.empty((B, L, C3 // 3), dtype=qkv.dtype, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _cabi.window_attention(qkv, qkv_bias, rel_bias.contiguous(), out, B, H, W, num_heads, window_size, shift)
+    return out
 
 
 def mha_self_attention(q, k, v, num_heads):

@@ -149,15 +149,23 @@ class ShiftWindowMSA(nn.Module):
         self.w_msa = WindowMSA(embed_dims, num_heads, to_2tuple(window_size), qkv_bias, qk_scale, attn_drop_rate,
                                proj_drop_rate)
 
-    def forward(self, query, hw_shape):
-        """query [B, H*W, C] (already normalised).  Padding to a multiple of the window is applied
-        here, AFTER norm1: pad tokens are exact zeros, come out of qkv as the bias and take part in
-        the softmax as ordinary keys (only the shift mask exists), then are cropped (reference :191-247)."""
+    def forward(self, query, hw_shape, identity=None):
+        """query [B, H*W, C] (already normalised) -> attention branch output (+ `identity` if given).
+        Padding to a multiple of the window is applied AFTER norm1: pad tokens are exact zeros, come
+        out of qkv as the bias and take part in the softmax as ordinary keys (only the shift mask
+        exists), then are cropped (reference :191-247)."""
         B, L, C = query.shape
         H, W = hw_shape
         if L != H * W:
             raise AssertionError("input feature has wrong size")
         ws, sh = self.window_size, self.shift_size
+        m = self.w_msa
+        if hip_ops.swin_window_attention_supported(query, m.num_heads, ws) and query.dtype == torch.float16:
+            # fused path: qkv GEMM on real tokens only, one kernel for everything between qkv and proj,
+            # residual folded into the proj GEMM's epilogue
+            qkv = hip_ops.linear(query, m.qkv.weight, m.qkv.bias)
+            o = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads, ws, sh)
+            return hip_ops.linear(o, m.proj.weight, m.proj.bias, residual=identity)
         x = query.view(B, H, W, C)
         pad_r, pad_b = (-W) % ws, (-H) % ws
         if pad_r or pad_b:
@@ -174,7 +182,8 @@ class ShiftWindowMSA(nn.Module):
             x = torch.roll(x, shifts=(sh, sh), dims=(1, 2))
         if pad_r or pad_b:
             x = x[:, :H, :W, :]
-        return x.reshape(B, H * W, C)
+        x = x.reshape(B, H * W, C)
+        return x if identity is None else x + identity
 
 
 class SwinBlock(nn.Module):
@@ -191,7 +200,7 @@ class SwinBlock(nn.Module):
 
     def forward(self, x, hw_shape):
         h = hip_ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = x + self.attn(h, hw_shape)
+        x = self.attn(h, hw_shape, identity=x)
         h = hip_ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.ffn(h, identity=x)
 

@@ -1,0 +1,274 @@
+// Fused (shifted-)window multi-head self-attention for the Swin backbone on MI355X (gfx950).
+//
+// One kernel replaces what the reference runs, per Swin block, as ~15 ATen kernels
+// (reference codetr/swin.py:191-252 and :92-112): zero-pad to a multiple of the window, cyclic
+// roll, window partition, q*scale, q@k^T, + relative-position bias, + shift mask, softmax,
+// attn@v, head merge, window reverse, reverse roll, crop.  Here none of the intermediate tensors
+// exist: the kernel reads q/k/v straight from the qkv GEMM output in SPATIAL token order
+// [B, H*W, 3C] and writes the attention output in spatial order [B, H*W, C]; padding, roll and
+// window (un)partitioning are index arithmetic on the loads and stores.
+//
+// Pad tokens.  The reference pads AFTER norm1 with zeros, so a pad token's qkv row equals the qkv
+// bias, and pad tokens take part in the softmax as ordinary keys (only the shift mask exists).
+// The qkv GEMM therefore runs on real tokens only and this kernel substitutes the bias vector for
+// the q/k/v of pad tokens.
+//
+// Mapping: one wave per (image, window, head); 4 waves per workgroup, no inter-wave traffic.
+//   * K [N x 32] and V [N x 32] (N = ws*ws = 144 tokens, head_dim 32 = 64-byte rows) are staged
+//     into the wave's LDS region (16-byte chunks, XOR-swizzled by (row>>2)&3);
+//   * per 16-query tile: S^T = K . Q^T with v_mfma_f32_16x16x32_f16 (K = head_dim, one MFMA per
+//     16x16 score tile, Q fragment straight from global memory), scores kept TRANSPOSED so that a
+//     lane owns 4 consecutive keys of ONE query: scale, + bias (8-byte loads of the gathered
+//     [nH,N,N] bias), + shift mask (region ids from LDS), softmax with two cross-lane reductions;
+//   * the fp16 probabilities are already laid out as the B operand of the next MFMA
+//     (cdna_hip_programming.md section 3, "accumulator tile as the next MFMA's operand"): O^T = V^T . P^T,
+//     V^T fragments come from the row-major V image through ds_read_b64_tr_b16 (hardware
+//     transpose), the k-slot permutation being the same on both operands;
+//   * O^T leaves as 8-byte stores (4 consecutive channels of one token), normalised by 1/rowsum.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codetr_hip.h"
+
+namespace {
+
+constexpr int HD = 32;  // head_dim of every Swin variant
+constexpr int kWaves = 4;
+constexpr int kThreads = 64 * kWaves;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Geometry {
+  int B, H, W, Hp, Wp, shift, nH, nWx, nWin;  // nWin = (Hp/ws)*(Wp/ws)
+};
+
+template <int WS>
+struct Tok {
+  int token;    // y*W + x in the unpadded map (valid only if `valid`)
+  bool valid;   // false: pad token -> q/k/v = qkv bias, output dropped
+  int region;   // shift-mask region id 0..8
+};
+
+template <int WS>
+__device__ __forceinline__ Tok<WS> map_token(int i, int wy, int wx, const Geometry& g) {
+  const int iy = i / WS, ix = i - iy * WS;
+  const int ys = wy * WS + iy, xs = wx * WS + ix;  // coordinates in the shifted, padded map
+  int y = ys + g.shift, x = xs + g.shift;          // roll(-shift): shifted[ys] = padded[(ys + shift) mod Hp]
+  y = y >= g.Hp ? y - g.Hp : y;
+  x = x >= g.Wp ? x - g.Wp : x;
+  Tok<WS> t;
+  t.valid = (y < g.H) && (x < g.W);
+  t.token = y * g.W + x;
+  const int rh = ys < g.Hp - WS ? 0 : (ys < g.Hp - g.shift ? 1 : 2);
+  const int rw = xs < g.Wp - WS ? 0 : (xs < g.Wp - g.shift ? 1 : 2);
+  t.region = g.shift > 0 ? rh * 3 + rw : 0;
+  return t;
+}
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+template <int WS>
+__global__ __launch_bounds__(kThreads) void window_attention_kernel(
+    const _Float16* __restrict__ qkv,       // [B, H*W, 3C]
+    const _Float16* __restrict__ qkv_bias,  // [3C] (zeros if the layer has no bias)
+    const _Float16* __restrict__ rel_bias,  // [nH, N, N]
+    _Float16* __restrict__ out,             // [B, H*W, C]
+    Geometry g, int n_problems) {
+  constexpr int N = WS * WS;
+  constexpr int NT = (N + 15) / 16;   // 16-token tiles
+  constexpr int NP = NT * 16;         // padded token count of K
+  constexpr int KS = (NT + 1) / 2;    // 32-key steps of the P.V product
+  constexpr int VR = KS * 32;         // padded rows of V (zero-filled beyond N)
+  constexpr int kWaveLds = NP * 64 + VR * 64 + NP;  // K image, V image, region ids
+  constexpr int kWaveLdsAligned = (kWaveLds + 15) & ~15;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[kWaves * kWaveLdsAligned];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int prob = blockIdx.x * kWaves + wave;
+  if (prob >= n_problems) return;  // whole wave exits; waves never synchronise with each other
+  const int head = prob % g.nH;
+  const int win = (prob / g.nH) % g.nWin;
+  const int b = prob / (g.nH * g.nWin);
+  const int wy = win / g.nWx, wx = win - wy * g.nWx;
+  const int C = g.nH * HD;
+  const size_t row_elems = (size_t)3 * C;
+  const _Float16* qkv_b = qkv + (size_t)b * g.H * g.W * row_elems;
+  const int hoff = head * HD;
+
+  unsigned char* ldsK = lds_all + wave * kWaveLdsAligned;
+  unsigned char* ldsV = ldsK + NP * 64;
+  unsigned char* ldsR = ldsV + VR * 64;
+
+  // ---------------- stage K and V (+ region ids) ----------------
+  for (int c = lane; c < VR * 4; c += 64) {
+    const int row = c >> 2, chunk = c & 3;
+    s16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < N) {
+      const Tok<WS> t = map_token<WS>(row, wy, wx, g);
+      const _Float16* src = t.valid ? qkv_b + (size_t)t.token * row_elems : qkv_bias;
+      kv = *reinterpret_cast<const s16x8*>(src + C + hoff + chunk * 8);
+      vv = *reinterpret_cast<const s16x8*>(src + 2 * C + hoff + chunk * 8);
+      if (chunk == 0) ldsR[row] = (unsigned char)t.region;
+    } else if (row < NP && chunk == 0) {
+      ldsR[row] = 0;
+    }
+    const int pos = swz(row, chunk) * 16;
+    if (row < NP) *reinterpret_cast<s16x8*>(ldsK + row * 64 + pos) = kv;
+    *reinterpret_cast<s16x8*>(ldsV + row * 64 + pos) = vv;
+  }
+  __builtin_amdgcn_wave_barrier();  // LDS ops of one wave retire in order; keep the compiler from reordering
+
+  const int l15 = lane & 15, grp = lane >> 4;
+  const float scale_log2e = 0.17677669529663687f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e)
+  const float log2e = 1.4426950408889634f;
+  const _Float16* bias_h = rel_bias + (size_t)head * N * N;
+
+  // per-lane addresses that do not depend on the query tile
+  // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block
+  const int tr_q = l15 >> 2, tr_p = l15 & 3;
+
+#pragma unroll 1
+  for (int qt = 0; qt < NT; ++qt) {
+    const int qi = qt * 16 + l15;
+    const bool q_in = (N % 16 == 0) || qi < N;
+    const Tok<WS> tq = map_token<WS>(q_in ? qi : 0, wy, wx, g);
+    const _Float16* qsrc = (tq.valid ? qkv_b + (size_t)tq.token * row_elems : qkv_bias) + hoff + grp * 8;
+    const f16x8 qf = *reinterpret_cast<const f16x8*>(qsrc);
+
+    // ---- S^T tiles: D[i = key][j = query] ----
+    f32x4 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const int row = kt * 16 + l15;
+      const f16x8 kf = *reinterpret_cast<const f16x8*>(ldsK + row * 64 + swz(row, grp) * 16);
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    // ---- scale, bias, mask (all in the log2 domain), row max ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const int key0 = kt * 16 + grp * 4;
+      f16x4 bv = {0, 0, 0, 0};
+      if constexpr (N % 4 == 0) {  // rows of the bias are 8-byte aligned and a 4-key group is all in or all out
+        if ((N % 16 == 0) || (q_in && key0 < N))
+          bv = *reinterpret_cast<const f16x4*>(bias_h + (size_t)(q_in ? qi : 0) * N + key0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (q_in && key0 + r < N) bv[r] = bias_h[(size_t)qi * N + key0 + r];
+      }
+      const unsigned regk = *reinterpret_cast<const unsigned*>(ldsR + key0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s[kt][r] * scale_log2e + (float)bv[r] * log2e;
+        if (g.shift > 0 && (int)((regk >> (8 * r)) & 0xff) != tq.region) v -= 100.0f * log2e;
+        if ((N % 16 != 0) && key0 + r >= N) v = -INFINITY;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // ---- exp, row sum, pack P^T as MFMA B fragments ----
+    float sum = 0.f;
+    f16x8 pf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kt = 2 * ks + h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = 0.f;
+          if (kt < NT) {
+            p = __builtin_amdgcn_exp2f(s[kt][r] - mx);  // v_exp_f32; argument <= 0
+            sum += p;
+          }
+          pf[ks][h * 4 + r] = (_Float16)p;
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    // ---- O^T = V^T . P^T : D[i = channel][j = query] ----
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int chunk = dt * 2 + (tr_p >> 1);
+        const int row0 = (2 * ks) * 16 + grp * 4 + tr_q;
+        const int row1 = row0 + 16;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(ldsV + row0 * 64 + swz(row0, chunk) * 16 + (tr_p & 1) * 8));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(ldsV + row1 * 64 + swz(row1, chunk) * 16 + (tr_p & 1) * 8));
+        s16x8 vf8 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        f16x8 vf;
+        __builtin_memcpy(&vf, &vf8, 16);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ks], o[dt], 0, 0, 0);
+      }
+    }
+    // ---- normalise and store: lane holds channels 16*dt + 4*grp + r of query l15 ----
+    if (q_in && tq.valid) {
+      const float inv = 1.0f / sum;
+      _Float16* dst = out + ((size_t)b * g.H * g.W + tq.token) * C + hoff + grp * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (_Float16)(o[dt][r] * inv);
+        *reinterpret_cast<f16x4*>(dst + dt * 16) = ov;
+      }
+    }
+  }
+}
+
+template <int WS>
+int launch_ws(hipStream_t st, const void* qkv, const void* qkv_bias, const void* rel_bias, void* out, Geometry g) {
+  const int64_t n = (int64_t)g.B * g.nWin * g.nH;
+  if (n > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
+  hipLaunchKernelGGL((window_attention_kernel<WS>), dim3(blocks), dim3(kThreads), 0, st,
+                     static_cast<const _Float16*>(qkv), static_cast<const _Float16*>(qkv_bias),
+                     static_cast<const _Float16*>(rel_bias), static_cast<_Float16*>(out), g, (int)n);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_window_attention_f16(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
+                                void* out_dev, int64_t B, int64_t H, int64_t W, int num_heads, int head_dim,
+                                int window_size, int shift) {
+  if (!qkv_dev || !qkv_bias_dev || !rel_bias_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || num_heads <= 0)
+    return CODETR_E_BADARG;
+  if (head_dim != HD || shift < 0 || shift >= window_size) return CODETR_E_UNSUPPORTED;
+  if (B * H * W > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  Geometry g;
+  g.B = (int)B;
+  g.H = (int)H;
+  g.W = (int)W;
+  g.Hp = (int)((H + window_size - 1) / window_size * window_size);
+  g.Wp = (int)((W + window_size - 1) / window_size * window_size);
+  g.shift = shift;
+  g.nH = num_heads;
+  g.nWx = g.Wp / window_size;
+  g.nWin = (g.Hp / window_size) * g.nWx;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (window_size) {
+    case 12: return launch_ws<12>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+    case 8: return launch_ws<8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+    case 7: return launch_ws<7>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+    case 4: return launch_ws<4>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+  }
+  return CODETR_E_UNSUPPORTED;
+}
+
+}  // extern "C"

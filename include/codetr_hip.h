@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 3
+#define CODETR_HIP_ABI_VERSION 4
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -125,6 +125,29 @@ int codetr_layernorm_f16(void *stream, const void *x_dev, const void *gamma_dev,
                          int64_t rows, int64_t C, float eps);
 int codetr_layernorm_bf16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev, void *y_dev,
                           int64_t rows, int64_t C, float eps);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused (shifted-)window multi-head self-attention of one Swin block.
+ *
+ * Replaces the tensor program of ShiftWindowMSA.forward + WindowMSA.forward between the qkv and
+ * the proj Linear (reference codetr/swin.py:191-252 and :92-112): pad-to-window, roll(-shift),
+ * window_partition, q*scale, q@k^T, + relative position bias, + shift mask (-100), softmax,
+ * attn@v, head merge, window_reverse, roll(+shift), crop.
+ *
+ *   qkv_dev      [B, H*W, 3*C]  f16  output of the qkv Linear on the UNPADDED, unrolled token map;
+ *                                    channel order (q | k | v), each head-major (C = num_heads*head_dim)
+ *   qkv_bias_dev [3*C]          f16  bias of that Linear (what a zero pad token turns into; zeros
+ *                                    if the layer has no bias) -- pad tokens take part in the
+ *                                    softmax as keys, exactly as in the reference
+ *   rel_bias_dev [num_heads, N, N] f16  gathered relative position bias, N = window_size^2
+ *   out_dev      [B, H*W, C]    f16  attention output in the same spatial token order
+ *   shift        0 (W-MSA) or window_size/2 (SW-MSA); head_dim must be 32; window_size in {4,7,8,12}
+ *
+ * fp32 scores / softmax / accumulation; probabilities rounded to f16 for the P.V product.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_window_attention_f16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
+                                const void *rel_bias_dev, void *out_dev, int64_t B, int64_t H, int64_t W,
+                                int num_heads, int head_dim, int window_size, int shift);
 
 #ifdef __cplusplus
 }

@@ -9,9 +9,10 @@ from collections import defaultdict
 
 CATS = [
     (r"^Cijk_|^Custom_Cijk", "GEMM (hipBLASLt/Tensile)"),
-    (r"gemm_|codetr_gemm|mfma_gemm", "GEMM (native)"),
+    (r"linear_kernel", "linear / GEMM (native MFMA)"),
     (r"msda_", "MSDA (native)"),
-    (r"window_attn|swin_attn", "window attention (native)"),
+    (r"window_attention_kernel", "window attention (native)"),
+    (r"layernorm_kernel", "layer norm (native)"),
     (r"layer_norm|layernorm|RowwiseMoments|GroupNorm|group_norm", "norm"),
     (r"softmax", "softmax"),
     (r"attn_fwd|flash|sdpa", "SDPA"),
