@@ -35,6 +35,10 @@ SIGNATURES = {
 
 _lib = None
 
+# how many times each native entry point was enqueued in this process: lets tests and bench.py prove
+# that the HIP kernels -- not a library path -- served a run
+CALLS = {"msda": 0, "linear": 0, "layernorm": 0, "window_attention": 0}
+
 
 def load():
     """Load the shared library once; raise ImportError (loudly) if it is absent or stale."""
@@ -91,6 +95,7 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
     """Enqueue the MSDA forward on torch's current stream.  All tensors must already satisfy the
     contract checked in ops.py (contiguous, on one HIP device, one float dtype, int64 shapes)."""
     lib = load()
+    CALLS["msda"] += 1
     name, _ = _MSDA_BY_DTYPE[value.dtype]
     B, S, M, D = value.shape
     Nq, L, P = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
@@ -119,6 +124,7 @@ def linear_supported(x, weight) -> bool:
 def linear(x2d, weight, bias, residual2d, act, out2d):
     """Enqueue y = act(x @ w.T + b) (+ r) on torch's current stream.  x2d [M,K], weight [N,K] contiguous."""
     lib = load()
+    CALLS["linear"] += 1
     M, K = x2d.shape
     N = weight.shape[0]
     rc = getattr(lib, _LINEAR_BY_DTYPE[x2d.dtype])(
@@ -140,6 +146,7 @@ def layernorm_supported(x, weight) -> bool:
 
 def layernorm(x2d, weight, bias, eps, out2d):
     rows, C = x2d.shape
+    CALLS["layernorm"] += 1
     rc = getattr(load(), _LN_BY_DTYPE[x2d.dtype])(
         current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(), bias.data_ptr(), out2d.data_ptr(),
         rows, C, float(eps))
@@ -147,12 +154,12 @@ def layernorm(x2d, weight, bias, eps, out2d):
     return out2d
 
 
-def window_attention_supported(qkv, num_heads, window_size) -> bool:
-    C = qkv.shape[-1] // 3
-    return qkv.dtype == torch.float16 and C == num_heads * 32 and window_size in (4, 7, 8, 12)
+def window_attention_supported(dtype, embed_dims, num_heads, window_size) -> bool:
+    return dtype == torch.float16 and embed_dims == num_heads * 32 and window_size in (4, 7, 8, 12)
 
 
 def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_size, shift):
+    CALLS["window_attention"] += 1
     rc = load().codetr_window_attention_f16(
         current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(), rel_bias.data_ptr(), out.data_ptr(),
         B, H, W, num_heads, 32, window_size, shift)

@@ -105,8 +105,9 @@ def window_attention(qkv, rel_bias, mask, num_heads):
     return (attn @ v).transpose(1, 2).reshape(nWB, N, C)
 
 
-def swin_window_attention_supported(qkv, num_heads, window_size):
-    return qkv.is_cuda and _cabi.window_attention_supported(qkv, num_heads, window_size)
+def swin_window_attention_supported(x, embed_dims, num_heads, window_size):
+    """True when the fused kernel serves this block (f16, head_dim 32, window in {4,7,8,12})."""
+    return x.is_cuda and _cabi.window_attention_supported(x.dtype, embed_dims, num_heads, window_size)
 
 
 def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_size, shift):

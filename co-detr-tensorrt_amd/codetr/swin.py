@@ -160,7 +160,7 @@ class ShiftWindowMSA(nn.Module):
             raise AssertionError("input feature has wrong size")
         ws, sh = self.window_size, self.shift_size
         m = self.w_msa
-        if hip_ops.swin_window_attention_supported(query, m.num_heads, ws) and query.dtype == torch.float16:
+        if hip_ops.swin_window_attention_supported(query, C, m.num_heads, ws):
             # fused path: qkv GEMM on real tokens only, one kernel for everything between qkv and proj,
             # residual folded into the proj GEMM's epilogue
             qkv = hip_ops.linear(query, m.qkv.weight, m.qkv.bias)

@@ -108,8 +108,14 @@ def test_swin_block_fused_matches_oracle():
     s.load_state_dict(sd, strict=False)
     s = s.to(DEV).half().eval()
     img = torch.randn(2, 3, 100, 150, generator=torch.Generator().manual_seed(3))  # 25 x 38 tokens -> pads to 36 x 48
+    from codetr import _cabi
+
+    before = dict(_cabi.CALLS)
     with torch.no_grad():
         outs = s(img.to(DEV).half())
+    assert _cabi.CALLS["window_attention"] - before["window_attention"] == 4  # every block took the fused kernel
+    assert _cabi.CALLS["linear"] - before["linear"] == 4 * 4 + 1             # qkv, proj, fc1, fc2 per block + 1 merge
+    assert _cabi.CALLS["layernorm"] > before["layernorm"]
     ref = M.swin_forward({"backbone." + k: v for k, v in sd.items()}, img, num_heads=(2, 4), window_size=12,
                          out_indices=(0, 1))
     for i in range(2):
