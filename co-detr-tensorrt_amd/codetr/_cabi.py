@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -26,8 +26,12 @@ SIGNATURES = {
     "codetr_msda_forward_f32": (_i32, _MSDA_ARGS),
     "codetr_msda_forward_f64": (_i32, _MSDA_ARGS),
     "codetr_msda_variant": (_cp, [_i32, _i32, _i32, _i32, _i32]),
-    "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
-    "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
+    "codetr_msda_fused_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32,
+                                             _i32, _i32, _i64, _i32, _vp]),
+    "codetr_msda_fused_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32,
+                                              _i32, _i32, _i64, _i32, _vp]),
+    "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
+    "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
     "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
@@ -37,7 +41,7 @@ _lib = None
 
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
-CALLS = {"msda": 0, "linear": 0, "layernorm": 0, "window_attention": 0}
+CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0}
 
 
 def load():
@@ -121,8 +125,9 @@ def linear_supported(x, weight) -> bool:
     return x.dtype in _LINEAR_BY_DTYPE and weight.dtype == x.dtype and weight.shape[1] % 64 == 0
 
 
-def linear(x2d, weight, bias, residual2d, act, out2d):
-    """Enqueue y = act(x @ w.T + b) (+ r) on torch's current stream.  x2d [M,K], weight [N,K] contiguous."""
+def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None):
+    """Enqueue y = act(x @ w.T + b) (+ r) on torch's current stream.  x2d [M,K], weight [N,K] contiguous;
+    row_mask [M] bool/uint8: masked rows are written as zeros."""
     lib = load()
     CALLS["linear"] += 1
     M, K = x2d.shape
@@ -131,6 +136,7 @@ def linear(x2d, weight, bias, residual2d, act, out2d):
         current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(),
         bias.data_ptr() if bias is not None else None,
         residual2d.data_ptr() if residual2d is not None else None,
+        row_mask.data_ptr() if row_mask is not None else None,
         out2d.data_ptr(), M, N, K, _ACT[act])
     check(rc, "codetr_linear")
     return out2d
@@ -164,4 +170,27 @@ def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_si
         current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(), rel_bias.data_ptr(), out.data_ptr(),
         B, H, W, num_heads, 32, window_size, shift)
     check(rc, "codetr_window_attention_f16")
+    return out
+
+
+_MSDA_FUSED_BY_DTYPE = {torch.float16: "codetr_msda_fused_forward_f16", torch.bfloat16: "codetr_msda_fused_forward_bf16"}
+
+
+def msda_fused_supported(dtype, D, L, P) -> bool:
+    return dtype in _MSDA_FUSED_BY_DTYPE and D in (16, 32, 64) and L * P * (256 // (D // 8)) * 32 <= 60 * 1024
+
+
+def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_col, ref, num_levels, num_points, out):
+    """value [B,S,M,D]; proj [B,Nq,Ncols] holds the sampling offsets at columns [off_col, off_col+M*L*P*2) and
+    the attention logits at [logit_col, logit_col+M*L*P); ref [B,Nq,L,2|4]; out [B,Nq,M*D]."""
+    lib = load()
+    CALLS["msda_fused"] += 1
+    B, S, M, D = value.shape
+    Nq, ncols = proj.shape[1], proj.shape[2]
+    es = proj.element_size()
+    rc = getattr(lib, _MSDA_FUSED_BY_DTYPE[value.dtype])(
+        current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+        proj.data_ptr() + off_col * es, ncols, proj.data_ptr() + logit_col * es, ncols,
+        ref.data_ptr(), ref.shape[-1], B, S, M, D, num_levels, Nq, num_points, out.data_ptr())
+    check(rc, "codetr_msda_fused_forward")
     return out

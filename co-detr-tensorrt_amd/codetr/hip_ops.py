@@ -16,7 +16,8 @@ import torch.nn.functional as F
 from . import _cabi
 
 # ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
-NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_window_attention(f16, head_dim 32)"}
+NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_window_attention(f16, head_dim 32)",
+          "msda_fused(softmax + sampling locations in-kernel)"}
 
 
 def _gpu(x, what):
@@ -27,8 +28,9 @@ def _gpu(x, what):
         )
 
 
-def linear(x, weight, bias=None, act=None, residual=None):
-    """y = act(x @ weight.T + bias) (+ residual);  act in {None, 'relu', 'gelu'}."""
+def linear(x, weight, bias=None, act=None, residual=None, row_mask=None):
+    """y = act(x @ weight.T + bias) (+ residual);  act in {None, 'relu', 'gelu'}.
+    row_mask (bool, x.shape[:-1]): rows where it is True come out as zeros (before the residual)."""
     _gpu(x, "linear")
     if _cabi.linear_supported(x, weight):
         # hand-written MFMA GEMM with the bias / activation / residual folded into its epilogue
@@ -43,10 +45,16 @@ def linear(x, weight, bias=None, act=None, residual=None):
             r2 = residual.reshape(-1, N)
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
+        mk = None
+        if row_mask is not None:
+            mk = row_mask.reshape(-1)
+            if mk.dtype != torch.bool and mk.dtype != torch.uint8:
+                mk = mk != 0
+            mk = mk.contiguous()
         out = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
         if x2.shape[0] > 0:
             with torch.cuda.device(x.device):
-                _cabi.linear(x2, w, bias, r2, act, out)
+                _cabi.linear(x2, w, bias, r2, act, out, mk)
         return out.view(*x.shape[:-1], N)
     # fp32 / odd-K layers (patch-embed is a conv; fp32 runs are parity runs): ATen library GEMM
     y = F.linear(x, weight, bias)
@@ -56,6 +64,8 @@ def linear(x, weight, bias=None, act=None, residual=None):
         y = F.gelu(y)
     elif act is not None:
         raise ValueError(act)
+    if row_mask is not None:
+        y = y.masked_fill(row_mask[..., None], 0.0)
     if residual is not None:
         y = y + residual
     return y
@@ -138,6 +148,25 @@ def mha_self_attention(q, k, v, num_heads):
     sp = lambda t: t.view(B, -1, num_heads, hd).transpose(1, 2)  # noqa: E731
     o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v))
     return o.transpose(1, 2).reshape(B, N, C)
+
+
+def msda_fused_supported(value_dtype, head_dim, num_levels, num_points):
+    return _cabi.msda_fused_supported(value_dtype, head_dim, num_levels, num_points)
+
+
+def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_col, reference_points, num_levels,
+               num_points):
+    """MSDA with softmax + sampling-location arithmetic inside the kernel (reference
+    multi_scale_deformable_attention.py:180-196 + the op).  value [B,S,M,D]; proj [B,Nq,cols] = output of the
+    fused (offsets | logits) projection; reference_points [B,Nq,L,2|4] -> [B,Nq,M*D]."""
+    _gpu(value, "msda_fused")
+    B, S, M, D = value.shape
+    out = torch.empty((B, proj.shape[1], M * D), dtype=value.dtype, device=value.device)
+    if out.numel():
+        with torch.cuda.device(value.device):
+            _cabi.msda_fused(value.contiguous(), spatial_shapes, level_start_index, proj.contiguous(), off_col,
+                             logit_col, reference_points.to(value.dtype).contiguous(), num_levels, num_points, out)
+    return out
 
 
 def msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step):

@@ -74,6 +74,19 @@ class MultiScaleDeformableAttention(nn.Module):
             nn.init.xavier_uniform_(proj.weight)
             nn.init.zeros_(proj.bias)
 
+    def _fused_projection(self):
+        """(sampling_offsets | attention_weights) as ONE [M*L*P*3, C] weight: the two Linears read the same
+        input, so they run as a single GEMM.  Rebuilt only when a parameter tensor changes."""
+        ws = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
+              self.attention_weights.bias)
+        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ws)
+        if getattr(self, "_fused_key", None) != key:
+            with torch.no_grad():
+                self._fused_w = torch.cat((ws[0], ws[2]), 0).contiguous()
+                self._fused_b = torch.cat((ws[1], ws[3]), 0).contiguous()
+            self._fused_key = key
+        return self._fused_w, self._fused_b
+
     # ------------------------------------------------------------------ batch-first core
     def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
                    level_start_index):
@@ -83,10 +96,20 @@ class MultiScaleDeformableAttention(nn.Module):
         B, Nq, _ = query.shape
         S = value.shape[1]
         H, L, P = self.num_heads, self.num_levels, self.num_points
-        v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias)
-        if key_padding_mask is not None:
-            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError(
+                f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead."
+            )
+        # value projection with the padding mask folded into the GEMM epilogue (reference :173-176)
+        v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask)
         v = v.view(B, S, H, -1)
+        if query.is_cuda and hip_ops.msda_fused_supported(v.dtype, v.shape[-1], L, P):
+            # one GEMM for (offsets | logits); softmax and location arithmetic happen inside the MSDA kernel
+            Wc, bc = self._fused_projection()
+            proj = hip_ops.linear(query, Wc, bc)
+            out = hip_ops.msda_fused(v, spatial_shapes, level_start_index, proj, 0, H * L * P * 2, reference_points,
+                                     L, P)
+            return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
         offsets = hip_ops.linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias)
         offsets = offsets.view(B, Nq, H, L, P, 2)
         weights = hip_ops.linear(query, self.attention_weights.weight, self.attention_weights.bias)

@@ -124,8 +124,9 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
                                                           const unsigned short* __restrict__ W,
                                                           const unsigned short* __restrict__ bias,
                                                           const unsigned short* __restrict__ R,
-                                                          unsigned short* __restrict__ Y, int M, int N, int K,
-                                                          int tiles_n) {
+                                                          unsigned short* __restrict__ Y,
+                                                          const unsigned char* __restrict__ row_mask, int M, int N,
+                                                          int K, int tiles_n) {
   // [buf][operand][16 KiB]; one object only (a second __shared__ object de-pipelines LDS-DMA kernels)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kTileBytes];
   const int tid = threadIdx.x;
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
       const int m = m0 + wm * 64 + ml;
       if (m < M && n < N) {
         s16x8 v = *reinterpret_cast<const s16x8*>(stage + ml * kPitch + schunk * 16);
+        if (row_mask && row_mask[m]) v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};  // masked_fill(mask[..., None], 0) on the linear's output
         const size_t off = (size_t)m * N + n;
         if (HAS_RES) {
           const s16x8 rr = *reinterpret_cast<const s16x8*>(R + off);
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
           if (ACT == 1) v = v < 0.f ? 0.f : v;
           if (ACT == 2) v = gelu_erf(v);
           unsigned short h = T::from_f32(v);
+          if (row_mask && row_mask[m]) h = 0;
           if (HAS_RES) h = T::from_f32(T::to_f32(h) + T::to_f32(R[off + r]));
           Y[off + r] = h;
         }
@@ -260,8 +263,8 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
 }
 
 template <class T, int ACT>
-int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, int M, int N,
-               int K) {
+int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
+               const void* mask, int M, int N, int K) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(kThreads);
   auto x = static_cast<const unsigned short*>(X);
@@ -269,26 +272,27 @@ int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto b = static_cast<const unsigned short*>(bias);
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
-  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true>), grid, block, 0, st, x, w, b, r, y, M, N, K, tiles_n);
-  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false>), grid, block, 0, st, x, w, b, r, y, M, N, K, tiles_n);
-  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true>), grid, block, 0, st, x, w, b, r, y, M, N, K, tiles_n);
-  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false>), grid, block, 0, st, x, w, b, r, y, M, N, K, tiles_n);
+  auto mk = static_cast<const unsigned char*>(mask);
+  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
 
 template <class T>
-int launch(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, int64_t M, int64_t N,
-           int64_t K, int act) {
+int launch(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
+           int64_t M, int64_t N, int64_t K, int act) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return CODETR_E_BADARG;
   if (K % BK != 0 || act < 0 || act > 2) return CODETR_E_UNSUPPORTED;
   if (M > 0x7fffffffLL || N > 0x7fffffffLL || K > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   if (((M + BM - 1) / BM) * ((N + BN - 1) / BN) > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) return CODETR_E_BADARG;
   switch (act) {
-    case 0: return launch_act<T, 0>(st, X, W, bias, R, Y, (int)M, (int)N, (int)K);
-    case 1: return launch_act<T, 1>(st, X, W, bias, R, Y, (int)M, (int)N, (int)K);
-    default: return launch_act<T, 2>(st, X, W, bias, R, Y, (int)M, (int)N, (int)K);
+    case 0: return launch_act<T, 0>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
+    case 1: return launch_act<T, 1>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
+    default: return launch_act<T, 2>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
   }
 }
 
@@ -297,13 +301,16 @@ int launch(hipStream_t st, const void* X, const void* W, const void* bias, const
 extern "C" {
 
 int codetr_linear_f16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev, const void* residual_dev,
-                      void* y_dev, int64_t M, int64_t N, int64_t K, int act) {
-  return launch<HalfT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, M, N, K, act);
+                      const void* row_mask_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act) {
+  return launch<HalfT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, row_mask_dev, M,
+                       N, K, act);
 }
 
 int codetr_linear_bf16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev,
-                       const void* residual_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act) {
-  return launch<BFloatT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, M, N, K, act);
+                       const void* residual_dev, const void* row_mask_dev, void* y_dev, int64_t M, int64_t N,
+                       int64_t K, int act) {
+  return launch<BFloatT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, row_mask_dev,
+                         M, N, K, act);
 }
 
 }  // extern "C"

@@ -101,13 +101,28 @@ struct __attribute__((aligned(16))) Entry {
   f32x4 w;
 };
 
-template <class TR, int LANES>
+// Extra inputs of the FUSED variant: instead of ready-made sampling locations and
+// softmax-ed weights the kernel takes what the two projections produce and the reference points, and
+// performs reference multi_scale_deformable_attention.py:180-196 itself, in fp32:
+//   weights = softmax over the L*P logits of a (query, head);
+//   loc     = ref_xy + off / (W_l, H_l)                  (2-d reference points)
+//           = ref_xy + off / P * ref_wh * 0.5            (4-d reference points)
+// `loc` then points at the offsets and `weight` at the logits; both are addressed as rows of one
+// (possibly wider, fused-projection) matrix with the strides below.
+struct FusedArgs {
+  const void* ref;      // [B*Nq, L, ref_dim]
+  int ref_dim;          // 2 or 4
+  int off_stride;       // elements between consecutive (b, q) rows of the offsets matrix
+  int logit_stride;     // same for the logits matrix
+};
+
+template <class TR, int LANES, bool FUSED>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_WAVES_PER_EU, MSDA_WAVES_PER_EU))) void msda_tiled_kernel(
     const typename TR::storage* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
     const int64_t* __restrict__ level_start, const typename TR::storage* __restrict__ loc,
     const typename TR::storage* __restrict__ weight, typename TR::storage* __restrict__ out,
     unsigned n_pairs /* B*Nq*M */, unsigned pairs_per_image /* Nq*M */, unsigned image_bytes /* S*M*D*sizeof */,
-    int M, int L, int P) {
+    int M, int L, int P, FusedArgs fa) {
   using S = typename TR::storage;
   constexpr int VEC = TR::VEC;
   constexpr int D = VEC * LANES;
@@ -119,6 +134,23 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
   const unsigned pair0 = tile * PAIRS;
   const int LP = L * P;
   const unsigned row_bytes = (unsigned)(M * D * sizeof(S));  // one pixel, all heads
+
+  // ---------------- phase 0 (fused only): softmax statistics of every pair's L*P logits ----------------
+  float* sm_stats = reinterpret_cast<float*>(entries + (size_t)LP * PAIRS);  // [PAIRS][2] = (max, 1/sum)
+  if (FUSED) {
+    for (int pl = threadIdx.x; pl < PAIRS; pl += kThreads) {
+      unsigned g = pair0 + pl;
+      g = g < n_pairs ? g : n_pairs - 1;
+      const S* lg = weight + (size_t)(g / (unsigned)M) * fa.logit_stride + (size_t)(g % (unsigned)M) * LP;
+      float mx = -INFINITY;
+      for (int i = 0; i < LP; ++i) mx = fmaxf(mx, TR::to_f32(lg[i]));
+      float sum = 0.f;
+      for (int i = 0; i < LP; ++i) sum += __expf(TR::to_f32(lg[i]) - mx);
+      sm_stats[2 * pl] = mx;
+      sm_stats[2 * pl + 1] = 1.0f / sum;
+    }
+    __syncthreads();
+  }
 
   // ---------------- phase 1: (x, y, w) -> {offsets, weights} into LDS ----------------
   for (int l = 0; l < L; ++l) {
@@ -133,10 +165,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
       g = g < n_pairs ? g : n_pairs - 1;  // tail: recompute the last pair, store is masked
       const unsigned b = g / pairs_per_image;
       const unsigned m = g % (unsigned)M;
-      const size_t pt = ((size_t)g * L + l) * P + p;
-      const float x = TR::to_f32(loc[2 * pt]);
-      const float y = TR::to_f32(loc[2 * pt + 1]);
-      const float aw = TR::to_f32(weight[pt]);
+      float x, y, aw;
+      if (FUSED) {
+        const unsigned row = g / (unsigned)M;  // (b, q)
+        const int col = ((int)m * L + l) * P + p;
+        const float ox = TR::to_f32(loc[(size_t)row * fa.off_stride + 2 * col]);
+        const float oy = TR::to_f32(loc[(size_t)row * fa.off_stride + 2 * col + 1]);
+        const S* rp = static_cast<const S*>(fa.ref) + ((size_t)row * L + l) * fa.ref_dim;
+        const float rx = TR::to_f32(rp[0]), ry = TR::to_f32(rp[1]);
+        if (fa.ref_dim == 2) {
+          x = rx + ox / Wf;
+          y = ry + oy / Hf;
+        } else {
+          x = rx + ox / (float)P * TR::to_f32(rp[2]) * 0.5f;
+          y = ry + oy / (float)P * TR::to_f32(rp[3]) * 0.5f;
+        }
+        aw = __expf(TR::to_f32(weight[(size_t)row * fa.logit_stride + col]) - sm_stats[2 * pl]) * sm_stats[2 * pl + 1];
+      } else {
+        const size_t pt = ((size_t)g * L + l) * P + p;
+        x = TR::to_f32(loc[2 * pt]);
+        y = TR::to_f32(loc[2 * pt + 1]);
+        aw = TR::to_f32(weight[pt]);
+      }
       // pixel coordinates (reference cu:246-247), fp32 regardless of T
       const float h_im = fmaf(y, Hf, -0.5f);
       const float w_im = fmaf(x, Wf, -0.5f);
@@ -295,9 +345,9 @@ int tiled_lanes(int elem_bytes, int D, int L, int P) {
   return lanes;
 }
 
-template <class TR, int LANES>
+template <class TR, int LANES, bool FUSED>
 int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int64_t* ls, const void* loc,
-                 const void* w, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq, int P) {
+                 const void* w, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq, int P, FusedArgs fa) {
   using ST = typename TR::storage;
   constexpr int D = TR::VEC * LANES;
   constexpr int PAIRS = kThreads / LANES;
@@ -312,17 +362,21 @@ int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int
   const int64_t bc_pairs = 0x7fffffffLL / pairs_per_image;
   if (bc_pairs < bc) bc = bc_pairs;
   if (bc < 1) return CODETR_E_TOO_LARGE;
-  const size_t lds = (size_t)PAIRS * L * P * sizeof(Entry);
-  const int64_t loc_per_image = pairs_per_image * L * P * 2, w_per_image = pairs_per_image * L * P;
+  const size_t lds = (size_t)PAIRS * L * P * sizeof(Entry) + (FUSED ? (size_t)PAIRS * 2 * sizeof(float) : 0);
+  // per-image strides of the loc / weight operands (rows of the projection matrices when fused)
+  const int64_t loc_per_image = FUSED ? Nq * (int64_t)fa.off_stride : pairs_per_image * L * P * 2;
+  const int64_t w_per_image = FUSED ? Nq * (int64_t)fa.logit_stride : pairs_per_image * L * P;
   for (int64_t b0 = 0; b0 < B; b0 += bc) {
     const int64_t nb = (B - b0) < bc ? (B - b0) : bc;
     const unsigned n_pairs = (unsigned)(nb * pairs_per_image);
     const unsigned grid = (n_pairs + PAIRS - 1) / PAIRS;
-    hipLaunchKernelGGL((msda_tiled_kernel<TR, LANES>), dim3(grid), dim3(kThreads), lds, st,
+    FusedArgs fb = fa;
+    if (FUSED) fb.ref = static_cast<const ST*>(fa.ref) + b0 * Nq * L * fa.ref_dim;
+    hipLaunchKernelGGL((msda_tiled_kernel<TR, LANES, FUSED>), dim3(grid), dim3(kThreads), lds, st,
                        static_cast<const ST*>(value) + b0 * image_elems, ss, ls,
                        static_cast<const ST*>(loc) + b0 * loc_per_image, static_cast<const ST*>(w) + b0 * w_per_image,
                        static_cast<ST*>(out) + b0 * pairs_per_image * D, n_pairs, (unsigned)pairs_per_image,
-                       (unsigned)image_bytes, M, L, P);
+                       (unsigned)image_bytes, M, L, P, fb);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
   }
@@ -332,13 +386,27 @@ int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int
 template <class TR>
 int dispatch_tiled(int lanes, hipStream_t st, const void* value, const int64_t* ss, const int64_t* ls,
                    const void* loc, const void* w, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq, int P) {
+  const FusedArgs none{nullptr, 0, 0, 0};
   switch (lanes) {
-    case 1: return launch_tiled<TR, 1>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P);
-    case 2: return launch_tiled<TR, 2>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P);
-    case 4: return launch_tiled<TR, 4>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P);
-    case 8: return launch_tiled<TR, 8>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P);
-    case 16: return launch_tiled<TR, 16>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P);
-    case 32: return launch_tiled<TR, 32>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P);
+    case 1: return launch_tiled<TR, 1, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
+    case 2: return launch_tiled<TR, 2, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
+    case 4: return launch_tiled<TR, 4, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
+    case 8: return launch_tiled<TR, 8, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
+    case 16: return launch_tiled<TR, 16, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
+    case 32: return launch_tiled<TR, 32, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
+  }
+  return CODETR_E_UNSUPPORTED;
+}
+
+// fused variant: only the lane counts the model family uses (D = 32 / 64 in 16-bit storage)
+template <class TR>
+int dispatch_fused(int lanes, hipStream_t st, const void* value, const int64_t* ss, const int64_t* ls,
+                   const void* off, const void* logits, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq,
+                   int P, FusedArgs fa) {
+  switch (lanes) {
+    case 2: return launch_tiled<TR, 2, true>(st, value, ss, ls, off, logits, out, B, S, M, L, Nq, P, fa);
+    case 4: return launch_tiled<TR, 4, true>(st, value, ss, ls, off, logits, out, B, S, M, L, Nq, P, fa);
+    case 8: return launch_tiled<TR, 8, true>(st, value, ss, ls, off, logits, out, B, S, M, L, Nq, P, fa);
   }
   return CODETR_E_UNSUPPORTED;
 }
@@ -405,6 +473,28 @@ const char* codetr_msda_variant(int elem_bytes, int M, int D, int L, int P) {
 CODETR_MSDA_ENTRY(codetr_msda_forward_f16, F16, _Float16, float, CvF16, 2)
 CODETR_MSDA_ENTRY(codetr_msda_forward_bf16, BF16, unsigned short, float, CvBF16, 2)
 CODETR_MSDA_ENTRY(codetr_msda_forward_f32, F32, float, float, CvF32, 4)
+
+#define CODETR_MSDA_FUSED_ENTRY(NAME, TR)                                                                        \
+  int NAME(void* stream, const void* value_dev, const int64_t* spatial_shapes_dev, const int64_t* level_start_dev, \
+           const void* offsets_dev, int64_t offsets_row_stride, const void* logits_dev, int64_t logits_row_stride, \
+           const void* ref_dev, int ref_dim, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,       \
+           void* out_dev) {                                                                                      \
+    const int rc = check_args(value_dev, spatial_shapes_dev, level_start_dev, offsets_dev, logits_dev, out_dev, B, \
+                              S, M, D, L, Nq, P, 1);                                                             \
+    if (rc) return rc;                                                                                           \
+    if (!ref_dev || (ref_dim != 2 && ref_dim != 4)) return CODETR_E_BADARG;                                      \
+    if (offsets_row_stride < (int64_t)M * L * P * 2 || logits_row_stride < (int64_t)M * L * P ||                  \
+        offsets_row_stride > 0x7fffffff || logits_row_stride > 0x7fffffff)                                       \
+      return CODETR_E_BADARG;                                                                                    \
+    const int lanes = tiled_lanes(2, D, L, P);                                                                   \
+    if (!lanes) return CODETR_E_UNSUPPORTED;                                                                     \
+    const FusedArgs fa{ref_dev, ref_dim, (int)offsets_row_stride, (int)logits_row_stride};                       \
+    return dispatch_fused<TR>(lanes, static_cast<hipStream_t>(stream), value_dev, spatial_shapes_dev,            \
+                              level_start_dev, offsets_dev, logits_dev, out_dev, B, S, M, L, Nq, P, fa);         \
+  }
+
+CODETR_MSDA_FUSED_ENTRY(codetr_msda_fused_forward_f16, F16)
+CODETR_MSDA_FUSED_ENTRY(codetr_msda_fused_forward_bf16, BF16)
 
 int codetr_msda_forward_f64(void* stream, const void* value_dev, const int64_t* spatial_shapes_dev,
                             const int64_t* level_start_dev, const void* loc_dev, const void* weight_dev, int64_t B,

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 4
+#define CODETR_HIP_ABI_VERSION 5
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -83,6 +83,32 @@ int codetr_msda_forward_f64(void *stream, const void *value_dev, const int64_t *
                             int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step,
                             void *out_dev);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention with its prologue fused.
+ *
+ * Same gather as above, but the kernel also performs the steps the reference's module runs between
+ * its two projections and the op (codetr/multi_scale_deformable_attention.py:180-196): softmax over
+ * the L*P attention logits of each (query, head), and sampling_locations = reference point +
+ * normalised offset.  The sampling-location and attention-weight tensors (131 MB + 65 MB per encoder
+ * call at 1920x1280 fp16) never exist.  The unfused entry points above remain the op's public form.
+ *
+ *   offsets_dev [B*Nq rows, offsets_row_stride]  columns [0, M*L*P*2): (x, y) offsets, order (m, l, p, xy)
+ *   logits_dev  [B*Nq rows, logits_row_stride]   columns [0, M*L*P): raw attention logits, order (m, l, p)
+ *               (both may be column ranges of ONE fused projection output: pass the same row stride
+ *                and pointers offset by the column start)
+ *   ref_dev     [B, Nq, L, ref_dim]  ref_dim 2: (x, y), loc = ref + off / (W_l, H_l)
+ *                                    ref_dim 4: (x, y, w, h), loc = ref_xy + off / P * ref_wh * 0.5
+ * fp32 softmax / locations; 16-bit storage only; D*2 bytes per head must be 32, 64 or 128.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_msda_fused_forward_f16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                                  const int64_t *level_start_dev, const void *offsets_dev, int64_t offsets_row_stride,
+                                  const void *logits_dev, int64_t logits_row_stride, const void *ref_dev, int ref_dim,
+                                  int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, void *out_dev);
+int codetr_msda_fused_forward_bf16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                                   const int64_t *level_start_dev, const void *offsets_dev, int64_t offsets_row_stride,
+                                   const void *logits_dev, int64_t logits_row_stride, const void *ref_dev, int ref_dim,
+                                   int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, void *out_dev);
+
 /* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
  * Pure host function; lets tests assert that the model shape takes the tiled path. */
 const char *codetr_msda_variant(int elem_bytes, int M, int D, int L, int P);
@@ -102,6 +128,9 @@ const char *codetr_msda_variant(int elem_bytes, int M, int D, int L, int P);
  *   w_dev        [N, K]  row-major (nn.Linear.weight) T
  *   bias_dev     [N] or NULL                          T
  *   residual_dev [M, N] or NULL (added AFTER the activation, as `identity + ffn(x)` does)   T
+ *   row_mask_dev [M] uint8/bool or NULL: rows with a non-zero mask are written as zeros (before the
+ *                residual) -- `value.masked_fill(key_padding_mask[..., None], 0.0)` of
+ *                codetr/multi_scale_deformable_attention.py:174-175 folded into value_proj
  *   y_dev        [M, N]  (may alias residual_dev)     T
  *   act          0 = none, 1 = ReLU, 2 = GELU (erf form, nn.GELU default)
  *
@@ -109,9 +138,11 @@ const char *codetr_msda_variant(int elem_bytes, int M, int D, int L, int P);
  * (every Linear of the model is; CODETR_E_UNSUPPORTED otherwise); x / w 16-byte aligned.
  * ------------------------------------------------------------------------------------------ */
 int codetr_linear_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
-                      const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act);
+                      const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
+                      int64_t K, int act);
 int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
-                       const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act);
+                       const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
+                       int64_t K, int act);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension: y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta

@@ -102,3 +102,23 @@ def test_linear_unsupported_k_is_loud():
     assert not _cabi.linear_supported(x, w)
     with pytest.raises(RuntimeError, match="outside what the kernel family implements"):
         _cabi.linear(x, w, None, None, None, out)
+
+
+def test_linear_row_mask():
+    from codetr import hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(3, 100, 256, device=DEV, generator=g).half()
+    w = (torch.randn(256, 256, device=DEV, generator=g) / 16).half()
+    b = torch.randn(256, device=DEV, generator=g).half()
+    r = torch.randn(3, 100, 256, device=DEV, generator=g).half()
+    mask = torch.rand(3, 100, device=DEV, generator=g) < 0.3
+    y = hip_ops.linear(x, w, b, row_mask=mask)
+    ref = _ref(x.reshape(-1, 256), w, b, None, None).view(3, 100, 256).masked_fill(mask[..., None], 0.0)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
+    assert (y[mask] == 0).all()
+    y2 = hip_ops.linear(x, w, b, residual=r, row_mask=mask)  # mask applies to the linear output, residual still added
+    torch.testing.assert_close(y2.float(), ref + r.float(), rtol=2e-3, atol=4e-3)
+    w5 = (torch.randn(5, 256, device=DEV, generator=g) / 16).half()  # ragged-N path
+    y3 = hip_ops.linear(x, w5, None, row_mask=mask)
+    assert (y3[mask] == 0).all() and (y3[~mask] != 0).any()

@@ -198,3 +198,70 @@ def test_opcheck_and_stream_semantics():
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(base, captured)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused variant: softmax + sampling-location arithmetic inside the kernel
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("extra_cols", [0, 24])
+def test_fused_prologue_vs_oracle(ref_dim, extra_cols):
+    """fused kernel == oracle( softmax(logits), ref + normalised offsets ) computed in fp64 on the host."""
+    from codetr import _cabi, hip_ops
+
+    rng = np.random.default_rng(3)
+    B, Nq, M, D, P = 2, 77, 8, 32, 4
+    shapes = [(9, 13), (5, 7), (3, 4), (2, 2), (1, 1)]
+    L = len(shapes)
+    ss = np.array(shapes, dtype=np.int64)
+    ls = O.level_start_index_from_shapes(ss)
+    S = int((ss[:, 0] * ss[:, 1]).sum())
+    h = lambda a: a.astype(np.float16).astype(np.float64)  # noqa: E731
+    value = h(rng.standard_normal((B, S, M, D)))
+    off = h(rng.standard_normal((B, Nq, M, L, P, 2)) * 2.0)
+    logits = h(rng.standard_normal((B, Nq, M, L * P)) * 2.0)
+    ref = h(rng.random((B, Nq, L, ref_dim)) * (0.6 if ref_dim == 4 else 1.0) + (0.1 if ref_dim == 4 else 0.0))
+    w = np.exp(logits - logits.max(-1, keepdims=True))
+    w = (w / w.sum(-1, keepdims=True)).reshape(B, Nq, M, L, P)
+    if ref_dim == 2:
+        norm = np.stack((ss[:, 1], ss[:, 0]), -1).astype(np.float64)
+        loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    expect = O.msda_forward_c(value, ss, ls, loc, w, dtype=np.float64, im2col_step=B)
+    # device side: one projection matrix holding (offsets | logits | unrelated columns)
+    proj = np.concatenate((off.reshape(B, Nq, -1), logits.reshape(B, Nq, -1),
+                           rng.standard_normal((B, Nq, extra_cols))), -1)
+    t = lambda a, dt: torch.as_tensor(np.asarray(a)).to(DEV).to(dt).contiguous()  # noqa: E731
+    before = _cabi.CALLS["msda_fused"]
+    out = hip_ops.msda_fused(t(value, torch.float16), t(ss, torch.int64), t(ls, torch.int64), t(proj, torch.float16), 0,
+                             M * L * P * 2, t(ref, torch.float16), L, P)
+    torch.cuda.synchronize()
+    assert _cabi.CALLS["msda_fused"] == before + 1
+    np.testing.assert_allclose(out.float().cpu().numpy(), expect, rtol=2e-3, atol=2e-3)
+
+
+def test_module_takes_fused_path_and_masks_value_rows():
+    """MultiScaleDeformableAttention (fp16) = fused projection GEMM + fused MSDA; key_padding_mask rows of the value
+    map are zeroed inside the value_proj GEMM.  Compared with the reference's module output (golden)."""
+    from codetr import _cabi
+    from codetr.multi_scale_deformable_attention import MultiScaleDeformableAttention
+    from helpers_model import assert_close_lowp, seeded_params, unpack_param_spec
+
+    g = np.load(os.path.join(GOLDEN, "model_msda_module.npz"))
+    m = MultiScaleDeformableAttention(embed_dims=256, num_levels=5, dropout=0.0)
+    m.load_state_dict(seeded_params(unpack_param_spec(g), int(g["seed"])))
+    m = m.to(DEV).half().eval()
+    t = lambda k, dt=torch.float16: torch.as_tensor(g[k]).to(DEV).to(dt)  # noqa: E731
+    before = dict(_cabi.CALLS)
+    with torch.no_grad():
+        out2 = m(t("value"), value=None, query_pos=t("query_pos"), key_padding_mask=t("key_padding_mask", torch.bool),
+                 reference_points=t("ref2"), spatial_shapes=t("spatial_shapes", torch.int64),
+                 level_start_index=t("level_start_index", torch.int64))
+        out4 = m(t("query4"), value=t("value"), query_pos=t("query_pos4"), key_padding_mask=t("key_padding_mask", torch.bool),
+                 reference_points=t("ref4"), spatial_shapes=t("spatial_shapes", torch.int64),
+                 level_start_index=t("level_start_index", torch.int64))
+    assert _cabi.CALLS["msda_fused"] - before["msda_fused"] == 2 and _cabi.CALLS["msda"] == before["msda"]
+    assert _cabi.CALLS["linear"] - before["linear"] == 6  # value_proj, (offsets|logits), output_proj  x 2 calls
+    assert_close_lowp(out2.float().cpu().numpy(), g["out2"], 5e-3, 5e-2, "module out, 2-d refs")
+    assert_close_lowp(out4.float().cpu().numpy(), g["out4"], 5e-3, 5e-2, "module out, 4-d refs")
