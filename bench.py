@@ -154,12 +154,14 @@ def main():
     g = torch.Generator(device=device).manual_seed(42 + rank)
     images = torch.randn(a.batch, 3, H, W, device=device, generator=g).to(dtype)  # ~ mean/std-normalised image
     masks = torch.zeros(a.batch, H, W, device=device, dtype=dtype)
+    from codetr.sharding import gather_detections, pack_detections
+
     gathered = torch.empty(world * a.batch, 300, 6, device=device, dtype=torch.float32) if world > 1 else None
 
     def forward():
         with torch.no_grad():
             boxes, scores, labels = model(images, masks)
-        return torch.cat((boxes.float(), scores.float()[..., None], labels.float()[..., None]), -1)  # [B,300,6]
+        return pack_detections(boxes, scores, labels)  # [B,300,6] fp32
 
     static_out = None
     graph = None
@@ -187,7 +189,7 @@ def main():
         else:
             static_out = forward()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, static_out)
+            gather_detections(static_out, world * a.batch, out=gathered)  # the only collective: 7.2 KB per image
 
     for _ in range(a.warmup):
         step()
