@@ -11,8 +11,9 @@
 //   * one 256-thread workgroup (4 waves, 2x2) owns a 128(M) x 128(N) output tile; each wave a
 //     64x64 quadrant = 4x4 MFMA tiles of 16x16, K-step 64 (2 MFMAs deep per tile).
 //   * both operands are K-contiguous (X rows, W rows), so both tiles are staged the same way:
-//     global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), two LDS
-//     buffers, next K-tile in flight while the current one feeds the MFMAs.
+//     global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into a ring
+//     of 2-4 LDS buffers; up to 3 K-tiles stay in flight across the one raw s_barrier per K step
+//     (counted s_waitcnt vmcnt), 64 KiB of LDS in every configuration -> 2 workgroups per CU.
 //   * LDS image = [128 rows][8 x 16-B chunks]; the DMA destination is lane-linear, so the
 //     bank-conflict swizzle is applied on the SOURCE address and undone on the fragment read:
 //     chunk position = chunk ^ ((row >> 1) & 7)  -> the 16 rows of a ds_read_b128 lane group
@@ -28,14 +29,16 @@
 // M and N are arbitrary (edge tiles clamp their loads and mask their stores).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "codetr_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128;
 constexpr int kThreads = 256;
-constexpr int kTileBytes = 128 * BK * 2;  // one operand tile: 16 KiB
+constexpr int kStagePitch = 64 * 2 + 16;            // epilogue staging: bytes per staged row of a wave's 64x64 quadrant
+constexpr int kStagingBytes = 4 * 64 * kStagePitch;  // 36,864 B for the 4 waves
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -91,17 +94,27 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_v);
 }
 
-// Stage one 128 x 64 operand tile (rows row0.. of a [rows_total, K] matrix, columns k0..k0+63) into LDS.
-// 4 LDS-DMA instructions per thread; LDS 16-B unit index u = q*256 + tid -> row u/8, position u%8,
-// which holds source chunk (u%8) ^ ((row>>1)&7).
+// LDS image of one operand tile: [128 rows][CH = BKT/8 chunks of 16 B].  The DMA destination is lane-linear, so
+// the bank swizzle lives on the SOURCE address: LDS position p of row r holds source chunk p ^ sw(r), and the
+// fragment read applies the same XOR.  sw(r) spreads the 16 rows of a ds_read_b128 lane group over distinct
+// 16-B slots of the 256-B bank row: (r>>1)&7 for 128-B rows, (r>>2)&3 for 64-B rows.
+template <int BKT>
+__device__ __forceinline__ int sw(int row) {
+  return BKT == 64 ? (row >> 1) & 7 : (row >> 2) & 3;
+}
+
+// Stage one 128 x BKT operand tile (rows row0.. of a [rows_total, K] matrix, columns k0..k0+BKT-1) into LDS with
+// BKT/16 LDS-DMA instructions per thread (16 B per lane each).
+template <int BKT>
 __device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ src, int rows_total, int K, int row0, int k0,
                                            unsigned char* lds_tile, int tid) {
+  constexpr int CH = BKT / 8;
   const int wave = tid >> 6;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < CH / 2; ++q) {
     const int u = q * kThreads + tid;
-    const int r = u >> 3, pos = u & 7;
-    const int chunk = pos ^ ((r >> 1) & 7);
+    const int r = u / CH, pos = u % CH;
+    const int chunk = pos ^ sw<BKT>(r);
     int grow = row0 + r;
     grow = grow < rows_total ? grow : rows_total - 1;  // edge tiles: re-read the last row, results masked later
     const unsigned short* g = src + (size_t)grow * K + k0 + chunk * 8;
@@ -112,14 +125,29 @@ __device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ sr
   }
 }
 
-template <class T>
+template <class T, int BKT>
 __device__ __forceinline__ typename T::frag read_frag(const unsigned char* lds_tile, int row, int chunk) {
-  const int pos = chunk ^ ((row >> 1) & 7);
-  return *reinterpret_cast<const typename T::frag*>(lds_tile + row * 128 + pos * 16);
+  const int pos = chunk ^ sw<BKT>(row);
+  return *reinterpret_cast<const typename T::frag*>(lds_tile + row * (BKT * 2) + pos * 16);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N < 0, "add the count");
 }
 
 // ACT: 0 none, 1 relu, 2 gelu(erf)
-template <class T, int ACT, bool HAS_BIAS, bool HAS_RES>
+// ACT: 0 none, 1 relu, 2 gelu(erf).  BKT x STAGES = the K pipeline: STAGES LDS buffers of one (W tile, X tile)
+// pair each, STAGES-1 tiles of LDS-DMA in flight across the per-K-step barrier (raw s_barrier + counted
+// s_waitcnt vmcnt: a __syncthreads() would drain the DMA queue, cdna_hip_programming.md section 5).
+template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, int BKT, int STAGES>
 __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* __restrict__ X,
                                                           const unsigned short* __restrict__ W,
                                                           const unsigned short* __restrict__ bias,
@@ -127,8 +155,14 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
                                                           unsigned short* __restrict__ Y,
                                                           const unsigned char* __restrict__ row_mask, int M, int N,
                                                           int K, int tiles_n) {
-  // [buf][operand][16 KiB]; one object only (a second __shared__ object de-pipelines LDS-DMA kernels)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kTileBytes];
+  constexpr int kTileBytes = 128 * BKT * 2;        // one operand tile
+  constexpr int kStageBytes = 2 * kTileBytes;      // W tile + X tile
+  constexpr int LPS = 2 * (BKT / 16);              // LDS-DMA instructions per thread per stage
+  constexpr int kLdsBytes = STAGES * kStageBytes > kStagingBytes ? STAGES * kStageBytes : kStagingBytes;
+  static_assert(kLdsBytes <= 64 * 1024, "pipeline does not fit 64 KiB");
+  static_assert(STAGES >= 2 && STAGES <= 4, "");
+  // one object only (a second __shared__ object de-pipelines LDS-DMA kernels); the epilogue staging reuses it
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;  // wave quadrant inside the 128x128 tile
@@ -143,36 +177,52 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / BK;
-  stage_tile(W, N, K, n0, 0, lds, tid);
-  stage_tile(X, M, K, m0, 0, lds + kTileBytes, tid);
-  __syncthreads();  // (emits the vmcnt(0) that retires the LDS-DMA before the barrier)
+  // bias of this lane's 4 x 4 output columns: loaded now so its latency hides under the K loop
+  const int ncol = 4 * (lane >> 4);
+  s16x4 bias_v[4];
+  if (HAS_BIAS && (N & 7) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + ncol;
+      bias_v[i] = n < N ? *reinterpret_cast<const s16x4*>(bias + n) : s16x4{0, 0, 0, 0};
+    }
+  }
+
+  const int nk = K / BKT;
+  auto issue = [&](int t) {
+    unsigned char* buf = lds + (t % STAGES) * kStageBytes;
+    stage_tile<BKT>(W, N, K, n0, t * BKT, buf, tid);
+    stage_tile<BKT>(X, M, K, m0, t * BKT, buf + kTileBytes, tid);
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < nk) issue(s0);
 
   const int frow = lane & 15, fchunk = lane >> 4;
-  int cur = 0;
   for (int t = 0; t < nk; ++t) {
-    unsigned char* bufW = lds + cur * 2 * kTileBytes;
-    unsigned char* bufX = bufW + kTileBytes;
-    if (t + 1 < nk) {
-      unsigned char* nW = lds + (cur ^ 1) * 2 * kTileBytes;
-      stage_tile(W, N, K, n0, (t + 1) * BK, nW, tid);
-      stage_tile(X, M, K, m0, (t + 1) * BK, nW + kTileBytes, tid);
-    }
+    // tiles issued beyond t: t+1 .. min(nk-1, t+STAGES-2); tile t itself must have landed
+    const int ahead = (nk - 1 < t + STAGES - 2 ? nk - 1 : t + STAGES - 2) - t;
+    if (STAGES >= 4 && ahead == 2) wait_vmcnt<2 * LPS>();
+    else if (STAGES >= 3 && ahead == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's part of tile t is in LDS; everyone is done reading tile t-1
+    if (t + STAGES - 1 < nk) issue(t + STAGES - 1);  // overwrites the buffer of tile t-1
+    const unsigned char* bufW = lds + (t % STAGES) * kStageBytes;
+    const unsigned char* bufX = bufW + kTileBytes;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BKT / 32; ++ks) {
       typename T::frag a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = read_frag<T>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
+      for (int i = 0; i < 4; ++i) a[i] = read_frag<T, BKT>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = read_frag<T>(bufX, wm * 64 + j * 16 + frow, ks * 4 + fchunk);
+      for (int j = 0; j < 4; ++j) b[j] = read_frag<T, BKT>(bufX, wm * 64 + j * 16 + frow, ks * 4 + fchunk);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma(a[i], b[j], acc[i][j]);
     }
-    __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
-    cur ^= 1;
   }
+  __builtin_amdgcn_s_barrier();  // all fragment reads done (no DMA is in flight any more): LDS is free for the epilogue
 
   // ---- epilogue -------------------------------------------------------------------------------
   // accumulator layout: for MFMA tile (i, j) a lane holds n = wn*64 + i*16 + 4*(lane>>4) + r (r = 0..3),
@@ -182,19 +232,18 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
   // accumulators -> fp16 image of the wave's 64x64 quadrant in its private LDS region -> read back by
   // rows, add the residual (fp16 + fp16 -> fp16, the same two roundings as `identity + linear(x)`
   // in the reference's fp16 path) -> global_store_dwordx4.
-  const int ncol = 4 * (lane >> 4);
   if ((N & 7) == 0) {
-    constexpr int kPitch = 64 * 2 + 16;  // bytes per staged row (+16: rows 0/8 do not share a bank pair)
+    constexpr int kPitch = kStagePitch;  // bytes per staged row (+16: rows 0/8 do not share a bank pair)
     unsigned char* stage = lds + wave * (64 * kPitch);  // main loop is done with LDS (barrier above)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + wn * 64 + i * 16 + ncol;
       float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (HAS_BIAS && n < N) {  // N % 8 == 0 and n % 4 == 0: the 4 columns are all inside or all outside
-        const s16x4 bb = *reinterpret_cast<const s16x4*>(bias + n);
+      if (HAS_BIAS) {  // N % 8 == 0 and n % 4 == 0: the 4 columns are all inside or all outside (zeros then)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = T::to_f32((unsigned short)bb[r]);
+        for (int r = 0; r < 4; ++r) bv[r] = T::to_f32((unsigned short)bias_v[i][r]);
       }
+      (void)n;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         s16x4 o;
@@ -262,8 +311,25 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
   }
 }
 
-template <class T, int ACT>
-int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
+// Pipeline configuration per problem (A/B on MI355X over the model's 22 layer shapes, tools/bench_linear.py):
+//   K <= 256 (every 256-wide transformer layer, Swin stage 0): 32-deep K steps, 2 buffers -> 36 KiB of LDS, 3
+//     workgroups per CU.  These layers run 4-8 K steps per tile; their cost is the per-tile fixed latency
+//     (first loads, bias, LDS staging, stores), which only more resident workgroups hide.
+//   K  > 256: 64-deep steps, 2 buffers (64 KiB, 2 workgroups per CU): twice the MFMA work per barrier.
+//   A 4-deep ring (3 tiles of DMA in flight, counted vmcnt) measured 5-10 % slower than either on every shape:
+//   the exposed latency is per tile, not per K step.
+// CODETR_GEMM_CFG=<bk><stages> (322, 324, 642) overrides, for A/B measurements only.
+int pipeline_cfg(int64_t K) {
+  static const int forced = [] {
+    const char* e = getenv("CODETR_GEMM_CFG");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 324 || forced == 322 || forced == 642) return forced;
+  return K <= 256 ? 322 : 642;
+}
+
+template <class T, int ACT, int BKT, int STAGES>
+int launch_cfg(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
                const void* mask, int M, int N, int K) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(kThreads);
@@ -273,19 +339,29 @@ int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+template <class T, int ACT>
+int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
+               const void* mask, int M, int N, int K) {
+  switch (pipeline_cfg(K)) {
+    case 324: return launch_cfg<T, ACT, 32, 4>(st, X, W, bias, R, Y, mask, M, N, K);
+    case 322: return launch_cfg<T, ACT, 32, 2>(st, X, W, bias, R, Y, mask, M, N, K);
+    default: return launch_cfg<T, ACT, 64, 2>(st, X, W, bias, R, Y, mask, M, N, K);
+  }
 }
 
 template <class T>
 int launch(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
            int64_t M, int64_t N, int64_t K, int act) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return CODETR_E_BADARG;
-  if (K % BK != 0 || act < 0 || act > 2) return CODETR_E_UNSUPPORTED;
+  if (K % 64 != 0 || act < 0 || act > 2) return CODETR_E_UNSUPPORTED;
   if (M > 0x7fffffffLL || N > 0x7fffffffLL || K > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   if (((M + BM - 1) / BM) * ((N + BN - 1) / BN) > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) return CODETR_E_BADARG;
