@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -34,6 +34,9 @@ SIGNATURES = {
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
     "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
+    "codetr_groupnorm_tokens_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "codetr_groupnorm_tokens_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i32,
+                                           ctypes.c_float]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
 }
 
@@ -41,7 +44,7 @@ _lib = None
 
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
-CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0}
+CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0}
 
 
 def load():
@@ -194,3 +197,20 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
         ref.data_ptr(), ref.shape[-1], B, S, M, D, num_levels, Nq, num_points, out.data_ptr())
     check(rc, "codetr_msda_fused_forward")
     return out
+
+
+def groupnorm_tokens_supported(x, groups) -> bool:
+    return x.dtype == torch.float16 and x.shape[-1] == groups * 8 and 256 % groups == 0
+
+
+def groupnorm_tokens(x, gamma, beta, groups, eps, out_slice, out_batch_stride):
+    """x [B,HW,C] contiguous -> GN written to out_slice (a view whose data_ptr is the destination of image 0,
+    row 0; consecutive images are out_batch_stride elements apart)."""
+    lib = load()
+    CALLS["groupnorm_tokens"] += 1
+    B, HW, C = x.shape
+    ws = torch.empty(lib.codetr_groupnorm_tokens_workspace_bytes(B, HW, C), dtype=torch.uint8, device=x.device)
+    rc = lib.codetr_groupnorm_tokens_f16(current_stream_ptr(x.device), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                         out_slice.data_ptr(), out_batch_stride, ws.data_ptr(), B, HW, C, groups,
+                                         float(eps))
+    check(rc, "codetr_groupnorm_tokens_f16")

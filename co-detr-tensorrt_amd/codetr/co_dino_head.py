@@ -97,16 +97,23 @@ class CoDINOHead(nn.Module):
                 capture=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """mlvl_feats: list of [B,C,h,w]; img_masks [B,H,W] (0 = image, 1 = padding).
         Returns boxes [B,K,4] (x1,y1,x2,y2 in input pixels), scores [B,K], labels [B,K] int64; K = max_per_img."""
+        shapes = [tuple(f.shape[-2:]) for f in mlvl_feats]
+        feat = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
+        return self.forward_flat(feat, shapes, img_masks, forced_topk_indices, capture)
+
+    def forward_flat(self, feat, shapes, img_masks, forced_topk_indices=None, capture=None):
+        """`forward` on the flattened multi-level map feat [B, S, C] (+ the level shapes): what the token-major
+        backbone/neck path hands over, no NCHW round trip."""
         Himg, Wimg = img_masks.shape[-2:]
         masks, pos = [], []
         m4 = img_masks.unsqueeze(1)
-        for f in mlvl_feats:
-            m = F.interpolate(m4, size=f.shape[-2:]).to(torch.bool).squeeze(1)  # nearest
+        for hw in shapes:
+            m = F.interpolate(m4, size=tuple(hw)).to(torch.bool).squeeze(1)  # nearest
             masks.append(m)
-            pos.append(self.positional_encoding(m, dtype=f.dtype))
-        state, refs = self.transformer(mlvl_feats, masks, pos, reg_branches=self.reg_branches,
-                                       cls_branches=self.cls_branches if self.as_two_stage else None,
-                                       forced_topk_indices=forced_topk_indices, capture=capture)
+            pos.append(self.positional_encoding.forward_tokens(m, dtype=feat.dtype))
+        state, refs = self.transformer.forward_flat(feat, shapes, masks, pos, reg_branches=self.reg_branches,
+                                                    cls_branches=self.cls_branches if self.as_two_stage else None,
+                                                    forced_topk_indices=forced_topk_indices, capture=capture)
         lvl = len(self.transformer.decoder.layers) - 1
         cls_head = self.cls_branches[lvl]
         cls = hip_ops.linear(state, cls_head.weight, cls_head.bias)  # [B,Nq,classes]

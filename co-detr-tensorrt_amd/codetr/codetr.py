@@ -73,7 +73,17 @@ class CoDETR(nn.Module):
 
     def forward(self, batch_inputs: Tensor, img_masks: Tensor, forced_topk_indices=None,
                 capture=None) -> Tuple[Tensor, Tensor, Tensor]:
-        feats = self.backbone(batch_inputs)
+        if (capture is None and hasattr(self.backbone, "forward_tokens") and hasattr(self, "neck")
+                and batch_inputs.is_cuda):
+            # token-major path: backbone stage outputs stay [B, HW, C], the neck's 1x1 convs are linears over
+            # tokens, GroupNorm writes straight into the encoder's [B, S, 256] input -- no NCHW round trip
+            tokens = self.backbone.forward_tokens(batch_inputs)
+            if self.neck.tokens_supported(tokens):
+                flat, shapes = self.neck.forward_tokens(tokens)
+                return self.query_head.forward_flat(flat, shapes, img_masks, forced_topk_indices=forced_topk_indices)
+            feats = [t.view(-1, *hw, t.shape[-1]).permute(0, 3, 1, 2).contiguous() for t, hw in tokens]
+        else:
+            feats = self.backbone(batch_inputs)
         if capture is not None:
             capture["backbone_feats"] = feats
         feats = self.neck(feats)

@@ -17,7 +17,7 @@ from . import _cabi
 
 # ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
 NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_window_attention(f16, head_dim 32)",
-          "msda_fused(softmax + sampling locations in-kernel)"}
+          "msda_fused(softmax + sampling locations in-kernel)", "groupnorm_tokens(f16, 8 ch/group)"}
 
 
 def _gpu(x, what):
@@ -89,6 +89,23 @@ def layer_norm(x, weight, bias, eps=1e-5):
 def group_norm(x, groups, weight, bias, eps=1e-5):
     _gpu(x, "group_norm")
     return F.group_norm(x, groups, weight, bias, eps)
+
+
+def groupnorm_tokens_supported(x, groups):
+    return x.is_cuda and _cabi.groupnorm_tokens_supported(x, groups)
+
+
+def groupnorm_tokens_into(x, gamma, beta, groups, eps, dest, row_start):
+    """GroupNorm of token-major x [B,HW,C] written into dest[:, row_start:row_start+HW, :] (dest [B,S,C] contiguous)."""
+    _gpu(x, "groupnorm_tokens_into")
+    B, HW, C = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if not dest.is_contiguous() or dest.shape[0] != B or dest.shape[2] != C:
+        raise AssertionError("destination must be a contiguous [B, S, C] tensor")
+    with torch.cuda.device(x.device):
+        _cabi.groupnorm_tokens(x, gamma, beta, groups, eps, dest[0, row_start:], dest.shape[1] * C)
+    return dest
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0):

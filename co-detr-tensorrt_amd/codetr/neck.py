@@ -55,6 +55,45 @@ class ChannelMapper(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
+    def tokens_supported(self, token_feats):
+        """True when every level can take the token-major path: 1x1 convs followed by GN with 8 channels per group."""
+        x0 = token_feats[0][0]
+        return all(c.conv.kernel_size == (1, 1) and c.groups is not None and c.conv.bias is None
+                   and hip_ops.groupnorm_tokens_supported(x0.new_empty(1, 1, c.conv.out_channels), c.groups)
+                   for c in self.convs)
+
+    def forward_tokens(self, token_feats):
+        """token_feats: list of (tokens [B, HW_i, C_i], (H_i, W_i)) from the backbone ->
+        (flat [B, S, out_channels] with the levels concatenated in order, list of (H_l, W_l)).
+        The 1x1 convs run as linears over tokens (native GEMM), GroupNorm writes each level directly into its
+        slice of `flat`; only the stride-2 3x3 extra level(s) go through NCHW (1/16 of the pixels of level 0)."""
+        if len(token_feats) != len(self.convs):
+            raise AssertionError("ChannelMapper: wrong number of input levels")
+        shapes = [hw for _, hw in token_feats]
+        n_extra = len(self.extra_convs) if self.extra_convs else 0
+        h, w = shapes[-1]
+        for _ in range(n_extra):
+            h, w = (h + 1) // 2, (w + 1) // 2
+            shapes.append((h, w))
+        B = token_feats[0][0].shape[0]
+        Cout = self.convs[0].conv.out_channels
+        S = sum(a * b for a, b in shapes)
+        flat = token_feats[0][0].new_empty(B, S, Cout)
+        start = 0
+        for conv, (t, hw) in zip(self.convs, token_feats):
+            y = hip_ops.linear(t, conv.conv.weight.view(Cout, -1), None)
+            hip_ops.groupnorm_tokens_into(y, conv.gn.weight, conv.gn.bias, conv.groups, conv.gn.eps, flat, start)
+            start += hw[0] * hw[1]
+        if n_extra:
+            t, hw = token_feats[-1]
+            src = t.view(B, hw[0], hw[1], -1).permute(0, 3, 1, 2)
+            for i, conv in enumerate(self.extra_convs):
+                src = conv(src)
+                n = src.shape[-2] * src.shape[-1]
+                flat[:, start:start + n] = src.flatten(2).transpose(1, 2)
+                start += n
+        return flat, shapes
+
     def forward(self, inputs):
         if len(inputs) != len(self.convs):
             raise AssertionError("ChannelMapper: wrong number of input levels")

@@ -18,6 +18,11 @@ class SinePositionalEncoding(nn.Module):
         """mask [B,H,W], non-zero = padding -> [B, 2*num_feats, H, W] (y features first).
         The running sums are accumulated in `dtype`, as the reference does (:78-79)."""
         B, H, W = mask.shape
+        return self.forward_tokens(mask, dtype).view(B, H, W, -1).permute(0, 3, 1, 2)
+
+    def forward_tokens(self, mask: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+        """Same encoding in the layout the transformer consumes: [B, H*W, 2*num_feats]."""
+        B, H, W = mask.shape
         valid = 1 - mask.to(torch.int)
         y = valid.cumsum(1, dtype=dtype)
         x = valid.cumsum(2, dtype=dtype)
@@ -30,7 +35,7 @@ class SinePositionalEncoding(nn.Module):
         py = y[..., None] / dim_t
         px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).view(B, H, W, -1)
         py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).view(B, H, W, -1)
-        return torch.cat((py, px), dim=3).permute(0, 3, 1, 2)
+        return torch.cat((py, px), dim=3).view(B, H * W, -1)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}(num_feats={self.num_feats}, temperature={self.temperature}, "

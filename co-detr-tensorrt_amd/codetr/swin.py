@@ -276,17 +276,21 @@ class SwinTransformer(nn.Module):
             elif isinstance(m, WindowMSA):
                 m.init_weights()
 
-    def forward(self, x):
-        """[B,3,H,W] -> list of [B, C_i, H/2^(i+2), W/2^(i+2)] for i in out_indices."""
+    def forward_tokens(self, x):
+        """[B,3,H,W] -> list of (tokens [B, H_i*W_i, C_i], (H_i, W_i)) for i in out_indices: the stage outputs
+        after their output norm, in the token-major layout they are computed in."""
         x, hw = self.patch_embed(x)
         outs = []
         for i, stage in enumerate(self.stages):
             x, hw, out, out_hw = stage(x, hw)
             if i in self.out_indices:
                 n = getattr(self, f"norm{i}")
-                out = hip_ops.layer_norm(out, n.weight, n.bias, n.eps)
-                outs.append(out.view(-1, *out_hw, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
+                outs.append((hip_ops.layer_norm(out, n.weight, n.bias, n.eps), out_hw))
         return outs
+
+    def forward(self, x):
+        """[B,3,H,W] -> list of [B, C_i, H/2^(i+2), W/2^(i+2)] for i in out_indices."""
+        return [t.view(-1, *hw, t.shape[-1]).permute(0, 3, 1, 2).contiguous() for t, hw in self.forward_tokens(x)]
 
 
 def swin_converter(ckpt):

@@ -145,12 +145,16 @@ def get_valid_ratio(mask, dtype=torch.float32):
 
 
 def get_reference_points(mlvl_feats, valid_ratios, device):
-    """pixel centres of every level, normalised by the VALID extent -> [B, S, 2] (x, y)."""
+    """pixel centres of every level, normalised by the VALID extent -> [B, S, 2] (x, y).
+    `mlvl_feats`: the level tensors [B,C,H,W], or a list of (H, W) tuples (dtype then follows valid_ratios)."""
     out = []
     for lvl, feat in enumerate(mlvl_feats):
-        B, _, H, W = feat.shape
-        ys, xs = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=feat.dtype, device=device),
-                                torch.linspace(0.5, W - 0.5, W, dtype=feat.dtype, device=device), indexing="ij")
+        if isinstance(feat, tuple):
+            (H, W), B, dt = feat, valid_ratios.shape[0], valid_ratios.dtype
+        else:
+            (B, _, H, W), dt = feat.shape, feat.dtype
+        ys, xs = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=dt, device=device),
+                                torch.linspace(0.5, W - 0.5, W, dtype=dt, device=device), indexing="ij")
         y = ys.reshape(1, -1) / (valid_ratios[:, lvl, 1].reshape(B, 1) * H)
         x = xs.reshape(1, -1) / (valid_ratios[:, lvl, 0].reshape(B, 1) * W)
         out.append(torch.stack((x, y), -1))
@@ -258,17 +262,25 @@ class CoDinoTransformer(nn.Module):
         Two test hooks that do not exist in the reference: ``forced_topk_indices`` [B,Nq] replaces the
         proposal top-k (parity checks on random weights, where top-k is unstable: reference
         tests/test_export.py:638-655) and ``capture`` (a dict) receives intermediates."""
-        if not self.as_two_stage:
-            raise AssertionError("as_two_stage must be True for DINO")
-        dev = mlvl_feats[0].device
         shapes = [tuple(f.shape[-2:]) for f in mlvl_feats]
         feat = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)  # [B,S,C]
+        pos_tokens = [p.flatten(2).transpose(1, 2) for p in mlvl_pos_embeds]
+        return self.forward_flat(feat, shapes, mlvl_masks, pos_tokens, reg_branches, cls_branches, forced_topk_indices,
+                                 capture)
+
+    def forward_flat(self, feat, shapes, mlvl_masks, mlvl_pos_tokens, reg_branches=None, cls_branches=None,
+                     forced_topk_indices=None, capture=None):
+        """Same computation on inputs that are already in the transformer's layout: feat [B,S,C] (levels
+        concatenated), shapes [(H_l, W_l)], masks list of [B,H_l,W_l] bool, positional encodings list of
+        [B, H_l*W_l, C]."""
+        if not self.as_two_stage:
+            raise AssertionError("as_two_stage must be True for DINO")
+        dev = feat.device
         mask = torch.cat([m.flatten(1) for m in mlvl_masks], 1)  # [B,S]
-        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embeds[l].view(1, 1, -1)
-                         for l, p in enumerate(mlvl_pos_embeds)], 1)
+        pos = torch.cat([p + self.level_embeds[l].view(1, 1, -1) for l, p in enumerate(mlvl_pos_tokens)], 1)
         spatial_shapes, level_start_index = _shape_tensors(shapes, dev)
         valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
-        reference_points = get_reference_points(mlvl_feats, valid_ratios, device=dev)  # [B,S,2]
+        reference_points = get_reference_points([tuple(s) for s in shapes], valid_ratios, device=dev)  # [B,S,2]
         ref_by_level = reference_points[:, :, None] * valid_ratios[:, None]  # [B,S,L,2]
 
         memory = self.encoder.forward_bf(feat, pos, mask, reference_points=ref_by_level, spatial_shapes=spatial_shapes,

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 5
+#define CODETR_HIP_ABI_VERSION 6
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -179,6 +179,25 @@ int codetr_layernorm_bf16(void *stream, const void *x_dev, const void *gamma_dev
 int codetr_window_attention_f16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
                                 const void *rel_bias_dev, void *out_dev, int64_t B, int64_t H, int64_t W,
                                 int num_heads, int head_dim, int window_size, int shift);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm on token-major activations, written into a slice of the flattened multi-level map.
+ *
+ * Replaces nn.GroupNorm(32, 256) of the ChannelMapper neck (mmdet v3.3.0, built at
+ * codetr/codetr.py:53-54 from configs lsj:40-47) together with the flatten / transpose / cat copies
+ * that turn the NCHW levels into the encoder's [B, S, C] input (codetr/transformer.py:508-519).
+ *
+ *   x_dev   [B, HW, C] f16 (output of the level's 1x1 conv run as a linear over tokens)
+ *   out_dev points at row `level_start` of image 0 in the [B, S, C] destination;
+ *           out_batch_stride = S*C elements between images
+ *   workspace_dev: codetr_groupnorm_tokens_workspace_bytes(B, HW, C) bytes of device scratch
+ *   groups must equal C/8 (8 channels = one 16-byte chunk per group: GN(32) on 256 channels)
+ * fp32 partial sums per 512-row slab, fp64 final reduction, statistics over (HW x 8) per (image, group).
+ * ------------------------------------------------------------------------------------------ */
+int64_t codetr_groupnorm_tokens_workspace_bytes(int64_t B, int64_t HW, int64_t C);
+int codetr_groupnorm_tokens_f16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev,
+                                void *out_dev, int64_t out_batch_stride, void *workspace_dev, int64_t B, int64_t HW,
+                                int64_t C, int groups, float eps);
 
 #ifdef __cplusplus
 }

@@ -238,3 +238,44 @@ def test_full_codetr_fp32_vs_oracle(backbone, hw):
            if torch.isfinite(b_).all() and torch.isfinite(s_)}
     untied = {t for t in exp if sum(1 for u in exp if u[0] == t[0]) == 1 and t[0] > float(sc[0].min())}
     assert untied <= own
+
+
+def test_token_major_path_equals_nchw_path():
+    """CoDETR.forward's token-major route (Swin tokens -> linear + native GroupNorm into [B,S,256] -> head) against
+    the generic NCHW route of the same model (taken when `capture` is requested), fp16, padded second image."""
+    import codetr
+    from codetr import _cabi
+
+    torch.manual_seed(0)
+    cfg = _tiny_codetr_cfg("swin")
+    cfg["backbone"].update(embed_dims=64, num_heads=[2, 4, 8, 16], window_size=12)
+    cfg["neck"]["in_channels"] = [64, 128, 256, 512]
+    model = codetr.CoDETR(**cfg)
+    spec = [(k, tuple(v.shape)) for k, v in model.named_parameters()]
+    full = dict(model.state_dict())
+    full.update(seeded_params(spec, 5, scale=1.0))
+    model.load_state_dict(full)
+    model = model.to(DEV).half().eval()
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(2, 3, 150, 200, generator=g).to(DEV).half()
+    mask = torch.zeros(2, 150, 200, device=DEV, dtype=torch.float16)
+    mask[1, :, 170:] = 1
+    cap = {}
+    with torch.no_grad():
+        model(img, mask, capture=cap)  # generic path, to obtain a NaN-free proposal selection
+        picks = valid_topk(cap["enc_outputs_class"].float().cpu(), cap["enc_outputs_coord_unact"].float().cpu(), 50).to(DEV)
+        cap = {}
+        b0, s0, l0 = model(img, mask, forced_topk_indices=picks, capture=cap)        # NCHW route
+        before = dict(_cabi.CALLS)
+        b1, s1, l1 = model(img, mask, forced_topk_indices=picks)                     # token-major route
+    assert _cabi.CALLS["groupnorm_tokens"] - before["groupnorm_tokens"] == 4
+    torch.testing.assert_close(s1.float(), s0.float(), rtol=2e-2, atol=2e-3)
+    # near-tied scores may swap ranks between the two routes (fp16 noise): match detections as sets --
+    # same label, score within 2 %, box within 1 px (200 px wide image)
+    matched = 0
+    for bi in range(2):
+        for k in range(20):
+            ok = (l0[bi] == l1[bi, k]) & ((s0[bi] - s1[bi, k]).abs() <= 2e-2 * s1[bi, k].abs() + 2e-3) \
+                & ((b0[bi].float() - b1[bi, k].float()).abs().max(-1)[0] <= 1.0)
+            matched += int(ok.any())
+    assert matched >= 36, matched
