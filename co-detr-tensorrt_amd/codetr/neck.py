@@ -5,6 +5,7 @@ extra 3x3 stride-2 conv + GroupNorm levels, the first of which reads the RAW las
 Parameter names follow mmcv's ConvModule: ``convs.{i}.conv.weight``, ``convs.{i}.gn.{weight,bias}``,
 ``extra_convs.{i}.conv.weight``, ``extra_convs.{i}.gn.*``."""
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import hip_ops
 
@@ -58,9 +59,12 @@ class ChannelMapper(nn.Module):
     def tokens_supported(self, token_feats):
         """True when every level can take the token-major path: 1x1 convs followed by GN with 8 channels per group."""
         x0 = token_feats[0][0]
-        return all(c.conv.kernel_size == (1, 1) and c.groups is not None and c.conv.bias is None
-                   and hip_ops.groupnorm_tokens_supported(x0.new_empty(1, 1, c.conv.out_channels), c.groups)
-                   for c in self.convs)
+        convs = list(self.convs) + list(self.extra_convs or [])
+        return (len(self.extra_convs or []) <= 1
+                and all(c.conv.kernel_size == (1, 1) for c in self.convs)
+                and all(c.groups is not None and c.conv.bias is None
+                        and hip_ops.groupnorm_tokens_supported(x0.new_empty(1, 1, c.conv.out_channels), c.groups)
+                        for c in convs))
 
     def forward_tokens(self, token_feats):
         """token_feats: list of (tokens [B, HW_i, C_i], (H_i, W_i)) from the backbone ->
@@ -85,13 +89,13 @@ class ChannelMapper(nn.Module):
             hip_ops.groupnorm_tokens_into(y, conv.gn.weight, conv.gn.bias, conv.groups, conv.gn.eps, flat, start)
             start += hw[0] * hw[1]
         if n_extra:
+            # 3x3 stride-2 conv on the RAW last backbone level as im2col + native GEMM (K = 9*C_in), then the same GN
             t, hw = token_feats[-1]
+            conv = self.extra_convs[0]
             src = t.view(B, hw[0], hw[1], -1).permute(0, 3, 1, 2)
-            for i, conv in enumerate(self.extra_convs):
-                src = conv(src)
-                n = src.shape[-2] * src.shape[-1]
-                flat[:, start:start + n] = src.flatten(2).transpose(1, 2)
-                start += n
+            cols = F.unfold(src, kernel_size=3, padding=1, stride=2).transpose(1, 2)  # [B, n, C_in*9], (c, ky, kx) order
+            y = hip_ops.linear(cols, conv.conv.weight.view(Cout, -1), None)
+            hip_ops.groupnorm_tokens_into(y, conv.gn.weight, conv.gn.bias, conv.groups, conv.gn.eps, flat, start)
         return flat, shapes
 
     def forward(self, inputs):

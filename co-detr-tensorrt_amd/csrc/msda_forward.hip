@@ -138,16 +138,23 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
   // ---------------- phase 0 (fused only): softmax statistics of every pair's L*P logits ----------------
   float* sm_stats = reinterpret_cast<float*>(entries + (size_t)LP * PAIRS);  // [PAIRS][2] = (max, 1/sum)
   if (FUSED) {
-    for (int pl = threadIdx.x; pl < PAIRS; pl += kThreads) {
-      unsigned g = pair0 + pl;
-      g = g < n_pairs ? g : n_pairs - 1;
-      const S* lg = weight + (size_t)(g / (unsigned)M) * fa.logit_stride + (size_t)(g % (unsigned)M) * LP;
-      float mx = -INFINITY;
-      for (int i = 0; i < LP; ++i) mx = fmaxf(mx, TR::to_f32(lg[i]));
-      float sum = 0.f;
-      for (int i = 0; i < LP; ++i) sum += __expf(TR::to_f32(lg[i]) - mx);
-      sm_stats[2 * pl] = mx;
-      sm_stats[2 * pl + 1] = 1.0f / sum;
+    // the LANES lanes that will serve a pair in phase 2 also split its L*P logits here; max and sum are
+    // combined with shuffles inside that (power-of-two, aligned) lane group -- every thread is busy
+    const int pl0 = threadIdx.x / LANES, sub0 = threadIdx.x % LANES;
+    unsigned g = pair0 + pl0;
+    g = g < n_pairs ? g : n_pairs - 1;
+    const S* lg = weight + (size_t)(g / (unsigned)M) * fa.logit_stride + (size_t)(g % (unsigned)M) * LP;
+    float mx = -INFINITY;
+    for (int i = sub0; i < LP; i += LANES) mx = fmaxf(mx, TR::to_f32(lg[i]));
+#pragma unroll
+    for (int o = LANES / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int i = sub0; i < LP; i += LANES) sum += __expf(TR::to_f32(lg[i]) - mx);
+#pragma unroll
+    for (int o = LANES / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (sub0 == 0) {
+      sm_stats[2 * pl0] = mx;
+      sm_stats[2 * pl0 + 1] = 1.0f / sum;
     }
     __syncthreads();
   }
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
     const int W = (int)spatial_shapes[2 * l + 1];
     const unsigned start = (unsigned)level_start[l];
     const float Hf = (float)H, Wf = (float)W;
+    const float invH = 1.0f / Hf, invW = 1.0f / Wf, half_over_p = 0.5f / (float)P;
     for (int e = threadIdx.x; e < PAIRS * P; e += kThreads) {
       const int pl = e / P, p = e - pl * P;
       unsigned g = pair0 + pl;
@@ -174,11 +182,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
         const S* rp = static_cast<const S*>(fa.ref) + ((size_t)row * L + l) * fa.ref_dim;
         const float rx = TR::to_f32(rp[0]), ry = TR::to_f32(rp[1]);
         if (fa.ref_dim == 2) {
-          x = rx + ox / Wf;
-          y = ry + oy / Hf;
+          x = fmaf(ox, invW, rx);
+          y = fmaf(oy, invH, ry);
         } else {
-          x = rx + ox / (float)P * TR::to_f32(rp[2]) * 0.5f;
-          y = ry + oy / (float)P * TR::to_f32(rp[3]) * 0.5f;
+          x = fmaf(ox * half_over_p, TR::to_f32(rp[2]), rx);
+          y = fmaf(oy * half_over_p, TR::to_f32(rp[3]), ry);
         }
         aw = __expf(TR::to_f32(weight[(size_t)row * fa.logit_stride + col]) - sm_stats[2 * pl]) * sm_stats[2 * pl + 1];
       } else {
