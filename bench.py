@@ -12,9 +12,11 @@ weights of the real architecture (no network: no checkpoint, no COCO).  Images s
 [B,300,6] per step over RCCL.  Timing: W warm-up steps, then exactly K steps between
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks.  Rank 0 prints ONE JSON line.
 
-Extra objects on that line (N=1 only): ``roofline`` -- the MSDA gather kernel (the hand-written kernel
-this round) timed live with HIP events on its launch stream at the encoder shape of the same workload,
-priced with the algorithmic bytes of BASELINE.md section 3; ``cpu_baseline`` -- the fp32 CPU oracle
+Extra objects on that line (N=1 only): ``roofline`` -- the dominant kernel of the forward, the hand-written
+MFMA linear, every launch of one forward timed live with HIP events on its launch stream and priced with
+2*M*N*K flops against the 2.5 PF dense fp16 MFMA peak; ``roofline_msda`` -- the MSDA gather kernel at the
+encoder shape of the same workload, priced with the algorithmic bytes of BASELINE.md section 3 against
+8 TB/s; ``cpu_baseline`` -- the fp32 CPU oracle
 (oracle/codetr_fp32.py + the C MSDA restatement) timed on the host cores on a bounded sample.
 """
 import argparse
@@ -33,6 +35,7 @@ import torch.distributed as dist  # noqa: E402
 
 CFG = os.path.join(ROOT, "co-detr-tensorrt_amd", "configs", "co_dino_5scale_swin_l_16xb1_16e_o365tococo.py")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak (~2.5 PF, not the 2:1-sparse 5 PF)
 
 
 def pyramid(h, w):
@@ -94,6 +97,35 @@ def msda_roofline(B, H, W, dtype, device, iters=30):
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
         "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg_s * 1e6, 1),
+    }
+
+
+def linear_roofline(model, images, masks, device):
+    """The dominant kernel of the workload is the hand-written MFMA linear (`linear_kernel`, ~58 % of the GPU time
+    of a forward): one eager forward with every launch bracketed by HIP events on its launch stream.
+    achieved = sum of algorithmic flops (2*M*N*K per launch) / sum of launch durations."""
+    from codetr import hip_ops
+
+    hip_ops.LINEAR_PROFILE = []
+    try:
+        with torch.no_grad():
+            model(images, masks)
+        torch.cuda.synchronize(device)
+        prof = hip_ops.LINEAR_PROFILE
+    finally:
+        hip_ops.LINEAR_PROFILE = None
+    flops = sum(p[2] for p in prof)
+    secs = sum(p[0].elapsed_time(p[1]) for p in prof) * 1e-3
+    achieved = flops / secs / 1e12
+    big = max(prof, key=lambda p: p[0].elapsed_time(p[1]))
+    return {
+        "kernel": "linear_kernel<f16> (all %d launches of one forward)" % len(prof),
+        "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "algorithmic_flops_per_forward": flops, "sum_launch_ms": round(secs * 1e3, 3),
+        "avg_launch_us": round(secs / len(prof) * 1e6, 1),
+        "longest_launch": {"M": big[3], "N": big[4], "K": big[5], "us": round(big[0].elapsed_time(big[1]) * 1e3, 1),
+                           "TFLOP/s": round(big[2] / (big[0].elapsed_time(big[1]) * 1e-3) / 1e12, 1)},
     }
 
 
@@ -243,7 +275,11 @@ def main():
                               "not the same hardware, so vs_baseline stays null",
         }
         if world == 1 and not a.no_roofline:
-            out["roofline"] = msda_roofline(a.batch, H, W, dtype if dtype != torch.float32 else torch.float32, device)
+            if dtype != torch.float32:
+                out["roofline"] = linear_roofline(model, images, masks, device)
+            out["roofline_msda"] = msda_roofline(a.batch, H, W, dtype, device)
+            if "roofline" not in out:
+                out["roofline"] = out["roofline_msda"]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))

@@ -20,6 +20,11 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "msda_fused(softmax + sampling locations in-kernel)", "groupnorm_tokens(f16, 8 ch/group)"}
 
 
+# bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
+# (entries: (start_event, end_event, flops, M, N, K)); None in normal operation
+LINEAR_PROFILE = None
+
+
 def _gpu(x, what):
     if not x.is_cuda:
         raise RuntimeError(
@@ -54,7 +59,15 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None):
         out = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
         if x2.shape[0] > 0:
             with torch.cuda.device(x.device):
-                _cabi.linear(x2, w, bias, r2, act, out, mk)
+                if LINEAR_PROFILE is None:
+                    _cabi.linear(x2, w, bias, r2, act, out, mk)
+                else:
+                    st = torch.cuda.current_stream(x.device)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    _cabi.linear(x2, w, bias, r2, act, out, mk)
+                    e1.record(st)
+                    LINEAR_PROFILE.append((e0, e1, 2.0 * x2.shape[0] * N * K, x2.shape[0], N, K))
         return out.view(*x.shape[:-1], N)
     # fp32 / odd-K layers (patch-embed is a conv; fp32 runs are parity runs): ATen library GEMM
     y = F.linear(x, weight, bias)
