@@ -49,6 +49,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct HalfT {
   using frag = f16x8;
+  __device__ static s16x4 pack4(const float (&v)[4]) {  // 2 x v_cvt_pk_f16_f32 (round-to-nearest-even)
+    f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    s16x4 o;
+    __builtin_memcpy(&o, &h, 8);
+    return o;
+  }
   __device__ static f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
   __device__ static float to_f32(unsigned short bits) {
     _Float16 h;
@@ -64,6 +70,9 @@ struct HalfT {
 };
 struct BFloatT {
   using frag = bf16x8;
+  __device__ static s16x4 pack4(const float (&v)[4]) {
+    return s16x4{(short)from_f32(v[0]), (short)from_f32(v[1]), (short)from_f32(v[2]), (short)from_f32(v[3])};
+  }
   __device__ static f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
   __device__ static float to_f32(unsigned short bits) { return __uint_as_float(((unsigned)bits) << 16); }
   __device__ static unsigned short from_f32(float v) {
@@ -171,21 +180,31 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
   const int tn = tile % tiles_n, tm = tile / tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
+  // The accumulators start at the bias (D = A.B + C with C = bias broadcast along m): the bias add costs nothing
+  // and its load latency hides under the first K stage.  A lane's 4 registers of tile (i, j) are the 4 consecutive
+  // output columns n = wn*64 + i*16 + 4*(lane>>4) + r, the same for every j.
+  const int ncol = 4 * (lane >> 4);
+  const bool vec_n = (N & 7) == 0;
   f32x4 acc[4][4];  // [n-tile][m-tile]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // bias of this lane's 4 x 4 output columns: loaded now so its latency hides under the K loop
-  const int ncol = 4 * (lane >> 4);
-  s16x4 bias_v[4];
-  if (HAS_BIAS && (N & 7) == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i) {
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_BIAS) {
       const int n = n0 + wn * 64 + i * 16 + ncol;
-      bias_v[i] = n < N ? *reinterpret_cast<const s16x4*>(bias + n) : s16x4{0, 0, 0, 0};
+      if (vec_n) {
+        if (n < N) {
+          const s16x4 bb = *reinterpret_cast<const s16x4*>(bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b4[r] = T::to_f32((unsigned short)bb[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) b4[r] = T::to_f32(bias[n + r]);
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = b4;
   }
 
   const int nk = K / BKT;
@@ -232,29 +251,22 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
   // accumulators -> fp16 image of the wave's 64x64 quadrant in its private LDS region -> read back by
   // rows, add the residual (fp16 + fp16 -> fp16, the same two roundings as `identity + linear(x)`
   // in the reference's fp16 path) -> global_store_dwordx4.
-  if ((N & 7) == 0) {
+  if (vec_n) {
     constexpr int kPitch = kStagePitch;  // bytes per staged row (+16: rows 0/8 do not share a bank pair)
     unsigned char* stage = lds + wave * (64 * kPitch);  // main loop is done with LDS (barrier above)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int n = n0 + wn * 64 + i * 16 + ncol;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (HAS_BIAS) {  // N % 8 == 0 and n % 4 == 0: the 4 columns are all inside or all outside (zeros then)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = T::to_f32((unsigned short)bias_v[i][r]);
-      }
-      (void)n;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        s16x4 o;
+        float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] + bv[r];
-          if (ACT == 1) v = v < 0.f ? 0.f : v;  // NaN-propagating, like torch.relu
-          if (ACT == 2) v = gelu_erf(v);
-          o[r] = (short)T::from_f32(v);
+          float x = acc[i][j][r];
+          if (ACT == 1) x = x < 0.f ? 0.f : x;  // NaN-propagating, like torch.relu
+          if (ACT == 2) x = gelu_erf(x);
+          v[r] = x;
         }
-        *reinterpret_cast<s16x4*>(stage + (j * 16 + frow) * kPitch + (i * 16 + ncol) * 2) = o;
+        *reinterpret_cast<s16x4*>(stage + (j * 16 + frow) * kPitch + (i * 16 + ncol) * 2) = T::pack4(v);
       }
     }
     __builtin_amdgcn_wave_barrier();  // same wave writes then reads: DS ops retire in order
@@ -284,12 +296,6 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + wn * 64 + i * 16 + ncol;
     if (n >= N) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (HAS_BIAS) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n + r < N) bv[r] = T::to_f32(bias[n + r]);
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + wm * 64 + j * 16 + frow;
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (n + r < N) {
-          float v = acc[i][j][r] + bv[r];
+          float v = acc[i][j][r];
           if (ACT == 1) v = v < 0.f ? 0.f : v;
           if (ACT == 2) v = gelu_erf(v);
           unsigned short h = T::from_f32(v);
@@ -316,8 +322,11 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
 //     workgroups per CU.  These layers run 4-8 K steps per tile; their cost is the per-tile fixed latency
 //     (first loads, bias, LDS staging, stores), which only more resident workgroups hide.
 //   K  > 256: 64-deep steps, 2 buffers (64 KiB, 2 workgroups per CU): twice the MFMA work per barrier.
-//   A 4-deep ring (3 tiles of DMA in flight, counted vmcnt) measured 5-10 % slower than either on every shape:
-//   the exposed latency is per tile, not per K step.
+//   A 4-deep ring (3 tiles of DMA in flight, counted vmcnt) measured 5-10 % slower than either on every shape, and
+//   a persistent-grid variant that prefetched the next tile's first stage under the epilogue 20 % slower: ablation
+//   (stores off / K loop off) shows the short-K layers bound by bytes through the CU's vector-memory path --
+//   L2->LDS operand re-reads (3.35 GB at ~17 TB/s for the encoder FFN up-projection) + staging + stores -- not by
+//   exposed latency.  The lever that remains is a larger tile (fewer operand re-reads); see DESIGN.md section 4.
 // CODETR_GEMM_CFG=<bk><stages> (322, 324, 642) overrides, for A/B measurements only.
 int pipeline_cfg(int64_t K) {
   static const int forced = [] {
