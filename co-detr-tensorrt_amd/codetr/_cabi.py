@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 9
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -26,12 +26,12 @@ SIGNATURES = {
     "codetr_msda_forward_f32": (_i32, _MSDA_ARGS),
     "codetr_msda_forward_f64": (_i32, _MSDA_ARGS),
     "codetr_msda_variant": (_cp, [_i32, _i32, _i32, _i32, _i32]),
-    "codetr_msda_fused_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32,
-                                             _i32, _i32, _i64, _i32, _vp]),
-    "codetr_msda_fused_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32,
-                                              _i32, _i32, _i64, _i32, _vp]),
-    "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
-    "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
+    "codetr_msda_fused_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _i64,
+                                             _i32, _i32, _i32, _i64, _i32, _vp]),
+    "codetr_msda_fused_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _i64,
+                                              _i32, _i32, _i32, _i64, _i32, _vp]),
+    "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
+    "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_groupnorm_tokens_workspace_bytes": (_i64, [_i64, _i64, _i64]),
@@ -128,9 +128,10 @@ def linear_supported(x, weight) -> bool:
     return x.dtype in _LINEAR_BY_DTYPE and weight.dtype == x.dtype and weight.shape[1] % 64 == 0
 
 
-def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None):
+def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None, hm_rows=0, hm_head_dim=0):
     """Enqueue y = act(x @ w.T + b) (+ r) on torch's current stream.  x2d [M,K], weight [N,K] contiguous;
-    row_mask [M] bool/uint8: masked rows are written as zeros."""
+    row_mask [M] bool/uint8: masked rows are written as zeros; hm_rows/hm_head_dim: head-major destination
+    y[b][head][position][channel] (see include/codetr_hip.h)."""
     lib = load()
     CALLS["linear"] += 1
     M, K = x2d.shape
@@ -140,7 +141,7 @@ def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None):
         bias.data_ptr() if bias is not None else None,
         residual2d.data_ptr() if residual2d is not None else None,
         row_mask.data_ptr() if row_mask is not None else None,
-        out2d.data_ptr(), M, N, K, _ACT[act])
+        out2d.data_ptr(), M, N, K, _ACT[act], hm_rows, hm_head_dim)
     check(rc, "codetr_linear")
     return out2d
 
@@ -183,18 +184,22 @@ def msda_fused_supported(dtype, D, L, P) -> bool:
     return dtype in _MSDA_FUSED_BY_DTYPE and D in (16, 32, 64) and L * P * (256 // (D // 8)) * 32 <= 60 * 1024
 
 
-def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_col, ref, num_levels, num_points, out):
-    """value [B,S,M,D]; proj [B,Nq,Ncols] holds the sampling offsets at columns [off_col, off_col+M*L*P*2) and
+def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_col, ref, num_levels, num_points, out,
+               head_major=False):
+    """value [B,S,M,D] (or [B,M,S,D] when head_major); proj [B,Nq,Ncols] holds the sampling offsets at columns [off_col, off_col+M*L*P*2) and
     the attention logits at [logit_col, logit_col+M*L*P); ref [B,Nq,L,2|4]; out [B,Nq,M*D]."""
     lib = load()
     CALLS["msda_fused"] += 1
-    B, S, M, D = value.shape
+    if head_major:
+        B, M, S, D = value.shape
+    else:
+        B, S, M, D = value.shape
     Nq, ncols = proj.shape[1], proj.shape[2]
     es = proj.element_size()
     rc = getattr(lib, _MSDA_FUSED_BY_DTYPE[value.dtype])(
         current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
         proj.data_ptr() + off_col * es, ncols, proj.data_ptr() + logit_col * es, ncols,
-        ref.data_ptr(), ref.shape[-1], B, S, M, D, num_levels, Nq, num_points, out.data_ptr())
+        ref.data_ptr(), ref.shape[-1], 1 if head_major else 0, B, S, M, D, num_levels, Nq, num_points, out.data_ptr())
     check(rc, "codetr_msda_fused_forward")
     return out
 
@@ -214,3 +219,8 @@ def groupnorm_tokens(x, gamma, beta, groups, eps, out_slice, out_batch_stride):
                                          out_slice.data_ptr(), out_batch_stride, ws.data_ptr(), B, HW, C, groups,
                                          float(eps))
     check(rc, "codetr_groupnorm_tokens_f16")
+
+
+def msda_head_major_supported(dtype, D, L, P) -> bool:
+    """the head-major fused kernel: 16-bit storage, 64- or 128-byte head rows, L*P <= 4 * lanes per pair"""
+    return dtype in _MSDA_FUSED_BY_DTYPE and D in (32, 64) and L * P <= 4 * 2 * (D // 8)

@@ -33,9 +33,11 @@ def _gpu(x, what):
         )
 
 
-def linear(x, weight, bias=None, act=None, residual=None, row_mask=None):
+def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_major=None):
     """y = act(x @ weight.T + bias) (+ residual);  act in {None, 'relu', 'gelu'}.
-    row_mask (bool, x.shape[:-1]): rows where it is True come out as zeros (before the residual)."""
+    row_mask (bool, x.shape[:-1]): rows where it is True come out as zeros (before the residual).
+    head_major = head_dim: x must be [B, S, K]; the result is returned as [B, N/head_dim, S, head_dim] (each head's
+    map contiguous) instead of [B, S, N] -- the value-map layout of the head-major MSDA kernel (native path only)."""
     _gpu(x, "linear")
     if _cabi.linear_supported(x, weight):
         # hand-written MFMA GEMM with the bias / activation / residual folded into its epilogue
@@ -56,19 +58,28 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None):
             if mk.dtype != torch.bool and mk.dtype != torch.uint8:
                 mk = mk != 0
             mk = mk.contiguous()
+        hm_rows = hm_hd = 0
+        if head_major:
+            if x.dim() != 3 or residual is not None:
+                raise ValueError("head_major needs a [B, S, K] input and no residual")
+            hm_rows, hm_hd = x.shape[1], int(head_major)
         out = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
         if x2.shape[0] > 0:
             with torch.cuda.device(x.device):
                 if LINEAR_PROFILE is None:
-                    _cabi.linear(x2, w, bias, r2, act, out, mk)
+                    _cabi.linear(x2, w, bias, r2, act, out, mk, hm_rows, hm_hd)
                 else:
                     st = torch.cuda.current_stream(x.device)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(st)
-                    _cabi.linear(x2, w, bias, r2, act, out, mk)
+                    _cabi.linear(x2, w, bias, r2, act, out, mk, hm_rows, hm_hd)
                     e1.record(st)
                     LINEAR_PROFILE.append((e0, e1, 2.0 * x2.shape[0] * N * K, x2.shape[0], N, K))
+        if head_major:
+            return out.view(x.shape[0], N // hm_hd, hm_rows, hm_hd)
         return out.view(*x.shape[:-1], N)
+    if head_major:
+        raise RuntimeError("head_major output exists only on the native linear (f16/bf16, K % 64 == 0)")
     # fp32 / odd-K layers (patch-embed is a conv; fp32 runs are parity runs): ATen library GEMM
     y = F.linear(x, weight, bias)
     if act == "relu":
@@ -184,18 +195,27 @@ def msda_fused_supported(value_dtype, head_dim, num_levels, num_points):
     return _cabi.msda_fused_supported(value_dtype, head_dim, num_levels, num_points)
 
 
+def msda_head_major_supported(value_dtype, head_dim, num_levels, num_points):
+    return _cabi.msda_head_major_supported(value_dtype, head_dim, num_levels, num_points)
+
+
 def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_col, reference_points, num_levels,
-               num_points):
+               num_points, head_major=False):
     """MSDA with softmax + sampling-location arithmetic inside the kernel (reference
-    multi_scale_deformable_attention.py:180-196 + the op).  value [B,S,M,D]; proj [B,Nq,cols] = output of the
-    fused (offsets | logits) projection; reference_points [B,Nq,L,2|4] -> [B,Nq,M*D]."""
+    multi_scale_deformable_attention.py:180-196 + the op).  value [B,S,M,D] (or [B,M,S,D] with head_major);
+    proj [B,Nq,cols] = output of the fused (offsets | logits) projection; reference_points [B,Nq,L,2|4]
+    -> [B,Nq,M*D]."""
     _gpu(value, "msda_fused")
-    B, S, M, D = value.shape
+    if head_major:
+        B, M, S, D = value.shape
+    else:
+        B, S, M, D = value.shape
     out = torch.empty((B, proj.shape[1], M * D), dtype=value.dtype, device=value.device)
     if out.numel():
         with torch.cuda.device(value.device):
             _cabi.msda_fused(value.contiguous(), spatial_shapes, level_start_index, proj.contiguous(), off_col,
-                             logit_col, reference_points.to(value.dtype).contiguous(), num_levels, num_points, out)
+                             logit_col, reference_points.to(value.dtype).contiguous(), num_levels, num_points, out,
+                             head_major=head_major)
     return out
 
 

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
                                                           const unsigned short* __restrict__ R,
                                                           unsigned short* __restrict__ Y,
                                                           const unsigned char* __restrict__ row_mask, int M, int N,
-                                                          int K, int tiles_n) {
+                                                          int K, int tiles_n, int hm_rows, int hm_hd) {
   constexpr int kTileBytes = 128 * BKT * 2;        // one operand tile
   constexpr int kStageBytes = 2 * kTileBytes;      // W tile + X tile
   constexpr int LPS = 2 * (BKT / 16);              // LDS-DMA instructions per thread per stage
@@ -279,7 +279,15 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
       if (m < M && n < N) {
         s16x8 v = *reinterpret_cast<const s16x8*>(stage + ml * kPitch + schunk * 16);
         if (row_mask && row_mask[m]) v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};  // masked_fill(mask[..., None], 0) on the linear's output
-        const size_t off = (size_t)m * N + n;
+        size_t off = (size_t)m * N + n;
+        if (hm_hd > 0) {
+          // head-major destination y[b][head][position][channel]: rows m = (b, position), columns n = (head, channel);
+          // an 8-column chunk never straddles heads (hm_hd % 8 == 0), 8 consecutive rows of one head are 8*hm_hd*2
+          // contiguous bytes
+          const int bb = m / hm_rows, pos = m - bb * hm_rows;
+          const int head = n / hm_hd, ch = n - head * hm_hd;
+          off = (((size_t)bb * (N / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
+        }
         if (HAS_RES) {
           const s16x8 rr = *reinterpret_cast<const s16x8*>(R + off);
 #pragma unroll
@@ -339,7 +347,7 @@ int pipeline_cfg(int64_t K) {
 
 template <class T, int ACT, int BKT, int STAGES>
 int launch_cfg(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
-               const void* mask, int M, int N, int K) {
+               const void* mask, int M, int N, int K, int hm_rows, int hm_hd) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(kThreads);
   auto x = static_cast<const unsigned short*>(X);
@@ -348,36 +356,40 @@ int launch_cfg(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd);
+  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd);
+  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd);
+  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
 
 template <class T, int ACT>
 int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
-               const void* mask, int M, int N, int K) {
+               const void* mask, int M, int N, int K, int hm_rows, int hm_hd) {
   switch (pipeline_cfg(K)) {
-    case 324: return launch_cfg<T, ACT, 32, 4>(st, X, W, bias, R, Y, mask, M, N, K);
-    case 322: return launch_cfg<T, ACT, 32, 2>(st, X, W, bias, R, Y, mask, M, N, K);
-    default: return launch_cfg<T, ACT, 64, 2>(st, X, W, bias, R, Y, mask, M, N, K);
+    case 324: return launch_cfg<T, ACT, 32, 4>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
+    case 322: return launch_cfg<T, ACT, 32, 2>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
+    default: return launch_cfg<T, ACT, 64, 2>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
   }
 }
 
 template <class T>
 int launch(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
-           int64_t M, int64_t N, int64_t K, int act) {
+           int64_t M, int64_t N, int64_t K, int act, int64_t hm_rows, int hm_hd) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return CODETR_E_BADARG;
   if (K % 64 != 0 || act < 0 || act > 2) return CODETR_E_UNSUPPORTED;
   if (M > 0x7fffffffLL || N > 0x7fffffffLL || K > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   if (((M + BM - 1) / BM) * ((N + BN - 1) / BN) > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) return CODETR_E_BADARG;
+  if (hm_hd != 0 || hm_rows != 0) {
+    if (hm_hd <= 0 || hm_rows <= 0 || hm_hd % 8 != 0 || N % hm_hd != 0 || N % 8 != 0 || M % hm_rows != 0 || R)
+      return CODETR_E_UNSUPPORTED;
+  }
   switch (act) {
-    case 0: return launch_act<T, 0>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
-    case 1: return launch_act<T, 1>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
-    default: return launch_act<T, 2>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
+    case 0: return launch_act<T, 0>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, (int)hm_rows, hm_hd);
+    case 1: return launch_act<T, 1>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, (int)hm_rows, hm_hd);
+    default: return launch_act<T, 2>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, (int)hm_rows, hm_hd);
   }
 }
 
@@ -386,16 +398,17 @@ int launch(hipStream_t st, const void* X, const void* W, const void* bias, const
 extern "C" {
 
 int codetr_linear_f16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev, const void* residual_dev,
-                      const void* row_mask_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act) {
+                      const void* row_mask_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act, int64_t hm_rows,
+                      int hm_head_dim) {
   return launch<HalfT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, row_mask_dev, M,
-                       N, K, act);
+                       N, K, act, hm_rows, hm_head_dim);
 }
 
 int codetr_linear_bf16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev,
                        const void* residual_dev, const void* row_mask_dev, void* y_dev, int64_t M, int64_t N,
-                       int64_t K, int act) {
+                       int64_t K, int act, int64_t hm_rows, int hm_head_dim) {
   return launch<BFloatT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, row_mask_dev,
-                         M, N, K, act);
+                         M, N, K, act, hm_rows, hm_head_dim);
 }
 
 }  // extern "C"

@@ -116,6 +116,140 @@ struct FusedArgs {
   int logit_stride;     // same for the logits matrix
 };
 
+constexpr int kMaxLevels = 16;  // level table kept in LDS
+
+// Phase 1 of both gather kernels, shared.  The PL lanes that serve a pair in phase 2 also prepare that pair's
+// L*P sample points: lane `sub` takes points sub, sub+PL, ... (at most KMAX of them).  ALL global loads of a lane
+// (locations / offsets, weights / logits, reference points) are issued before the first use, so the prologue
+// exposes one memory latency, not one per level (a level-by-level loop measured 239 us of a 680 us launch).
+// Softmax over the pair's logits (FUSED) is two shuffle reductions inside the PL-lane group.  Every point becomes
+// a 32-byte Entry in LDS: byte offsets of its 4 corners (clamped: always dereferenceable) + 4 fp32 weights
+// (bilinear x attention; 0 for out-of-image corners and gated points), so phase 2 is branch-free.
+//   pair_base  byte offset of (image b, head m) inside the value tensor, without the level start
+//   row_bytes  bytes between horizontally adjacent pixels of one head
+template <class TR, int PL, int KMAX, bool FUSED>
+__device__ __forceinline__ void build_entries(Entry* __restrict__ entries, int PAIRS, const int* __restrict__ s_meta,
+                                              int pl, int sub, unsigned g, int M, int L, int P, unsigned pair_base,
+                                              unsigned row_bytes, const typename TR::storage* __restrict__ loc,
+                                              const typename TR::storage* __restrict__ weight, const FusedArgs& fa) {
+  using S = typename TR::storage;
+  struct __attribute__((aligned(2 * sizeof(S)))) S2 { S a, b; };
+  const int LP = L * P;
+  const unsigned m = g % (unsigned)M, row = g / (unsigned)M;
+  float px[KMAX], py[KMAX], pw[KMAX], rw[KMAX], rh[KMAX];
+  int lvl[KMAX];
+  // ---- all loads first ----
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int pt = sub + k * PL;
+    lvl[k] = 0;
+    px[k] = py[k] = 0.f;
+    pw[k] = FUSED ? -INFINITY : 0.f;
+    rw[k] = rh[k] = 0.f;
+    if (pt < LP) {
+      const int l = pt / P;
+      lvl[k] = l;
+      if (FUSED) {
+        const int col = (int)m * LP + pt;
+        const S2 o2 = *reinterpret_cast<const S2*>(loc + (size_t)row * fa.off_stride + 2 * col);
+        const S* rp = static_cast<const S*>(fa.ref) + ((size_t)row * L + l) * fa.ref_dim;
+        const S2 r2 = *reinterpret_cast<const S2*>(rp);
+        px[k] = TR::to_f32(o2.a);
+        py[k] = TR::to_f32(o2.b);
+        rw[k] = TR::to_f32(r2.a);
+        rh[k] = TR::to_f32(r2.b);
+        pw[k] = TR::to_f32(weight[(size_t)row * fa.logit_stride + col]);
+        if (fa.ref_dim == 4) {  // fold (w, h) into the offsets now: off / P * wh * 0.5
+          const S2 wh = *reinterpret_cast<const S2*>(rp + 2);
+          px[k] *= TR::to_f32(wh.a) * (0.5f / (float)P);
+          py[k] *= TR::to_f32(wh.b) * (0.5f / (float)P);
+        }
+      } else {
+        const size_t e = (size_t)g * LP + pt;
+        const S2 l2 = *reinterpret_cast<const S2*>(loc + 2 * e);
+        px[k] = TR::to_f32(l2.a);
+        py[k] = TR::to_f32(l2.b);
+        pw[k] = TR::to_f32(weight[e]);
+      }
+    }
+  }
+  // ---- softmax over the pair's logits ----
+  if (FUSED) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) mx = fmaxf(mx, pw[k]);
+#pragma unroll
+    for (int o = PL / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      pw[k] = __expf(pw[k] - mx);  // exp(-inf) = 0 for the unused slots
+      sum += pw[k];
+    }
+#pragma unroll
+    for (int o = PL / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) pw[k] *= inv;
+  }
+  // ---- entries ----
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int pt = sub + k * PL;
+    if (pt >= LP) continue;
+    const int H = s_meta[4 * lvl[k]], W = s_meta[4 * lvl[k] + 1];
+    const unsigned start = (unsigned)s_meta[4 * lvl[k] + 2];
+    const float Hf = (float)H, Wf = (float)W;
+    float x = px[k], y = py[k];
+    if (FUSED) {
+      if (fa.ref_dim == 2) {
+        x = fmaf(x, 1.0f / Wf, rw[k]);
+        y = fmaf(y, 1.0f / Hf, rh[k]);
+      } else {
+        x += rw[k];
+        y += rh[k];
+      }
+    }
+    const float aw = pw[k];
+    // pixel coordinates (reference cu:246-247), fp32 regardless of T
+    const float h_im = fmaf(y, Hf, -0.5f);
+    const float w_im = fmaf(x, Wf, -0.5f);
+    const bool gate = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;  // cu:249
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h0 = (int)hf, w0 = (int)wf;
+    const float lh = h_im - hf, lw = w_im - wf;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const bool h0ok = h0 >= 0, w0ok = w0 >= 0, h1ok = h0 + 1 <= H - 1, w1ok = w0 + 1 <= W - 1;  // cu:52-71
+    const float g_aw = gate ? aw : 0.f;
+    Entry en;
+    en.w[0] = (h0ok && w0ok) ? hh * hw * g_aw : 0.f;
+    en.w[1] = (h0ok && w1ok) ? hh * lw * g_aw : 0.f;
+    en.w[2] = (h1ok && w0ok) ? lh * hw * g_aw : 0.f;
+    en.w[3] = (h1ok && w1ok) ? lh * lw * g_aw : 0.f;
+    // clamped coordinates keep every address inside level l of image b
+    const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
+    const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
+    const unsigned base = pair_base + start * row_bytes;
+    en.off[0] = base + (unsigned)(h0c * W + w0c) * row_bytes;
+    en.off[1] = base + (unsigned)(h0c * W + w1c) * row_bytes;
+    en.off[2] = base + (unsigned)(h1c * W + w0c) * row_bytes;
+    en.off[3] = base + (unsigned)(h1c * W + w1c) * row_bytes;
+    entries[pt * PAIRS + pl] = en;
+  }
+}
+
+// level table (H, W, start, -) in LDS; spatial_shapes / level_start stay on device (reference cu:236-239)
+__device__ __forceinline__ void load_level_table(int* s_meta, const int64_t* __restrict__ spatial_shapes,
+                                                 const int64_t* __restrict__ level_start, int L) {
+  if ((int)threadIdx.x < L) {
+    s_meta[4 * threadIdx.x] = (int)spatial_shapes[2 * threadIdx.x];
+    s_meta[4 * threadIdx.x + 1] = (int)spatial_shapes[2 * threadIdx.x + 1];
+    s_meta[4 * threadIdx.x + 2] = (int)level_start[threadIdx.x];
+    s_meta[4 * threadIdx.x + 3] = 0;
+  }
+  __syncthreads();
+}
+
 template <class TR, int LANES, bool FUSED>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_WAVES_PER_EU, MSDA_WAVES_PER_EU))) void msda_tiled_kernel(
     const typename TR::storage* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
@@ -135,97 +269,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
   const int LP = L * P;
   const unsigned row_bytes = (unsigned)(M * D * sizeof(S));  // one pixel, all heads
 
-  // ---------------- phase 0 (fused only): softmax statistics of every pair's L*P logits ----------------
-  float* sm_stats = reinterpret_cast<float*>(entries + (size_t)LP * PAIRS);  // [PAIRS][2] = (max, 1/sum)
-  if (FUSED) {
-    // the LANES lanes that will serve a pair in phase 2 also split its L*P logits here; max and sum are
-    // combined with shuffles inside that (power-of-two, aligned) lane group -- every thread is busy
-    const int pl0 = threadIdx.x / LANES, sub0 = threadIdx.x % LANES;
-    unsigned g = pair0 + pl0;
-    g = g < n_pairs ? g : n_pairs - 1;
-    const S* lg = weight + (size_t)(g / (unsigned)M) * fa.logit_stride + (size_t)(g % (unsigned)M) * LP;
-    float mx = -INFINITY;
-    for (int i = sub0; i < LP; i += LANES) mx = fmaxf(mx, TR::to_f32(lg[i]));
-#pragma unroll
-    for (int o = LANES / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float sum = 0.f;
-    for (int i = sub0; i < LP; i += LANES) sum += __expf(TR::to_f32(lg[i]) - mx);
-#pragma unroll
-    for (int o = LANES / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if (sub0 == 0) {
-      sm_stats[2 * pl0] = mx;
-      sm_stats[2 * pl0 + 1] = 1.0f / sum;
-    }
-    __syncthreads();
-  }
-
-  // ---------------- phase 1: (x, y, w) -> {offsets, weights} into LDS ----------------
-  for (int l = 0; l < L; ++l) {
-    // uniform index -> scalar loads; shapes stay on device (reference cu:236-239)
-    const int H = (int)spatial_shapes[2 * l];
-    const int W = (int)spatial_shapes[2 * l + 1];
-    const unsigned start = (unsigned)level_start[l];
-    const float Hf = (float)H, Wf = (float)W;
-    const float invH = 1.0f / Hf, invW = 1.0f / Wf, half_over_p = 0.5f / (float)P;
-    for (int e = threadIdx.x; e < PAIRS * P; e += kThreads) {
-      const int pl = e / P, p = e - pl * P;
-      unsigned g = pair0 + pl;
-      g = g < n_pairs ? g : n_pairs - 1;  // tail: recompute the last pair, store is masked
-      const unsigned b = g / pairs_per_image;
-      const unsigned m = g % (unsigned)M;
-      float x, y, aw;
-      if (FUSED) {
-        const unsigned row = g / (unsigned)M;  // (b, q)
-        const int col = ((int)m * L + l) * P + p;
-        const float ox = TR::to_f32(loc[(size_t)row * fa.off_stride + 2 * col]);
-        const float oy = TR::to_f32(loc[(size_t)row * fa.off_stride + 2 * col + 1]);
-        const S* rp = static_cast<const S*>(fa.ref) + ((size_t)row * L + l) * fa.ref_dim;
-        const float rx = TR::to_f32(rp[0]), ry = TR::to_f32(rp[1]);
-        if (fa.ref_dim == 2) {
-          x = fmaf(ox, invW, rx);
-          y = fmaf(oy, invH, ry);
-        } else {
-          x = fmaf(ox * half_over_p, TR::to_f32(rp[2]), rx);
-          y = fmaf(oy * half_over_p, TR::to_f32(rp[3]), ry);
-        }
-        aw = __expf(TR::to_f32(weight[(size_t)row * fa.logit_stride + col]) - sm_stats[2 * pl]) * sm_stats[2 * pl + 1];
-      } else {
-        const size_t pt = ((size_t)g * L + l) * P + p;
-        x = TR::to_f32(loc[2 * pt]);
-        y = TR::to_f32(loc[2 * pt + 1]);
-        aw = TR::to_f32(weight[pt]);
-      }
-      // pixel coordinates (reference cu:246-247), fp32 regardless of T
-      const float h_im = fmaf(y, Hf, -0.5f);
-      const float w_im = fmaf(x, Wf, -0.5f);
-      const bool gate = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;  // cu:249
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const int h0 = (int)hf, w0 = (int)wf;
-      const float lh = h_im - hf, lw = w_im - wf;
-      const float hh = 1.f - lh, hw = 1.f - lw;
-      const bool h0ok = h0 >= 0, w0ok = w0 >= 0, h1ok = h0 + 1 <= H - 1, w1ok = w0 + 1 <= W - 1;  // cu:52-71
-      const float g_aw = gate ? aw : 0.f;
-      Entry en;
-      en.w[0] = (h0ok && w0ok) ? hh * hw * g_aw : 0.f;
-      en.w[1] = (h0ok && w1ok) ? hh * lw * g_aw : 0.f;
-      en.w[2] = (h1ok && w0ok) ? lh * hw * g_aw : 0.f;
-      en.w[3] = (h1ok && w1ok) ? lh * lw * g_aw : 0.f;
-      // clamped coordinates keep every address inside level l of image b
-      const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
-      const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
-      const unsigned base = b * image_bytes + start * row_bytes + m * (unsigned)(D * sizeof(S));
-      en.off[0] = base + (unsigned)(h0c * W + w0c) * row_bytes;
-      en.off[1] = base + (unsigned)(h0c * W + w1c) * row_bytes;
-      en.off[2] = base + (unsigned)(h1c * W + w0c) * row_bytes;
-      en.off[3] = base + (unsigned)(h1c * W + w1c) * row_bytes;
-      entries[(l * P + p) * PAIRS + pl] = en;
-    }
+  // ---------------- phase 1: sample points -> {corner offsets, weights} in LDS ----------------
+  int* s_meta = reinterpret_cast<int*>(entries + (size_t)LP * PAIRS);
+  load_level_table(s_meta, spatial_shapes, level_start, L);
+  const int pl = threadIdx.x / LANES;
+  const int sub = threadIdx.x % LANES;
+  {
+    unsigned g = pair0 + pl;
+    g = g < n_pairs ? g : n_pairs - 1;  // tail: recompute the last pair, its store is masked
+    const unsigned b = g / pairs_per_image, m = g % (unsigned)M;
+    build_entries<TR, LANES, 8, FUSED>(entries, PAIRS, s_meta, pl, sub, g, M, L, P,
+                                       b * image_bytes + m * (unsigned)(D * sizeof(S)), row_bytes, loc, weight, fa);
   }
   __syncthreads();
 
   // ---------------- phase 2: gather + blend ----------------
-  const int pl = threadIdx.x / LANES;
-  const int sub = threadIdx.x % LANES;
   const unsigned lane_byte = (unsigned)(sub * 16);
   const unsigned char* vbase = reinterpret_cast<const unsigned char*>(value);
   float acc[VEC];
@@ -238,6 +296,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
   constexpr int GROUP = MSDA_GROUP;
   const Entry* my = entries + pl;
   int i = 0;
+#if defined(MSDA_ABLATE) && MSDA_ABLATE == 1  // timing experiment only: no gather phase
+  i = LP;
+#endif
   for (; i + GROUP <= LP; i += GROUP) {
     Entry en[GROUP];
     V raw[GROUP][4];
@@ -247,7 +308,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
     for (int g = 0; g < GROUP; ++g)
 #pragma unroll
       for (int k = 0; k < 4; ++k)
+#if defined(MSDA_ABLATE) && MSDA_ABLATE == 2  // timing experiment only: every lane re-reads one hot line
+        raw[g][k] = *reinterpret_cast<const V*>(vbase + (size_t)((en[g].off[k] & 0) + lane_byte));
+#else
         raw[g][k] = *reinterpret_cast<const V*>(vbase + (size_t)(en[g].off[k] + lane_byte));
+#endif
 #pragma unroll
     for (int g = 0; g < GROUP; ++g)
 #pragma unroll
@@ -275,6 +340,141 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
     for (int j = 0; j < VEC; ++j) packed[j] = TR::from_f32(acc[j]);
     *reinterpret_cast<V*>(reinterpret_cast<unsigned char*>(out) + ((size_t)g * D * sizeof(S) + lane_byte)) = packed;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Head-major fused variant.  Value map laid out [B, M, S, D] (each head's map contiguous, written that
+// way by the value projection's epilogue): the two horizontal neighbours (x0, x1) of a sample are then
+// 2*D*sizeof(T) = 128 contiguous bytes = one whole cache line, where the reference layout [B, S, M, D]
+// puts them 512 B apart and every 64-B corner read uses half a line.  A pair is served by 2*LANES lanes:
+// the low LANES lanes take the x0 column, the high LANES lanes the x1 column, so a wave instruction
+// covers 8 pairs x 128 B (8 full lines instead of 16 half lines) and a point needs two loads (rows y0,
+// y1) per lane instead of four; the two column partial sums meet in one shuffle at the end.
+// Clamping / zero weights per corner as in the tiled kernel, so x0 / x1 out of range or W == 1 only cost
+// contiguity, never correctness.
+// ------------------------------------------------------------------------------------------
+template <class TR, int LANES>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_WAVES_PER_EU, MSDA_WAVES_PER_EU))) void msda_fused_headmajor_kernel(
+    const typename TR::storage* __restrict__ value /* [B,M,S,D] */, const int64_t* __restrict__ spatial_shapes,
+    const int64_t* __restrict__ level_start, const typename TR::storage* __restrict__ offs,
+    const typename TR::storage* __restrict__ logits, typename TR::storage* __restrict__ out, unsigned n_pairs,
+    unsigned pairs_per_image, unsigned plane_bytes /* S*D*sizeof */, int M, int L, int P, FusedArgs fa) {
+  using S = typename TR::storage;
+  using V = typename TR::vec;
+  constexpr int VEC = TR::VEC;
+  constexpr int D = VEC * LANES;
+  constexpr int PL = 2 * LANES;            // lanes per pair
+  constexpr int PAIRS = kThreads / PL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Entry* entries = reinterpret_cast<Entry*>(smem_raw);  // [L*P][PAIRS]
+  const int LP = L * P;
+
+  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const unsigned pair0 = tile * PAIRS;
+  const unsigned row_bytes = (unsigned)(D * sizeof(S));  // one pixel of one head
+
+  int* s_meta = reinterpret_cast<int*>(entries + (size_t)LP * PAIRS);
+  load_level_table(s_meta, spatial_shapes, level_start, L);
+  const int pl = threadIdx.x / PL;
+  {
+    unsigned g = pair0 + pl;
+    g = g < n_pairs ? g : n_pairs - 1;
+    const unsigned b = g / pairs_per_image, m = g % (unsigned)M;
+    build_entries<TR, PL, 4, true>(entries, PAIRS, s_meta, pl, threadIdx.x % PL, g, M, L, P,
+                                   (b * (unsigned)M + m) * plane_bytes, row_bytes, offs, logits, fa);
+  }
+  __syncthreads();
+
+  // phase 2: lane = (pair, x column, 16-byte channel group)
+  const int xh = (threadIdx.x / LANES) & 1;
+  const int sub = threadIdx.x % LANES;
+  const unsigned lane_byte = (unsigned)(sub * 16);
+  const unsigned char* vbase = reinterpret_cast<const unsigned char*>(value);
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  constexpr int GROUP = 2 * MSDA_GROUP;  // 2 loads per point -> same 16 loads in flight per lane
+  const Entry* my = entries + pl;
+  int i = 0;
+  for (; i + GROUP <= LP; i += GROUP) {
+    unsigned o0[GROUP], o1[GROUP];
+    float w0[GROUP], w1[GROUP];
+    V r0[GROUP], r1[GROUP];
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+      const Entry en = my[(i + g) * PAIRS];
+      o0[g] = xh ? en.off[1] : en.off[0];
+      o1[g] = xh ? en.off[3] : en.off[2];
+      w0[g] = xh ? en.w[1] : en.w[0];
+      w1[g] = xh ? en.w[3] : en.w[2];
+    }
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+      r0[g] = *reinterpret_cast<const V*>(vbase + (size_t)(o0[g] + lane_byte));
+      r1[g] = *reinterpret_cast<const V*>(vbase + (size_t)(o1[g] + lane_byte));
+    }
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = __builtin_fmaf(w0[g], TR::to_f32(r0[g][j]), acc[j]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = __builtin_fmaf(w1[g], TR::to_f32(r1[g][j]), acc[j]);
+    }
+  }
+  for (; i < LP; ++i) {
+    const Entry en = my[i * PAIRS];
+    const V r0 = *reinterpret_cast<const V*>(vbase + (size_t)((xh ? en.off[1] : en.off[0]) + lane_byte));
+    const V r1 = *reinterpret_cast<const V*>(vbase + (size_t)((xh ? en.off[3] : en.off[2]) + lane_byte));
+    const float w0 = xh ? en.w[1] : en.w[0], w1 = xh ? en.w[3] : en.w[2];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = __builtin_fmaf(w0, TR::to_f32(r0[j]), acc[j]);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = __builtin_fmaf(w1, TR::to_f32(r1[j]), acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] += __shfl_xor(acc[j], LANES, 64);  // x0 column + x1 column
+  const unsigned g = pair0 + pl;
+  if (g < n_pairs && xh == 0) {
+    V packed;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) packed[j] = TR::from_f32(acc[j]);
+    *reinterpret_cast<V*>(reinterpret_cast<unsigned char*>(out) + ((size_t)g * D * sizeof(S) + lane_byte)) = packed;
+  }
+}
+
+template <class TR, int LANES>
+int launch_headmajor(hipStream_t st, const void* value, const int64_t* ss, const int64_t* ls, const void* off,
+                     const void* logits, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq, int P,
+                     FusedArgs fa) {
+  using ST = typename TR::storage;
+  constexpr int D = TR::VEC * LANES;
+  constexpr int PAIRS = kThreads / (2 * LANES);
+  const int64_t image_elems = S * M * D;
+  const int64_t image_bytes = image_elems * (int64_t)sizeof(ST);
+  const int64_t pairs_per_image = Nq * M;
+  if (image_bytes > 0xffffffffLL || pairs_per_image * (int64_t)PAIRS > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if (L * P > 4 * 2 * LANES || L > kMaxLevels) return CODETR_E_UNSUPPORTED;
+  int64_t bc = 0xffffffffLL / image_bytes;
+  const int64_t bc_pairs = 0x7fffffffLL / pairs_per_image;
+  if (bc_pairs < bc) bc = bc_pairs;
+  if (bc < 1) return CODETR_E_TOO_LARGE;
+  const size_t lds = (size_t)PAIRS * L * P * sizeof(Entry) + kMaxLevels * 4 * sizeof(int);
+  for (int64_t b0 = 0; b0 < B; b0 += bc) {
+    const int64_t nb = (B - b0) < bc ? (B - b0) : bc;
+    const unsigned n_pairs = (unsigned)(nb * pairs_per_image);
+    const unsigned grid = (n_pairs + PAIRS - 1) / PAIRS;
+    FusedArgs fb = fa;
+    fb.ref = static_cast<const ST*>(fa.ref) + b0 * Nq * L * fa.ref_dim;
+    hipLaunchKernelGGL((msda_fused_headmajor_kernel<TR, LANES>), dim3(grid), dim3(kThreads), lds, st,
+                       static_cast<const ST*>(value) + b0 * image_elems, ss, ls,
+                       static_cast<const ST*>(off) + b0 * Nq * (int64_t)fa.off_stride,
+                       static_cast<const ST*>(logits) + b0 * Nq * (int64_t)fa.logit_stride,
+                       static_cast<ST*>(out) + b0 * pairs_per_image * D, n_pairs, (unsigned)pairs_per_image,
+                       (unsigned)(S * D * (int64_t)sizeof(ST)), M, L, P, fb);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -349,7 +549,7 @@ int tiled_lanes(int elem_bytes, int D, int L, int P) {
   const int lanes = D / vec;
   if (lanes < 1 || lanes > 32 || (lanes & (lanes - 1))) return 0;
   const long lds = (long)(kThreads / lanes) * L * P * (long)sizeof(Entry);
-  if (lds > kMaxTiledLdsBytes) return 0;
+  if (lds > kMaxTiledLdsBytes || L > kMaxLevels || L * P > 8 * lanes) return 0;
   return lanes;
 }
 
@@ -370,7 +570,7 @@ int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int
   const int64_t bc_pairs = 0x7fffffffLL / pairs_per_image;
   if (bc_pairs < bc) bc = bc_pairs;
   if (bc < 1) return CODETR_E_TOO_LARGE;
-  const size_t lds = (size_t)PAIRS * L * P * sizeof(Entry) + (FUSED ? (size_t)PAIRS * 2 * sizeof(float) : 0);
+  const size_t lds = (size_t)PAIRS * L * P * sizeof(Entry) + kMaxLevels * 4 * sizeof(int);
   // per-image strides of the loc / weight operands (rows of the projection matrices when fused)
   const int64_t loc_per_image = FUSED ? Nq * (int64_t)fa.off_stride : pairs_per_image * L * P * 2;
   const int64_t w_per_image = FUSED ? Nq * (int64_t)fa.logit_stride : pairs_per_image * L * P;
@@ -485,8 +685,8 @@ CODETR_MSDA_ENTRY(codetr_msda_forward_f32, F32, float, float, CvF32, 4)
 #define CODETR_MSDA_FUSED_ENTRY(NAME, TR)                                                                        \
   int NAME(void* stream, const void* value_dev, const int64_t* spatial_shapes_dev, const int64_t* level_start_dev, \
            const void* offsets_dev, int64_t offsets_row_stride, const void* logits_dev, int64_t logits_row_stride, \
-           const void* ref_dev, int ref_dim, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,       \
-           void* out_dev) {                                                                                      \
+           const void* ref_dev, int ref_dim, int value_head_major, int64_t B, int64_t S, int M, int D, int L,    \
+           int64_t Nq, int P, void* out_dev) {                                                                   \
     const int rc = check_args(value_dev, spatial_shapes_dev, level_start_dev, offsets_dev, logits_dev, out_dev, B, \
                               S, M, D, L, Nq, P, 1);                                                             \
     if (rc) return rc;                                                                                           \
@@ -495,8 +695,21 @@ CODETR_MSDA_ENTRY(codetr_msda_forward_f32, F32, float, float, CvF32, 4)
         offsets_row_stride > 0x7fffffff || logits_row_stride > 0x7fffffff)                                       \
       return CODETR_E_BADARG;                                                                                    \
     const int lanes = tiled_lanes(2, D, L, P);                                                                   \
-    if (!lanes) return CODETR_E_UNSUPPORTED;                                                                     \
+    if (!lanes || L * P > 8 * lanes) return CODETR_E_UNSUPPORTED;                                                \
+    if ((offsets_row_stride & 1) || (reinterpret_cast<uintptr_t>(offsets_dev) & 3) ||                            \
+        (reinterpret_cast<uintptr_t>(ref_dev) & 3))                                                              \
+      return CODETR_E_BADARG; /* (x, y) pairs are read with 32-bit loads */                                      \
     const FusedArgs fa{ref_dev, ref_dim, (int)offsets_row_stride, (int)logits_row_stride};                       \
+    if (value_head_major) {                                                                                      \
+      hipStream_t hst = static_cast<hipStream_t>(stream);                                                        \
+      if (lanes == 4)                                                                                            \
+        return launch_headmajor<TR, 4>(hst, value_dev, spatial_shapes_dev, level_start_dev, offsets_dev,         \
+                                       logits_dev, out_dev, B, S, M, L, Nq, P, fa);                              \
+      if (lanes == 8)                                                                                            \
+        return launch_headmajor<TR, 8>(hst, value_dev, spatial_shapes_dev, level_start_dev, offsets_dev,         \
+                                       logits_dev, out_dev, B, S, M, L, Nq, P, fa);                              \
+      return CODETR_E_UNSUPPORTED;                                                                               \
+    }                                                                                                            \
     return dispatch_fused<TR>(lanes, static_cast<hipStream_t>(stream), value_dev, spatial_shapes_dev,            \
                               level_start_dev, offsets_dev, logits_dev, out_dev, B, S, M, L, Nq, P, fa);         \
   }

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 6
+#define CODETR_HIP_ABI_VERSION 9
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -98,16 +98,22 @@ int codetr_msda_forward_f64(void *stream, const void *value_dev, const int64_t *
  *                and pointers offset by the column start)
  *   ref_dev     [B, Nq, L, ref_dim]  ref_dim 2: (x, y), loc = ref + off / (W_l, H_l)
  *                                    ref_dim 4: (x, y, w, h), loc = ref_xy + off / P * ref_wh * 0.5
+ *   value_head_major  0: value_dev is [B, S, M, D] (the op's layout);
+ *                     1: value_dev is [B, M, S, D] (written that way by codetr_linear_*'s head-major
+ *                        epilogue): the x0/x1 neighbours of a sample are one 128-byte line, a pair is
+ *                        served by twice the lanes and half the loads (D*2 bytes in {64, 128})
  * fp32 softmax / locations; 16-bit storage only; D*2 bytes per head must be 32, 64 or 128.
  * ------------------------------------------------------------------------------------------ */
 int codetr_msda_fused_forward_f16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
                                   const int64_t *level_start_dev, const void *offsets_dev, int64_t offsets_row_stride,
                                   const void *logits_dev, int64_t logits_row_stride, const void *ref_dev, int ref_dim,
-                                  int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, void *out_dev);
+                                  int value_head_major, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,
+                                  void *out_dev);
 int codetr_msda_fused_forward_bf16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
                                    const int64_t *level_start_dev, const void *offsets_dev, int64_t offsets_row_stride,
                                    const void *logits_dev, int64_t logits_row_stride, const void *ref_dev, int ref_dim,
-                                   int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, void *out_dev);
+                                   int value_head_major, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,
+                                   void *out_dev);
 
 /* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
  * Pure host function; lets tests assert that the model shape takes the tiled path. */
@@ -133,16 +139,20 @@ const char *codetr_msda_variant(int elem_bytes, int M, int D, int L, int P);
  *                codetr/multi_scale_deformable_attention.py:174-175 folded into value_proj
  *   y_dev        [M, N]  (may alias residual_dev)     T
  *   act          0 = none, 1 = ReLU, 2 = GELU (erf form, nn.GELU default)
+ *   hm_rows, hm_head_dim   0, 0: y is row-major [M, N].  Otherwise the rows are (batch, position) with
+ *                hm_rows positions per batch and the columns (head, channel) with hm_head_dim channels per
+ *                head, and y is written HEAD-MAJOR: y[b][head][position][channel] -- the value-map layout
+ *                of codetr_msda_fused_forward_*(value_head_major = 1).  Needs N % 8 == 0, no residual.
  *
  * fp32 accumulation on the MFMA units, one rounding at the store.  K must be a multiple of 64
  * (every Linear of the model is; CODETR_E_UNSUPPORTED otherwise); x / w 16-byte aligned.
  * ------------------------------------------------------------------------------------------ */
 int codetr_linear_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                       const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
-                      int64_t K, int act);
+                      int64_t K, int act, int64_t hm_rows, int hm_head_dim);
 int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                        const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
-                       int64_t K, int act);
+                       int64_t K, int act, int64_t hm_rows, int hm_head_dim);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension: y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta

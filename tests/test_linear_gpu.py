@@ -122,3 +122,19 @@ def test_linear_row_mask():
     w5 = (torch.randn(5, 256, device=DEV, generator=g) / 16).half()  # ragged-N path
     y3 = hip_ops.linear(x, w5, None, row_mask=mask)
     assert (y3[mask] == 0).all() and (y3[~mask] != 0).any()
+
+
+def test_linear_head_major_output():
+    """y[b][head][pos][ch] layout of the value projection (+ row mask) == permuted row-major result."""
+    from codetr import hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(4)
+    B, S, K, Hh, hd = 2, 333, 256, 8, 32
+    x = torch.randn(B, S, K, device=DEV, generator=g).half()
+    w = (torch.randn(Hh * hd, K, device=DEV, generator=g) / 16).half()
+    b = torch.randn(Hh * hd, device=DEV, generator=g).half()
+    mask = torch.rand(B, S, device=DEV, generator=g) < 0.2
+    y_rm = hip_ops.linear(x, w, b, row_mask=mask)                     # [B,S,N]
+    y_hm = hip_ops.linear(x, w, b, row_mask=mask, head_major=hd)      # [B,H,S,hd]
+    assert y_hm.shape == (B, Hh, S, hd)
+    assert torch.equal(y_hm, y_rm.view(B, S, Hh, hd).permute(0, 2, 1, 3))

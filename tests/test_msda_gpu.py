@@ -203,15 +203,16 @@ def test_opcheck_and_stream_semantics():
 # ---------------------------------------------------------------------------------------------------
 # fused variant: softmax + sampling-location arithmetic inside the kernel
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("head_major", [False, True])
 @pytest.mark.parametrize("ref_dim", [2, 4])
 @pytest.mark.parametrize("extra_cols", [0, 24])
-def test_fused_prologue_vs_oracle(ref_dim, extra_cols):
+def test_fused_prologue_vs_oracle(ref_dim, extra_cols, head_major):
     """fused kernel == oracle( softmax(logits), ref + normalised offsets ) computed in fp64 on the host."""
     from codetr import _cabi, hip_ops
 
     rng = np.random.default_rng(3)
     B, Nq, M, D, P = 2, 77, 8, 32, 4
-    shapes = [(9, 13), (5, 7), (3, 4), (2, 2), (1, 1)]
+    shapes = [(9, 13), (5, 7), (3, 4), (2, 1), (1, 1)]  # incl. W == 1 levels: x1 never exists there
     L = len(shapes)
     ss = np.array(shapes, dtype=np.int64)
     ls = O.level_start_index_from_shapes(ss)
@@ -234,8 +235,11 @@ def test_fused_prologue_vs_oracle(ref_dim, extra_cols):
                            rng.standard_normal((B, Nq, extra_cols))), -1)
     t = lambda a, dt: torch.as_tensor(np.asarray(a)).to(DEV).to(dt).contiguous()  # noqa: E731
     before = _cabi.CALLS["msda_fused"]
-    out = hip_ops.msda_fused(t(value, torch.float16), t(ss, torch.int64), t(ls, torch.int64), t(proj, torch.float16), 0,
-                             M * L * P * 2, t(ref, torch.float16), L, P)
+    vdev = t(value, torch.float16)
+    if head_major:
+        vdev = vdev.permute(0, 2, 1, 3).contiguous()  # [B, M, S, D]
+    out = hip_ops.msda_fused(vdev, t(ss, torch.int64), t(ls, torch.int64), t(proj, torch.float16), 0,
+                             M * L * P * 2, t(ref, torch.float16), L, P, head_major=head_major)
     torch.cuda.synchronize()
     assert _cabi.CALLS["msda_fused"] == before + 1
     np.testing.assert_allclose(out.float().cpu().numpy(), expect, rtol=2e-3, atol=2e-3)

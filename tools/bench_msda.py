@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--uniform", action="store_true", help="uniform random locations instead of encoder-like")
+    ap.add_argument("--fused", action="store_true", help="also time the fused-prologue variant on equivalent inputs")
     a = ap.parse_args()
     import codetr  # noqa: F401
 
@@ -88,6 +89,20 @@ def main():
         Nq = loc.shape[1]
         med, best = time_op(lambda: op(value, ss, ls, loc, w, 64), a.iters)
         nbytes = algorithmic_bytes(a.batch, S, Nq, e=e)
+        if a.fused and a.dtype != "f32":
+            from codetr import hip_ops
+            M, L, P = 8, len(shapes), 4
+            # equivalent fused inputs: reference = the sampling location of point 0, offsets relative to it, logits = log w
+            ref = loc[:, :, 0, :, 0, :].contiguous()  # [B,Nq,L,2]
+            norm = torch.stack((ss[:, 1], ss[:, 0]), -1).to(dt)[None, None, None, :, None, :]
+            off = ((loc - ref[:, :, None, :, None, :]) * norm).reshape(a.batch, Nq, -1)
+            logits = torch.log(w.float().clamp_min(1e-6)).to(dt).reshape(a.batch, Nq, -1)
+            proj = torch.cat((off, logits), -1).contiguous()
+            fm, fb = time_op(lambda: hip_ops.msda_fused(value, ss, ls, proj, 0, M * L * P * 2, ref, L, P), a.iters)
+            print(f"{a.res} {a.dtype} B={a.batch} {tag}: FUSED median {fm * 1e6:9.1f} us  best {fb * 1e6:9.1f} us")
+            vhm = value.permute(0, 2, 1, 3).contiguous()
+            hm, hb = time_op(lambda: hip_ops.msda_fused(vhm, ss, ls, proj, 0, M * L * P * 2, ref, L, P, head_major=True), a.iters)
+            print(f"{a.res} {a.dtype} B={a.batch} {tag}: FUSED head-major median {hm * 1e6:9.1f} us  best {hb * 1e6:9.1f} us")
         print(f"{a.res} {a.dtype} B={a.batch} {tag}: S={S} Nq={Nq} median {med * 1e6:9.1f} us  best {best * 1e6:9.1f} us  "
               f"algorithmic {nbytes / 1e6:8.1f} MB -> {nbytes / med / 1e9:8.1f} GB/s  "
               f"(gather volume {a.batch * Nq * 8 * 20 * 4 * 32 * e / 1e9:.2f} GB -> {a.batch * Nq * 8 * 20 * 4 * 32 * e / med / 1e12:.2f} TB/s)")
