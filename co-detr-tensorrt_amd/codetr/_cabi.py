@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -37,6 +37,8 @@ SIGNATURES = {
     "codetr_groupnorm_tokens_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "codetr_groupnorm_tokens_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i32,
                                            ctypes.c_float]),
+    "codetr_sine_pos_tokens_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, ctypes.c_float,
+                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, _i32]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
 }
 
@@ -44,7 +46,8 @@ _lib = None
 
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
-CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0}
+CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
+         "sine_pos_tokens": 0}
 
 
 def load():
@@ -224,3 +227,15 @@ def groupnorm_tokens(x, gamma, beta, groups, eps, out_slice, out_batch_stride):
 def msda_head_major_supported(dtype, D, L, P) -> bool:
     """the head-major fused kernel: 16-bit storage, 64- or 128-byte head rows, L*P <= 4 * lanes per pair"""
     return dtype in _MSDA_FUSED_BY_DTYPE and D in (32, 64) and L * P <= 4 * 2 * (D // 8)
+
+
+def sine_pos_tokens(ycum, xcum, level_embed, out_slice, out_batch_stride, num_feats, temperature, scale, eps, offset,
+                    normalize):
+    """ycum/xcum [B,H,W] fp32 -> encoding written at out_slice.data_ptr() (image 0), see include/codetr_hip.h."""
+    CALLS["sine_pos_tokens"] += 1
+    B, H, W = ycum.shape
+    rc = load().codetr_sine_pos_tokens_f16(
+        current_stream_ptr(ycum.device), ycum.data_ptr(), xcum.data_ptr(),
+        level_embed.data_ptr() if level_embed is not None else None, out_slice.data_ptr(), out_batch_stride, B, H, W,
+        num_feats, float(temperature), float(scale), float(eps), float(offset), 1 if normalize else 0)
+    check(rc, "codetr_sine_pos_tokens_f16")

@@ -107,13 +107,24 @@ class CoDINOHead(nn.Module):
         Himg, Wimg = img_masks.shape[-2:]
         masks, pos = [], []
         m4 = img_masks.unsqueeze(1)
-        for hw in shapes:
+        pe = self.positional_encoding
+        native_pos = feat.is_cuda and feat.dtype == torch.float16 and pe.num_feats % 8 == 0
+        pos_flat = feat.new_empty(feat.shape[0], feat.shape[1], 2 * pe.num_feats) if native_pos else None
+        start = 0
+        for lvl, hw in enumerate(shapes):
             m = F.interpolate(m4, size=tuple(hw)).to(torch.bool).squeeze(1)  # nearest
             masks.append(m)
-            pos.append(self.positional_encoding.forward_tokens(m, dtype=feat.dtype))
+            if native_pos:
+                # one kernel per level: encoding + level embedding straight into lvl_pos_embed[:, start:start+HW]
+                hip_ops.sine_pos_tokens_into(m, pos_flat, start, self.transformer.level_embeds[lvl], pe.num_feats,
+                                             pe.temperature, pe.scale, pe.eps, pe.offset, pe.normalize)
+                start += hw[0] * hw[1]
+            else:
+                pos.append(pe.forward_tokens(m, dtype=feat.dtype))
         state, refs = self.transformer.forward_flat(feat, shapes, masks, pos, reg_branches=self.reg_branches,
                                                     cls_branches=self.cls_branches if self.as_two_stage else None,
-                                                    forced_topk_indices=forced_topk_indices, capture=capture)
+                                                    forced_topk_indices=forced_topk_indices, capture=capture,
+                                                    lvl_pos_embed_flat=pos_flat)
         lvl = len(self.transformer.decoder.layers) - 1
         cls_head = self.cls_branches[lvl]
         cls = hip_ops.linear(state, cls_head.weight, cls_head.bias)  # [B,Nq,classes]

@@ -17,7 +17,8 @@ from . import _cabi
 
 # ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
 NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_window_attention(f16, head_dim 32)",
-          "msda_fused(softmax + sampling locations in-kernel)", "groupnorm_tokens(f16, 8 ch/group)"}
+          "msda_fused(softmax + sampling locations in-kernel)", "groupnorm_tokens(f16, 8 ch/group)",
+          "sine_pos_tokens(f16, + level_embed)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -129,6 +130,21 @@ def groupnorm_tokens_into(x, gamma, beta, groups, eps, dest, row_start):
         raise AssertionError("destination must be a contiguous [B, S, C] tensor")
     with torch.cuda.device(x.device):
         _cabi.groupnorm_tokens(x, gamma, beta, groups, eps, dest[0, row_start:], dest.shape[1] * C)
+    return dest
+
+
+def sine_pos_tokens_into(mask, dest, row_start, level_embed, num_feats, temperature, scale, eps, offset, normalize):
+    """Sine positional encoding of one level (mask [B,H,W] bool, True = padding) + level_embed, written into
+    dest[:, row_start:row_start+H*W, :] (dest [B,S,2*num_feats] f16 contiguous)."""
+    _gpu(mask, "sine_pos_tokens_into")
+    valid = ~mask
+    ycum = valid.cumsum(1, dtype=torch.float32).contiguous()
+    xcum = valid.cumsum(2, dtype=torch.float32).contiguous()
+    if dest.dtype != torch.float16 or not dest.is_contiguous() or dest.shape[2] != 2 * num_feats:
+        raise AssertionError("destination must be a contiguous f16 [B, S, 2*num_feats] tensor")
+    with torch.cuda.device(mask.device):
+        _cabi.sine_pos_tokens(ycum, xcum, level_embed, dest[0, row_start:], dest.shape[1] * dest.shape[2], num_feats,
+                              temperature, scale, eps, offset, normalize)
     return dest
 
 

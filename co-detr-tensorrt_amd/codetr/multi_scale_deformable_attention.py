@@ -9,6 +9,7 @@ Differences by design:
   reference's sequence-first default and just permutes around it.
 """
 import math
+import os
 import warnings
 from typing import Optional
 
@@ -16,6 +17,14 @@ import torch
 import torch.nn as nn
 
 from . import hip_ops
+
+
+# Value-map layout used between the value projection and the fused gather kernel (both ours, so free to choose):
+# head-major [B, M, S, D] makes the two horizontal neighbours of a sample one 128-byte line.  A/B on MI355X at the
+# 1920x1280 encoder shape (tools/bench_msda.py --fused): 616 us vs 665 us per launch with +-3 px synthetic offsets,
+# 1236 us vs 1447 us with uniformly random locations -- but no difference end to end on the model (22.6 vs 22.5
+# ms/image: freshly initialised offsets are a few pixels), so the op's own [B, S, M, D] layout stays the default.
+HEAD_MAJOR_VALUE = os.environ.get("CODETR_MSDA_HEAD_MAJOR", "0") != "0"
 
 
 class MultiScaleDeformableAttention(nn.Module):
@@ -100,6 +109,18 @@ class MultiScaleDeformableAttention(nn.Module):
             raise ValueError(
                 f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead."
             )
+        hd = self.value_proj.out_features // H
+        if (HEAD_MAJOR_VALUE and query.is_cuda and self.value_proj.in_features % 64 == 0
+                and hip_ops.msda_head_major_supported(value.dtype, hd, L, P)):
+            # value map written head-major [B, M, S, D] by the projection's epilogue (padding mask folded in too):
+            # the x0/x1 neighbours of every sample are then one 128-byte line for the gather kernel
+            v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask,
+                               head_major=hd)
+            Wc, bc = self._fused_projection()
+            proj = hip_ops.linear(query, Wc, bc)
+            out = hip_ops.msda_fused(v, spatial_shapes, level_start_index, proj, 0, H * L * P * 2, reference_points,
+                                     L, P, head_major=True)
+            return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
         # value projection with the padding mask folded into the GEMM epilogue (reference :173-176)
         v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask)
         v = v.view(B, S, H, -1)

@@ -269,15 +269,18 @@ class CoDinoTransformer(nn.Module):
                                  capture)
 
     def forward_flat(self, feat, shapes, mlvl_masks, mlvl_pos_tokens, reg_branches=None, cls_branches=None,
-                     forced_topk_indices=None, capture=None):
+                     forced_topk_indices=None, capture=None, lvl_pos_embed_flat=None):
         """Same computation on inputs that are already in the transformer's layout: feat [B,S,C] (levels
         concatenated), shapes [(H_l, W_l)], masks list of [B,H_l,W_l] bool, positional encodings list of
-        [B, H_l*W_l, C]."""
+        [B, H_l*W_l, C] -- or `lvl_pos_embed_flat` [B,S,C], the encodings with the level embeddings already added."""
         if not self.as_two_stage:
             raise AssertionError("as_two_stage must be True for DINO")
         dev = feat.device
         mask = torch.cat([m.flatten(1) for m in mlvl_masks], 1)  # [B,S]
-        pos = torch.cat([p + self.level_embeds[l].view(1, 1, -1) for l, p in enumerate(mlvl_pos_tokens)], 1)
+        if lvl_pos_embed_flat is not None:
+            pos = lvl_pos_embed_flat
+        else:
+            pos = torch.cat([p + self.level_embeds[l].view(1, 1, -1) for l, p in enumerate(mlvl_pos_tokens)], 1)
         spatial_shapes, level_start_index = _shape_tensors(shapes, dev)
         valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
         reference_points = get_reference_points([tuple(s) for s in shapes], valid_ratios, device=dev)  # [B,S,2]

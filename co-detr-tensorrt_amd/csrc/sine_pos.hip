@@ -1,0 +1,82 @@
+// Sine positional encoding of one pyramid level, produced directly in the transformer's layout.
+//
+// Replaces SinePositionalEncoding.forward (reference codetr/positional_encoding.py:58-93: normalise the running
+// sums, divide by 128 temperatures, interleaved sin / cos, cat, permute -- ~14 ATen kernels per level) plus the
+// flatten / transpose / "+ level_embed" / cat steps of CoDinoTransformer.forward (codetr/transformer.py:508-519):
+// one launch writes lvl_pos_embed[b, level_start + y*W + x, :] = [pos_y (num_feats) | pos_x (num_feats)] + level_embed.
+//
+// Inputs are the running sums of the not-mask along y and x (exact small integers, computed by the host with two
+// cumsum calls); everything else happens here in fp32:  e = (cum + offset) / (last + eps) * scale,
+// channel 2f -> sin(e / T^(2f/num_feats)), channel 2f+1 -> cos(same).  One lane = 8 output channels (16 B).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codetr_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(kThreads) void sine_pos_kernel(const float* __restrict__ ycum, const float* __restrict__ xcum,
+                                                            const _Float16* __restrict__ level_embed,
+                                                            _Float16* __restrict__ out, int64_t out_batch_stride, int H,
+                                                            int W, int num_feats, float log2_temperature, float scale,
+                                                            float eps, float offset, int normalize, int64_t total_chunks) {
+  const int lanes_per_token = (2 * num_feats) >> 3;  // 16-byte chunks per token
+  const int half = lanes_per_token >> 1;             // chunks per axis
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * kThreads) {
+    const int c = (int)(i % lanes_per_token);
+    const int64_t tok = i / lanes_per_token;  // b*H*W + y*W + x
+    const int hw = H * W;
+    const int b = (int)(tok / hw);
+    const int r = (int)(tok - (int64_t)b * hw);
+    const int y = r / W, x = r - y * W;
+    const bool is_x = c >= half;
+    const float* cum = is_x ? xcum : ycum;
+    float e = cum[tok];
+    if (normalize) {
+      const float last = is_x ? xcum[(int64_t)b * hw + y * W + (W - 1)] : ycum[(int64_t)b * hw + (H - 1) * W + x];
+      e = (e + offset) / (last + eps) * scale;
+    }
+    const int ch0 = (is_x ? c - half : c) * 8;  // first channel of this chunk inside its axis block
+    f16x8 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int f = (ch0 >> 1) + p;  // frequency index: channels 2f, 2f+1
+      const float inv = __builtin_amdgcn_exp2f(-log2_temperature * (2.0f * (float)f / (float)num_feats));
+      const float a = e * inv;
+      o[2 * p] = (_Float16)sinf(a);
+      o[2 * p + 1] = (_Float16)cosf(a);
+    }
+    if (level_embed) {
+      const f16x8 le = *reinterpret_cast<const f16x8*>(level_embed + c * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (_Float16)((float)o[k] + (float)le[k]);  // fp16 + fp16 -> fp16, as the reference
+    }
+    *reinterpret_cast<f16x8*>(out + (size_t)b * out_batch_stride + (size_t)r * (2 * num_feats) + c * 8) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_sine_pos_tokens_f16(void* stream, const float* ycum_dev, const float* xcum_dev, const void* level_embed_dev,
+                               void* out_dev, int64_t out_batch_stride, int64_t B, int64_t H, int64_t W, int num_feats,
+                               float temperature, float scale, float eps, float offset, int normalize) {
+  if (!ycum_dev || !xcum_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || num_feats <= 0 || temperature <= 0.f)
+    return CODETR_E_BADARG;
+  if (num_feats % 8 != 0) return CODETR_E_UNSUPPORTED;
+  if (B * H * W > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  const int64_t chunks = B * H * W * ((2 * num_feats) / 8);
+  int64_t blocks = (chunks + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(sine_pos_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream), ycum_dev,
+                     xcum_dev, static_cast<const _Float16*>(level_embed_dev), static_cast<_Float16*>(out_dev),
+                     out_batch_stride, (int)H, (int)W, num_feats, log2f(temperature), scale, eps, offset, normalize, chunks);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // extern "C"

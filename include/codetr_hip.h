@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 9
+#define CODETR_HIP_ABI_VERSION 10
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -208,6 +208,22 @@ int64_t codetr_groupnorm_tokens_workspace_bytes(int64_t B, int64_t HW, int64_t C
 int codetr_groupnorm_tokens_f16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev,
                                 void *out_dev, int64_t out_batch_stride, void *workspace_dev, int64_t B, int64_t HW,
                                 int64_t C, int groups, float eps);
+
+/* ------------------------------------------------------------------------------------------
+ * Sine positional encoding of one pyramid level, written into a slice of lvl_pos_embed [B, S, 2*num_feats].
+ *
+ * Replaces SinePositionalEncoding.forward (codetr/positional_encoding.py:58-93) and the flatten / transpose /
+ * "+ level_embeds[lvl]" / cat steps of CoDinoTransformer.forward (codetr/transformer.py:508-519).
+ *   ycum_dev, xcum_dev [B, H, W] f32: running sums of (1 - mask) along y and along x (host: two cumsum calls)
+ *   level_embed_dev    [2*num_feats] f16 or NULL
+ *   out_dev            row `level_start` of image 0 in the [B, S, 2*num_feats] destination; out_batch_stride =
+ *                      S * 2*num_feats elements between images
+ * channel layout [pos_y | pos_x], inside each: channel 2f = sin(e / T^(2f/num_feats)), 2f+1 = cos(same),
+ * e = (cum + offset) / (last + eps) * scale when `normalize`, else cum.  fp32 arithmetic, f16 result.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_sine_pos_tokens_f16(void *stream, const float *ycum_dev, const float *xcum_dev, const void *level_embed_dev,
+                               void *out_dev, int64_t out_batch_stride, int64_t B, int64_t H, int64_t W, int num_feats,
+                               float temperature, float scale, float eps, float offset, int normalize);
 
 #ifdef __cplusplus
 }
