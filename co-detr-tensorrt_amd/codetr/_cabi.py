@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 12
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -39,6 +39,8 @@ SIGNATURES = {
                                            ctypes.c_float]),
     "codetr_sine_pos_tokens_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_float, _i32]),
+    "codetr_ffn_relu_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
+    "codetr_ffn_pack_w2_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
 }
 
@@ -47,7 +49,7 @@ _lib = None
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
-         "sine_pos_tokens": 0}
+         "sine_pos_tokens": 0, "ffn_fused": 0}
 
 
 def load():
@@ -239,3 +241,25 @@ def sine_pos_tokens(ycum, xcum, level_embed, out_slice, out_batch_stride, num_fe
         level_embed.data_ptr() if level_embed is not None else None, out_slice.data_ptr(), out_batch_stride, B, H, W,
         num_feats, float(temperature), float(scale), float(eps), float(offset), 1 if normalize else 0)
     check(rc, "codetr_sine_pos_tokens_f16")
+
+
+def ffn_fused_supported(x, w1, w2, act) -> bool:
+    return (x.dtype == torch.float16 and act == "relu" and x.shape[-1] == 256 and w1.shape[1] == 256
+            and w2.shape[0] == 256 and w1.shape[0] % 64 == 0 and w1.dtype == x.dtype and w2.dtype == x.dtype)
+
+
+def ffn_pack_w2(w2):
+    """one-time re-layout of the second Linear's weight for ffn_fused (see include/codetr_hip.h)"""
+    out = torch.empty_like(w2)
+    rc = load().codetr_ffn_pack_w2_f16(current_stream_ptr(w2.device), w2.data_ptr(), out.data_ptr(), w2.shape[0], w2.shape[1])
+    check(rc, "codetr_ffn_pack_w2_f16")
+    return out
+
+
+def ffn_fused(x2d, w1, b1, w2, b2, out2d):
+    """w2 must be the PACKED weight (ffn_pack_w2)."""
+    CALLS["ffn_fused"] += 1
+    rc = load().codetr_ffn_relu_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                    w2.data_ptr(), b2.data_ptr(), out2d.data_ptr(), x2d.shape[0], x2d.shape[1], w1.shape[0])
+    check(rc, "codetr_ffn_relu_f16")
+    return out2d

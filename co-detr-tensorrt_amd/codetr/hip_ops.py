@@ -18,7 +18,7 @@ from . import _cabi
 # ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
 NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_window_attention(f16, head_dim 32)",
           "msda_fused(softmax + sampling locations in-kernel)", "groupnorm_tokens(f16, 8 ch/group)",
-          "sine_pos_tokens(f16, + level_embed)"}
+          "sine_pos_tokens(f16, + level_embed)", "ffn_fused(f16, 256 -> hidden -> 256, ReLU, + identity)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -94,6 +94,38 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
     if residual is not None:
         y = y + residual
     return y
+
+
+def ffn_fused_supported(x, w1, w2, act):
+    return x.is_cuda and _cabi.ffn_fused_supported(x, w1, w2, act)
+
+
+_W2_PACKED = {}
+
+
+def _packed_w2(w2):
+    """the kernel's pre-packed copy of a second-Linear weight, rebuilt only when the tensor changes"""
+    key = (w2.data_ptr(), w2._version, w2.dtype, str(w2.device), tuple(w2.shape))
+    hit = _W2_PACKED.get(id(w2))
+    if hit is None or hit[0] != key:
+        with torch.no_grad(), torch.cuda.device(w2.device):
+            hit = (key, _cabi.ffn_pack_w2(w2.detach().contiguous()))
+        _W2_PACKED[id(w2)] = hit
+    return hit[1]
+
+
+def ffn_fused(x, w1, b1, w2, b2):
+    """y = x + relu(x @ w1.T + b1) @ w2.T + b2 in one kernel (hidden activation stays on-chip); x [..., 256].
+    w2 is the plain nn.Linear weight; its packed form is cached."""
+    _gpu(x, "ffn_fused")
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    out = torch.empty_like(x2)
+    if x2.shape[0] > 0:
+        with torch.cuda.device(x.device):
+            _cabi.ffn_fused(x2, w1.contiguous(), b1, _packed_w2(w2), b2, out)
+    return out.view(x.shape)
 
 
 def layer_norm(x, weight, bias, eps=1e-5):

@@ -62,6 +62,10 @@ class FFN(nn.Module):
 
     def forward(self, x, identity=None):
         fc1, fc2 = self.layers[0][0], self.layers[1]
+        if (self.add_identity and identity is None and fc1.bias is not None and fc2.bias is not None
+                and hip_ops.ffn_fused_supported(x, fc1.weight, fc2.weight, self.act)):
+            # encoder / decoder FFN (256 -> 2048 -> 256, ReLU): one kernel, the hidden activation never reaches HBM
+            return hip_ops.ffn_fused(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
         h = hip_ops.linear(x, fc1.weight, fc1.bias, act=self.act)
         if not self.add_identity:
             return hip_ops.linear(h, fc2.weight, fc2.bias)

@@ -1,0 +1,274 @@
+// Fused transformer FFN for MI355X (gfx950):  Y = X + relu(X . W1^T + b1) . W2^T + b2
+// (reference codetr/transformer_mmcv.py:484-500: Linear -> ReLU -> Linear + identity; encoder / decoder FFN of
+// Co-DINO: C = 256, hidden = 2048 -- 37 % of the model's flops at 1920x1280).
+//
+// As two GEMMs the hidden activation [M, 2048] (838 MB in fp16 at M = 204 600) is written to HBM by the first and
+// read back by the second, and each GEMM re-reads its activation tile from L2 once per 128-column output tile.  Here
+// the hidden activation never leaves the CU:
+//   * a 256-thread workgroup owns 128 rows; each wave keeps its 32 rows of X as MFMA B-fragments in registers
+//     (2 m-tiles x 8 k-steps) for the whole kernel and its 32 x 256 slice of Y in accumulators;
+//   * the hidden dimension is walked in chunks of 64: H^T[h][m] = W1c . X^T  (K = 256), bias folded into the
+//     accumulator init, ReLU, fp16 pack -- and the packed accumulator IS the B operand of the second product
+//     (cdna_hip_programming.md section 3 "accumulator tile as the next MFMA's operand": the k-slot permutation
+//     8g+j <-> rows {4g..4g+3} of two 16-row tiles is baked into W2 once, by codetr_ffn_pack_w2_f16, so that the
+//     matching A fragment is one ds_read_b128);
+//     Y^T[n][m] += W2c . relu(H)^T  (K = 64);
+//   * W1 / W2 chunks (32 KiB each) stream through a 2-stage LDS ring by LDS-DMA, XOR-swizzled on the source address
+//     so that the ds_read_b128 fragment reads are conflict-free; one barrier per chunk (128 MFMAs per wave);
+//     with one wave per SIMD nothing else hides LDS latency: fragments are read one step ahead of their MFMAs;
+//   * the epilogue adds the residual X and streams whole rows out through LDS, like the linear kernel.
+// Algorithmic HBM traffic: X once in, Y once out (2 x M x 256 x 2 B) + 2 MB of weights re-read from L2 per workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codetr_hip.h"
+
+namespace {
+
+constexpr int C = 256;         // model width (K of the first product, N of the second)
+constexpr int BM = 128;        // rows per workgroup
+constexpr int BH = 64;         // hidden units per chunk
+constexpr int kThreads = 256;
+constexpr int kW1Bytes = BH * C * 2;   // 32 KiB: [64 h][256 k]
+constexpr int kW2Bytes = C * BH * 2;   // 32 KiB: [256 n][64 h]
+constexpr int kStageBytes = kW1Bytes + kW2Bytes;
+constexpr int kOutPitch = C * 2 + 16;  // staged output row: 512 B + 16
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// stage chunk `c` (hidden units c*64 .. c*64+63) of W1 [Hd, 256] and W2 [256, Hd] into one LDS stage
+__device__ __forceinline__ void stage_chunk(const unsigned short* __restrict__ W1, const unsigned short* __restrict__ W2,
+                                            int Hd, int c, unsigned char* stage, int tid) {
+  const int wave = tid >> 6;
+  // W1 chunk: 64 rows x 32 chunks of 16 B; LDS position p of row r holds source chunk p ^ (r & 15) (low 4 bits)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int u = q * kThreads + tid;
+    const int r = u >> 5, pos = u & 31;
+    const int chunk = pos ^ (r & 15);
+    const unsigned short* g = W1 + (size_t)(c * BH + r) * C + chunk * 8;
+    unsigned char* l = stage + (q * kThreads + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  }
+  // W2 chunk: 256 rows (n) x 8 chunks of 16 B (64 hidden units); position p of row n holds chunk p ^ ((n >> 1) & 7)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int u = q * kThreads + tid;
+    const int n = u >> 3, pos = u & 7;
+    const int chunk = pos ^ ((n >> 1) & 7);
+    const unsigned short* g = W2 + (size_t)n * Hd + c * BH + chunk * 8;
+    unsigned char* l = stage + kW1Bytes + (q * kThreads + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(
+    const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
+    const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
+    int Hd) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes];  // 128 KiB, one object
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, grp = lane >> 4;
+  const int m0 = (int)xcd_tile(blockIdx.x, gridDim.x) * BM + wave * 32;  // this wave's first row
+  const int nchunks = Hd / BH;
+
+  stage_chunk(W1, W2, Hd, 0, lds, tid);
+
+  // X fragments of this wave's 32 rows (B operand: lane (j = l15, g) holds X[m][32*ks + 8g .. +7]), kept for good
+  f16x8 xf[2][8];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int m = m0 + mt * 16 + l15;
+    m = m < M ? m : M - 1;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      xf[mt][ks] = *reinterpret_cast<const f16x8*>(X + (size_t)m * C + ks * 32 + grp * 8);
+  }
+  // Y accumulators start at b2 (lane's 4 consecutive n of tile nt: n = 16*nt + 4*grp + r)
+  f32x4 yacc[16][2];
+#pragma unroll
+  for (int nt = 0; nt < 16; ++nt) {
+    const f16x4 bb = *reinterpret_cast<const f16x4*>(b2 + nt * 16 + grp * 4);
+    const f32x4 b4 = {(float)bb[0], (float)bb[1], (float)bb[2], (float)bb[3]};
+    yacc[nt][0] = b4;
+    yacc[nt][1] = b4;
+  }
+
+  // bias of a chunk's hidden units for this lane (4 consecutive h per 16-row tile); loaded one chunk ahead
+  f16x4 b1v[4], b1n[4];
+#pragma unroll
+  for (int ht = 0; ht < 4; ++ht) b1v[ht] = *reinterpret_cast<const f16x4*>(b1 + ht * 16 + grp * 4);
+
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c landed (and the bias / X loads issued earlier)
+    __builtin_amdgcn_s_barrier();                      // ... for everyone; everyone is done with chunk c-1's stage
+    if (c + 1 < nchunks) {
+      stage_chunk(W1, W2, Hd, c + 1, lds + ((c + 1) & 1) * kStageBytes, tid);
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht) b1n[ht] = *reinterpret_cast<const f16x4*>(b1 + (c + 1) * BH + ht * 16 + grp * 4);
+    }
+    const unsigned char* sW1 = lds + (c & 1) * kStageBytes;
+    const unsigned char* sW2 = sW1 + kW1Bytes;
+
+    // ---- H^T = W1c . X^T : D[i = h][j = m] ----
+    f32x4 hacc[4][2];
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht) {
+      const f32x4 b4 = {(float)b1v[ht][0], (float)b1v[ht][1], (float)b1v[ht][2], (float)b1v[ht][3]};
+      hacc[ht][0] = b4;
+      hacc[ht][1] = b4;
+    }
+    // one wave per SIMD: nobody else hides LDS latency, so the A fragments of k-step ks+1 are read while the
+    // MFMAs of k-step ks issue (explicit register double buffering)
+    auto read_w1 = [&](int ks, f16x8 (&a)[4]) {
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht) {
+        const int row = ht * 16 + l15;
+        const int chunk = (ks * 4 + grp) ^ (row & 15);
+        a[ht] = *reinterpret_cast<const f16x8*>(sW1 + row * (C * 2) + chunk * 16);
+      }
+    };
+    f16x8 aw[2][4];
+    read_w1(0, aw[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // pin the schedule: 4 LDS reads of step ks+1, then the 8
+#pragma unroll                                          // MFMAs of step ks (hipcc otherwise serialises read->wait->2 MFMA)
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) read_w1(ks + 1, aw[(ks + 1) & 1]);
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht) {
+        hacc[ht][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks & 1][ht], xf[0][ks], hacc[ht][0], 0, 0, 0);
+        hacc[ht][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks & 1][ht], xf[1][ks], hacc[ht][1], 0, 0, 0);
+      }
+      if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+    // ---- ReLU + pack: B operand of the second product, k-slot 8g+j = rows 4g..4g+3 of tiles 2s and 2s+1 ----
+    f16x8 pf[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = hacc[2 * s + h][mt][r];
+            pf[s][mt][h * 4 + r] = (_Float16)(v < 0.f ? 0.f : v);
+          }
+    // ---- Y^T += W2c . relu(H)^T : D[i = n][j = m], k = hidden unit (permuted identically on both operands) ----
+    // W2 fragments (pre-packed: the 8 k-slots of lane group g are 16 contiguous bytes) are read two n-tiles
+    // ahead of their MFMAs, same double buffering
+    auto read_w2 = [&](int ntp, f16x8 (&a)[4]) {  // n-tiles 2*ntp, 2*ntp+1; index [t*2 + s]
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n = (2 * ntp + t) * 16 + l15;
+        const unsigned char* rowp = sW2 + n * (BH * 2);
+        const int sw = (n >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          a[t * 2 + s] = *reinterpret_cast<const f16x8*>(rowp + ((4 * s + grp) ^ sw) * 16);
+      }
+    };
+    f16x8 a2[2][4];
+    read_w2(0, a2[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int ntp = 0; ntp < 8; ++ntp) {
+      if (ntp + 1 < 8) read_w2(ntp + 1, a2[(ntp + 1) & 1]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int nt = 2 * ntp + t;
+          yacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ntp & 1][t * 2 + s], pf[s][0], yacc[nt][0], 0, 0, 0);
+          yacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ntp & 1][t * 2 + s], pf[s][1], yacc[nt][1], 0, 0, 0);
+        }
+      if (ntp + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht) b1v[ht] = b1n[ht];
+  }
+  __builtin_amdgcn_s_barrier();  // every wave is done with the last stage: LDS is free
+
+  // ---- epilogue: Y tile of this wave (32 rows x 256) through LDS, + residual X, whole 512-byte rows out ----
+  unsigned char* stage = lds + wave * (32 * kOutPitch);
+#pragma unroll
+  for (int nt = 0; nt < 16; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const f16x4 o = {(_Float16)yacc[nt][mt][0], (_Float16)yacc[nt][mt][1], (_Float16)yacc[nt][mt][2],
+                       (_Float16)yacc[nt][mt][3]};
+      *reinterpret_cast<f16x4*>(stage + (mt * 16 + l15) * kOutPitch + (nt * 16 + grp * 4) * 2) = o;
+    }
+  __builtin_amdgcn_wave_barrier();
+  // 32 rows x 32 chunks of 16 B: lane -> (row = it*2 + lane/32, chunk = lane%32)
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 2 + (lane >> 5), chunk = lane & 31;
+    const int m = m0 + row;
+    if (m < M) {
+      const f16x8 y = *reinterpret_cast<const f16x8*>(stage + row * kOutPitch + chunk * 16);
+      const f16x8 x = *reinterpret_cast<const f16x8*>(X + (size_t)m * C + chunk * 8);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)y[e] + (float)x[e]);  // identity + ffn(x): fp16 + fp16 -> fp16
+      *reinterpret_cast<f16x8*>(Y + (size_t)m * C + chunk * 8) = o;
+    }
+  }
+}
+
+// W2 [256, hidden] -> same shape with the columns of every 64-block reordered to MFMA k-slot order:
+// new column 32s + 8g + j  <-  old column 32s + 4g + j (j < 4)  |  32s + 16 + 4g + (j - 4) (j >= 4)
+__global__ void pack_w2_kernel(const unsigned short* __restrict__ w2, unsigned short* __restrict__ out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i & 63);
+  const int s = col >> 5, g = (col >> 3) & 3, j = col & 7;
+  const int old = 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+  out[i] = w2[(i & ~(int64_t)63) + old];
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_ffn_pack_w2_f16(void* stream, const void* w2_dev, void* w2_packed_dev, int64_t C_out, int64_t hidden) {
+  if (!w2_dev || !w2_packed_dev || C_out <= 0 || hidden <= 0) return CODETR_E_BADARG;
+  if (hidden % BH != 0) return CODETR_E_UNSUPPORTED;
+  const int64_t total = C_out * hidden;
+  hipLaunchKernelGGL(pack_w2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(w2_dev), static_cast<unsigned short*>(w2_packed_dev), total);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+int codetr_ffn_relu_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
+                        const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                        int64_t hidden) {
+  const void* w2_dev = w2_packed_dev;
+  if (!x_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !y_dev || M <= 0 || hidden <= 0) return CODETR_E_BADARG;
+  if (C_in != C || hidden % BH != 0) return CODETR_E_UNSUPPORTED;
+  if (M > 0x7fffffffLL - BM || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  const unsigned blocks = (unsigned)((M + BM - 1) / BM);
+  hipLaunchKernelGGL(ffn_fused_kernel, dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(x_dev), static_cast<const unsigned short*>(w1_dev),
+                     static_cast<const unsigned short*>(b1_dev), static_cast<const unsigned short*>(w2_dev),
+                     static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
+                     (int)hidden);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // extern "C"

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 10
+#define CODETR_HIP_ABI_VERSION 12
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -224,6 +224,24 @@ int codetr_groupnorm_tokens_f16(void *stream, const void *x_dev, const void *gam
 int codetr_sine_pos_tokens_f16(void *stream, const float *ycum_dev, const float *xcum_dev, const void *level_embed_dev,
                                void *out_dev, int64_t out_batch_stride, int64_t B, int64_t H, int64_t W, int num_feats,
                                float temperature, float scale, float eps, float offset, int normalize);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused transformer FFN:  y = x + relu(x . w1^T + b1) . w2^T + b2      (hidden activation never leaves the CU)
+ *
+ * Replaces FFN.forward (codetr/transformer_mmcv.py:484-500: Linear, ReLU, Linear, + identity) of the deformable
+ * encoder / DINO decoder layers (configs lsj:72-79, 92-99: embed_dims 256, feedforward_channels 2048).
+ *   x_dev [M, 256]; w1_dev [hidden, 256]; b1_dev [hidden]; b2_dev [256]; y_dev [M, 256]; all f16
+ *   w2_packed_dev [256, hidden]: the second Linear's weight passed ONCE through codetr_ffn_pack_w2_f16 (a column
+ *   permutation inside every 64-block that puts the hidden units in the order the first product's accumulators
+ *   hold them, so that those accumulators feed the second product without leaving registers)
+ * C_in must be 256, hidden a multiple of 64.  fp32 accumulation; the hidden activation is rounded to f16 between
+ * the two products and the FFN output once more before the residual add (as the two-kernel f16 path does).
+ * ------------------------------------------------------------------------------------------ */
+int codetr_ffn_relu_f16(void *stream, const void *x_dev, const void *w1_dev, const void *b1_dev,
+                        const void *w2_packed_dev, const void *b2_dev, void *y_dev, int64_t M, int64_t C_in,
+                        int64_t hidden);
+/* one-time weight pre-pack for the call above: w2_dev [C_out, hidden] f16 -> w2_packed_dev (same shape) */
+int codetr_ffn_pack_w2_f16(void *stream, const void *w2_dev, void *w2_packed_dev, int64_t C_out, int64_t hidden);
 
 #ifdef __cplusplus
 }

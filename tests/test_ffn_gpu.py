@@ -1,0 +1,58 @@
+"""GPU parity of the fused FFN kernel (C ABI codetr_ffn_relu_f16) against a plain PyTorch fp32 reference of the
+same op, y = x + relu(x W1^T + b1) W2^T + b2, with the hidden activation rounded to fp16 between the products (what
+the kernel -- and the reference's fp16 path -- does).  Tolerance: fp32 accumulation on both sides; differences are
+summation order + the two fp16 roundings of the FFN branch: |err| <= 2 ulp(fp16) of the branch magnitude + 1 ulp
+of the result."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(x, w1, b1, w2, b2):
+    h = torch.relu(x.float() @ w1.float().t() + b1.float()).half().float()
+    y = (h @ w2.float().t() + b2.float()).half().float()
+    return (y + x.float())
+
+
+@pytest.mark.parametrize("M,hidden", [(1, 64), (128, 2048), (129, 2048), (900, 2048), (5000, 512), (30785, 2048)])
+def test_ffn_fused_vs_fp32(M, hidden):
+    from codetr import _cabi, hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(M + hidden)
+    x = torch.randn(M, 256, device=DEV, generator=g).half()
+    w1 = (torch.randn(hidden, 256, device=DEV, generator=g) / 16).half()
+    b1 = (torch.randn(hidden, device=DEV, generator=g) * 0.5).half()
+    w2 = (torch.randn(256, hidden, device=DEV, generator=g) / hidden ** 0.5).half()
+    b2 = (torch.randn(256, device=DEV, generator=g) * 0.5).half()
+    before = _cabi.CALLS["ffn_fused"]
+    y = hip_ops.ffn_fused(x, w1, b1, w2, b2)
+    torch.cuda.synchronize()
+    assert _cabi.CALLS["ffn_fused"] == before + 1 and y.shape == x.shape and y.dtype == torch.float16
+    ref = _ref(x, w1, b1, w2, b2)
+    branch = (ref - x.float()).abs()
+    tol = 2.0 ** -10 * (2 * branch + ref.abs()) + 2e-3
+    err = (y.float() - ref).abs()
+    assert (err <= tol).all(), f"max err {float(err.max())} at tol {float(tol.flatten()[err.argmax()])}"
+
+
+def test_ffn_module_takes_fused_path_and_matches_two_gemm_path():
+    from codetr import _cabi, hip_ops
+    from codetr.transformer_layers import FFN
+
+    torch.manual_seed(0)
+    ffn = FFN(embed_dims=256, feedforward_channels=2048).to(DEV).half().eval()
+    x = torch.randn(2, 777, 256, device=DEV).half()
+    before = dict(_cabi.CALLS)
+    with torch.no_grad():
+        y = ffn(x)
+        fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
+        h = hip_ops.linear(x, fc1.weight, fc1.bias, act="relu")
+        y2 = hip_ops.linear(h, fc2.weight, fc2.bias, residual=x)
+    assert _cabi.CALLS["ffn_fused"] == before["ffn_fused"] + 1
+    torch.testing.assert_close(y.float(), y2.float(), rtol=2e-3, atol=4e-3)
+    # explicit identity / no identity keep the two-GEMM path (different residual semantics)
+    with torch.no_grad():
+        y3 = ffn(x, identity=torch.zeros_like(x))
+    torch.testing.assert_close(y3.float(), (y2.float() - x.float()), rtol=2e-3, atol=6e-3)

@@ -1,0 +1,27 @@
+"""Micro-benchmark: fused FFN kernel vs two native GEMMs at the encoder shape (GPU box only)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "co-detr-tensorrt_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench_linear import timeit  # noqa: E402
+from codetr import hip_ops  # noqa: E402
+
+for M in (204600, 73656, 30785):
+    x = torch.randn(M, 256, device="cuda").half()
+    w1 = (torch.randn(2048, 256, device="cuda") / 16).half()
+    b1 = torch.randn(2048, device="cuda").half()
+    w2 = (torch.randn(256, 2048, device="cuda") / 45).half()
+    b2 = torch.randn(256, device="cuda").half()
+    tf = timeit(lambda: hip_ops.ffn_fused(x, w1, b1, w2, b2))
+
+    def two():
+        h = hip_ops.linear(x, w1, b1, act="relu")
+        return hip_ops.linear(h, w2, b2, residual=x)
+
+    t2 = timeit(two)
+    fl = 2 * 2.0 * M * 256 * 2048
+    print(f"M={M}: fused FFN {tf * 1e6:.1f} us ({fl / tf / 1e12:.0f} TF/s)   two native GEMMs {t2 * 1e6:.1f} us ({fl / t2 / 1e12:.0f} TF/s)")
