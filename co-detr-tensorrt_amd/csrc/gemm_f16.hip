@@ -228,17 +228,35 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
     if (t + STAGES - 1 < nk) issue(t + STAGES - 1);  // overwrites the buffer of tile t-1
     const unsigned char* bufW = lds + (t % STAGES) * kStageBytes;
     const unsigned char* bufX = bufW + kTileBytes;
+    // Fragment reads of k-step ks+1 are issued before the MFMAs of k-step ks (register double buffering), and the
+    // order is pinned with sched_group_barrier: left alone, hipcc emits read -> s_waitcnt lgkmcnt(0) -> a few MFMAs
+    // groups, which exposes the LDS latency whenever the co-resident waves are in the same phase.
+    constexpr int KS = BKT / 32;
+    typename T::frag a[2][4], b[2][4];
+    auto read_frags = [&](int ks, int buf) {
 #pragma unroll
-    for (int ks = 0; ks < BKT / 32; ++ks) {
-      typename T::frag a[4], b[4];
+      for (int i = 0; i < 4; ++i) a[buf][i] = read_frag<T, BKT>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = read_frag<T, BKT>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
+      for (int j = 0; j < 4; ++j) b[buf][j] = read_frag<T, BKT>(bufX, wm * 64 + j * 16 + frow, ks * 4 + fchunk);
+    };
+    read_frags(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = read_frag<T, BKT>(bufX, wm * 64 + j * 16 + frow, ks * 4 + fchunk);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) read_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma(a[ks & 1][i], b[ks & 1][j], acc[i][j]);
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
     }
   }
   __builtin_amdgcn_s_barrier();  // all fragment reads done (no DMA is in flight any more): LDS is free for the epilogue
