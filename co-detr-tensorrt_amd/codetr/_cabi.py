@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 14
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -32,6 +32,10 @@ SIGNATURES = {
                                               _i32, _i32, _i32, _i64, _i32, _vp]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
+    "codetr_mask_pyramid": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "codetr_linear_splitk_plan": (_i32, [_i64, _i64, _i64, _vp]),
+    "codetr_linear_splitk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
+    "codetr_linear_splitk_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
     "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_groupnorm_tokens_workspace_bytes": (_i64, [_i64, _i64, _i64]),
@@ -49,7 +53,7 @@ _lib = None
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
-         "sine_pos_tokens": 0, "ffn_fused": 0}
+         "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0}
 
 
 def load():
@@ -148,6 +152,54 @@ def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None, hm_rows=0, 
         row_mask.data_ptr() if row_mask is not None else None,
         out2d.data_ptr(), M, N, K, _ACT[act], hm_rows, hm_head_dim)
     check(rc, "codetr_linear")
+    return out2d
+
+
+def mask_pyramid(img_masks, shapes):
+    """img_masks [B,H,W] bool/uint8 -> (mask_flat [B,S] bool, ycum, xcum (flat fp32, level l = [B,H_l,W_l] at
+    B*start_l), valid_counts [B,L,2] fp32); see include/codetr_hip.h"""
+    CALLS["mask_pyramid"] += 1
+    B, Hi, Wi = img_masks.shape
+    L = len(shapes)
+    S = sum(int(h) * int(w) for h, w in shapes)
+    dev = img_masks.device
+    mask_flat = torch.empty((B, S), dtype=torch.bool, device=dev)
+    cums = torch.empty((2, B * S), dtype=torch.float32, device=dev)
+    counts = torch.empty((B, L, 2), dtype=torch.float32, device=dev)
+    hw = (ctypes.c_int64 * (2 * L))(*[int(v) for s in shapes for v in s])
+    rc = load().codetr_mask_pyramid(current_stream_ptr(dev), img_masks.data_ptr(), B, Hi, Wi, L, hw,
+                                    mask_flat.data_ptr(), cums[0].data_ptr(), cums[1].data_ptr(), counts.data_ptr())
+    check(rc, "codetr_mask_pyramid")
+    return mask_flat, cums[0], cums[1], counts
+
+
+_SPLITK_PLANS = {}
+
+
+def linear_splitk_plan(M, N, K):
+    """(splits, workspace_bytes) the library wants for this problem; splits == 1 -> single-pass codetr_linear_*"""
+    key = (M, N, K)
+    if key not in _SPLITK_PLANS:
+        nbytes = ctypes.c_int64(0)
+        splits = load().codetr_linear_splitk_plan(M, N, K, ctypes.byref(nbytes))
+        _SPLITK_PLANS[key] = (int(splits), int(nbytes.value))
+    return _SPLITK_PLANS[key]
+
+
+def linear_splitk(x2d, weight, bias, residual2d, act, out2d, splits, workspace, row_mask=None):
+    """Two-pass split-K form of `linear` (few output tiles, long K); workspace: uint8 tensor from the plan."""
+    lib = load()
+    CALLS["linear"] += 1
+    CALLS["linear_splitk"] += 1
+    M, K = x2d.shape
+    N = weight.shape[0]
+    fn = lib.codetr_linear_splitk_f16 if x2d.dtype == torch.float16 else lib.codetr_linear_splitk_bf16
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(),
+            bias.data_ptr() if bias is not None else None,
+            residual2d.data_ptr() if residual2d is not None else None,
+            row_mask.data_ptr() if row_mask is not None else None,
+            out2d.data_ptr(), M, N, K, _ACT[act], splits, workspace.data_ptr(), workspace.numel())
+    check(rc, "codetr_linear_splitk")
     return out2d
 
 

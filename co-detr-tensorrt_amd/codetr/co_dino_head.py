@@ -106,25 +106,38 @@ class CoDINOHead(nn.Module):
         backbone/neck path hands over, no NCHW round trip."""
         Himg, Wimg = img_masks.shape[-2:]
         masks, pos = [], []
-        m4 = img_masks.unsqueeze(1)
         pe = self.positional_encoding
         native_pos = feat.is_cuda and feat.dtype == torch.float16 and pe.num_feats % 8 == 0
         pos_flat = feat.new_empty(feat.shape[0], feat.shape[1], 2 * pe.num_feats) if native_pos else None
+        B = feat.shape[0]
+        mask_flat = valid_counts = None
+        if feat.is_cuda:
+            # one launch: level masks (already concatenated), running valid counts for the encoding, valid-ratio counts
+            mask_flat, ycum, xcum, valid_counts = hip_ops.mask_pyramid(img_masks, shapes)
+        else:
+            m4 = img_masks.unsqueeze(1)
         start = 0
         for lvl, hw in enumerate(shapes):
-            m = F.interpolate(m4, size=tuple(hw)).to(torch.bool).squeeze(1)  # nearest
+            n = hw[0] * hw[1]
+            if mask_flat is not None:
+                m = mask_flat[:, start:start + n].view(B, hw[0], hw[1])
+                cums = hip_ops.level_cums(ycum, xcum, B, start, hw)
+            else:
+                m = F.interpolate(m4, size=tuple(hw)).to(torch.bool).squeeze(1)  # nearest
+                cums = None
             masks.append(m)
             if native_pos:
                 # one kernel per level: encoding + level embedding straight into lvl_pos_embed[:, start:start+HW]
                 hip_ops.sine_pos_tokens_into(m, pos_flat, start, self.transformer.level_embeds[lvl], pe.num_feats,
-                                             pe.temperature, pe.scale, pe.eps, pe.offset, pe.normalize)
-                start += hw[0] * hw[1]
+                                             pe.temperature, pe.scale, pe.eps, pe.offset, pe.normalize, cums=cums)
             else:
                 pos.append(pe.forward_tokens(m, dtype=feat.dtype))
+            start += n
         state, refs = self.transformer.forward_flat(feat, shapes, masks, pos, reg_branches=self.reg_branches,
                                                     cls_branches=self.cls_branches if self.as_two_stage else None,
                                                     forced_topk_indices=forced_topk_indices, capture=capture,
-                                                    lvl_pos_embed_flat=pos_flat)
+                                                    lvl_pos_embed_flat=pos_flat, mask_flat=mask_flat,
+                                                    valid_counts=valid_counts)
         lvl = len(self.transformer.decoder.layers) - 1
         cls_head = self.cls_branches[lvl]
         cls = hip_ops.linear(state, cls_head.weight, cls_head.bias)  # [B,Nq,classes]

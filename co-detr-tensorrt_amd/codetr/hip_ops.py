@@ -18,7 +18,8 @@ from . import _cabi
 # ops served by hand-written HIP kernels in this build (kept in sync with include/codetr_hip.h)
 NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_window_attention(f16, head_dim 32)",
           "msda_fused(softmax + sampling locations in-kernel)", "groupnorm_tokens(f16, 8 ch/group)",
-          "sine_pos_tokens(f16, + level_embed)", "ffn_fused(f16, 256 -> hidden -> 256, ReLU, + identity)"}
+          "sine_pos_tokens(f16, + level_embed)", "ffn_fused(f16, 256 -> hidden -> 256, ReLU, + identity)",
+          "mask_pyramid(level masks + running valid counts + valid ratios)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -67,13 +68,20 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
         out = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
         if x2.shape[0] > 0:
             with torch.cuda.device(x.device):
+                splits, ws_bytes = (1, 0) if head_major else _cabi.linear_splitk_plan(x2.shape[0], N, K)
+                if splits > 1:
+                    # few output tiles, long K (the neck's extra level as a GEMM): two-pass split-K, fp32 partials
+                    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+                    launch = lambda: _cabi.linear_splitk(x2, w, bias, r2, act, out, splits, ws, mk)  # noqa: E731
+                else:
+                    launch = lambda: _cabi.linear(x2, w, bias, r2, act, out, mk, hm_rows, hm_hd)  # noqa: E731
                 if LINEAR_PROFILE is None:
-                    _cabi.linear(x2, w, bias, r2, act, out, mk, hm_rows, hm_hd)
+                    launch()
                 else:
                     st = torch.cuda.current_stream(x.device)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(st)
-                    _cabi.linear(x2, w, bias, r2, act, out, mk, hm_rows, hm_hd)
+                    launch()
                     e1.record(st)
                     LINEAR_PROFILE.append((e0, e1, 2.0 * x2.shape[0] * N * K, x2.shape[0], N, K))
         if head_major:
@@ -96,8 +104,15 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
     return y
 
 
+# One 128-row block of the fused FFN kernel runs ~100 us (it walks the whole hidden dimension alone), and the chip
+# holds 256 of them: below ~24k rows the grid is under one wave and the two plain GEMMs (which split N over blocks)
+# finish sooner -- measured 98.6 us fused vs 27 us as two GEMMs at the decoder's 900 rows.
+FFN_FUSED_MIN_ROWS = 24576
+
+
 def ffn_fused_supported(x, w1, w2, act):
-    return x.is_cuda and _cabi.ffn_fused_supported(x, w1, w2, act)
+    return (x.is_cuda and x.numel() // max(x.shape[-1], 1) >= FFN_FUSED_MIN_ROWS
+            and _cabi.ffn_fused_supported(x, w1, w2, act))
 
 
 _W2_PACKED = {}
@@ -165,16 +180,41 @@ def groupnorm_tokens_into(x, gamma, beta, groups, eps, dest, row_start):
     return dest
 
 
-def sine_pos_tokens_into(mask, dest, row_start, level_embed, num_feats, temperature, scale, eps, offset, normalize):
+def mask_pyramid(img_masks, shapes):
+    """img_masks [B,H,W] (float 0/1, bool or uint8; non-zero = padding) + level shapes [(H_l, W_l)] ->
+    (mask_flat [B,S] bool, ycum, xcum, valid_counts [B,L,2] fp32): the level masks (nearest resize), their running
+    valid counts and first-row / first-column valid counts, one launch (csrc/mask_pyramid.hip).  ycum / xcum are flat
+    fp32 buffers; `level_cums` slices out one level as [B,H_l,W_l]."""
+    _gpu(img_masks, "mask_pyramid")
+    m = img_masks
+    if m.dtype != torch.bool and m.dtype != torch.uint8:
+        m = m != 0
+    with torch.cuda.device(m.device):
+        return _cabi.mask_pyramid(m.contiguous(), [tuple(int(v) for v in s) for s in shapes])
+
+
+def level_cums(ycum, xcum, B, start, hw):
+    """level views [B,H_l,W_l] of mask_pyramid's running-count buffers (start = rows of the levels before)"""
+    n = hw[0] * hw[1]
+    return (ycum[B * start:B * (start + n)].view(B, hw[0], hw[1]), xcum[B * start:B * (start + n)].view(B, hw[0], hw[1]))
+
+
+def sine_pos_tokens_into(mask, dest, row_start, level_embed, num_feats, temperature, scale, eps, offset, normalize,
+                         cums=None):
     """Sine positional encoding of one level (mask [B,H,W] bool, True = padding) + level_embed, written into
-    dest[:, row_start:row_start+H*W, :] (dest [B,S,2*num_feats] f16 contiguous)."""
-    _gpu(mask, "sine_pos_tokens_into")
-    valid = ~mask
-    ycum = valid.cumsum(1, dtype=torch.float32).contiguous()
-    xcum = valid.cumsum(2, dtype=torch.float32).contiguous()
+    dest[:, row_start:row_start+H*W, :] (dest [B,S,2*num_feats] f16 contiguous).  cums = (ycum, xcum) [B,H,W] fp32
+    from mask_pyramid skips the two cumsum calls (mask may then be None)."""
+    if cums is None:
+        _gpu(mask, "sine_pos_tokens_into")
+        valid = ~mask
+        ycum = valid.cumsum(1, dtype=torch.float32).contiguous()
+        xcum = valid.cumsum(2, dtype=torch.float32).contiguous()
+    else:
+        ycum, xcum = cums
+        _gpu(ycum, "sine_pos_tokens_into")
     if dest.dtype != torch.float16 or not dest.is_contiguous() or dest.shape[2] != 2 * num_feats:
         raise AssertionError("destination must be a contiguous f16 [B, S, 2*num_feats] tensor")
-    with torch.cuda.device(mask.device):
+    with torch.cuda.device(ycum.device):
         _cabi.sine_pos_tokens(ycum, xcum, level_embed, dest[0, row_start:], dest.shape[1] * dest.shape[2], num_feats,
                               temperature, scale, eps, offset, normalize)
     return dest

@@ -144,6 +144,21 @@ def get_valid_ratio(mask, dtype=torch.float32):
     return torch.stack((vw, vh), -1)
 
 
+_PIXEL_CENTRES = {}
+
+
+def _pixel_centres(H, W, dtype, device):
+    """(ys, xs) [1, H*W]: linspace(0.5, H-0.5, H) x linspace(0.5, W-0.5, W) meshgrid, flattened; built once per
+    level shape (constants of the pyramid: keeps ~6 tiny kernels per level out of every forward)"""
+    key = (H, W, dtype, str(device))
+    hit = _PIXEL_CENTRES.get(key)
+    if hit is None:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=dtype, device=device),
+                                torch.linspace(0.5, W - 0.5, W, dtype=dtype, device=device), indexing="ij")
+        hit = _PIXEL_CENTRES[key] = (ys.reshape(1, -1).contiguous(), xs.reshape(1, -1).contiguous())
+    return hit
+
+
 def get_reference_points(mlvl_feats, valid_ratios, device):
     """pixel centres of every level, normalised by the VALID extent -> [B, S, 2] (x, y).
     `mlvl_feats`: the level tensors [B,C,H,W], or a list of (H, W) tuples (dtype then follows valid_ratios)."""
@@ -153,17 +168,24 @@ def get_reference_points(mlvl_feats, valid_ratios, device):
             (H, W), B, dt = feat, valid_ratios.shape[0], valid_ratios.dtype
         else:
             (B, _, H, W), dt = feat.shape, feat.dtype
-        ys, xs = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=dt, device=device),
-                                torch.linspace(0.5, W - 0.5, W, dtype=dt, device=device), indexing="ij")
-        y = ys.reshape(1, -1) / (valid_ratios[:, lvl, 1].reshape(B, 1) * H)
-        x = xs.reshape(1, -1) / (valid_ratios[:, lvl, 0].reshape(B, 1) * W)
+        ys, xs = _pixel_centres(H, W, dt, device)
+        y = ys / (valid_ratios[:, lvl, 1].reshape(B, 1) * H)
+        x = xs / (valid_ratios[:, lvl, 0].reshape(B, 1) * W)
         out.append(torch.stack((x, y), -1))
     return torch.cat(out, 1)
 
 
+_LVL_REPEATED = {}
+
+
 def get_lvl_repeated(mlvl_masks, dtype=torch.float32):
-    return torch.cat([torch.full((m.shape[-2] * m.shape[-1],), float(lvl), dtype=dtype, device=m.device)
-                      for lvl, m in enumerate(mlvl_masks)], 0)
+    """[S] level index of every token (constant per pyramid: cached)"""
+    key = (tuple(m.shape[-2] * m.shape[-1] for m in mlvl_masks), dtype, str(mlvl_masks[0].device))
+    hit = _LVL_REPEATED.get(key)
+    if hit is None:
+        hit = _LVL_REPEATED[key] = torch.cat([torch.full((n,), float(lvl), dtype=dtype, device=mlvl_masks[0].device)
+                                              for lvl, n in enumerate(key[0])], 0)
+    return hit
 
 
 def make_encoder_output_proposals_export(reference_points, mlvl_masks):
@@ -194,6 +216,16 @@ def apply_mask_to_proposal_and_memory(output_proposals, memory, memory_padding_m
 
 
 _SHAPE_TENSORS = {}
+_LEVEL_WH = {}
+
+
+def _level_wh(shapes, dtype, device):
+    """[L,2] (W_l, H_l) in `dtype`, built once per pyramid (the divisors of get_valid_ratio)"""
+    key = (tuple(tuple(s) for s in shapes), dtype, str(device))
+    hit = _LEVEL_WH.get(key)
+    if hit is None:
+        hit = _LEVEL_WH[key] = torch.tensor([[float(w), float(h)] for h, w in shapes], dtype=dtype, device=device)
+    return hit
 
 
 def _shape_tensors(shapes, device):
@@ -269,20 +301,27 @@ class CoDinoTransformer(nn.Module):
                                  capture)
 
     def forward_flat(self, feat, shapes, mlvl_masks, mlvl_pos_tokens, reg_branches=None, cls_branches=None,
-                     forced_topk_indices=None, capture=None, lvl_pos_embed_flat=None):
+                     forced_topk_indices=None, capture=None, lvl_pos_embed_flat=None, mask_flat=None,
+                     valid_counts=None):
         """Same computation on inputs that are already in the transformer's layout: feat [B,S,C] (levels
         concatenated), shapes [(H_l, W_l)], masks list of [B,H_l,W_l] bool, positional encodings list of
-        [B, H_l*W_l, C] -- or `lvl_pos_embed_flat` [B,S,C], the encodings with the level embeddings already added."""
+        [B, H_l*W_l, C] -- or `lvl_pos_embed_flat` [B,S,C], the encodings with the level embeddings already added.
+        `mask_flat` [B,S] bool / `valid_counts` [B,L,2] fp32 (hip_ops.mask_pyramid): the concatenated level masks and
+        the valid pixel counts of each level's first row / column, when the caller already has them."""
         if not self.as_two_stage:
             raise AssertionError("as_two_stage must be True for DINO")
         dev = feat.device
-        mask = torch.cat([m.flatten(1) for m in mlvl_masks], 1)  # [B,S]
+        mask = mask_flat if mask_flat is not None else torch.cat([m.flatten(1) for m in mlvl_masks], 1)  # [B,S]
         if lvl_pos_embed_flat is not None:
             pos = lvl_pos_embed_flat
         else:
             pos = torch.cat([p + self.level_embeds[l].view(1, 1, -1) for l, p in enumerate(mlvl_pos_tokens)], 1)
         spatial_shapes, level_start_index = _shape_tensors(shapes, dev)
-        valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
+        if valid_counts is not None:
+            # sum(~mask[:, 0, :]) / W, sum(~mask[:, :, 0]) / H of get_valid_ratio, from the counts of the pyramid kernel
+            valid_ratios = valid_counts.to(feat.dtype) / _level_wh(shapes, feat.dtype, dev)  # [B,L,2]
+        else:
+            valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
         reference_points = get_reference_points([tuple(s) for s in shapes], valid_ratios, device=dev)  # [B,S,2]
         ref_by_level = reference_points[:, :, None] * valid_ratios[:, None]  # [B,S,L,2]
 

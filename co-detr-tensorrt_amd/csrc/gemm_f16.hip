@@ -156,14 +156,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ACT: 0 none, 1 relu, 2 gelu(erf).  BKT x STAGES = the K pipeline: STAGES LDS buffers of one (W tile, X tile)
 // pair each, STAGES-1 tiles of LDS-DMA in flight across the per-K-step barrier (raw s_barrier + counted
 // s_waitcnt vmcnt: a __syncthreads() would drain the DMA queue, cdna_hip_programming.md section 5).
-template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, int BKT, int STAGES>
+// SPLITK: blockIdx.y picks a range of `kps` K tiles; the block's fp32 partial tile goes to Y viewed as
+// float[gridDim.y][M][N] (no bias / activation / residual: splitk_reduce_kernel applies them to the sum).
+template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, int BKT, int STAGES, bool SPLITK = false>
 __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* __restrict__ X,
                                                           const unsigned short* __restrict__ W,
                                                           const unsigned short* __restrict__ bias,
                                                           const unsigned short* __restrict__ R,
                                                           unsigned short* __restrict__ Y,
                                                           const unsigned char* __restrict__ row_mask, int M, int N,
-                                                          int K, int tiles_n, int hm_rows, int hm_hd) {
+                                                          int K, int tiles_n, int hm_rows, int hm_hd, int kps) {
   constexpr int kTileBytes = 128 * BKT * 2;        // one operand tile
   constexpr int kStageBytes = 2 * kTileBytes;      // W tile + X tile
   constexpr int LPS = 2 * (BKT / 16);              // LDS-DMA instructions per thread per stage
@@ -207,11 +209,12 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
     for (int j = 0; j < 4; ++j) acc[i][j] = b4;
   }
 
-  const int nk = K / BKT;
+  const int kt0 = SPLITK ? (int)blockIdx.y * kps : 0;
+  const int nk = SPLITK ? (K / BKT - kt0 < kps ? K / BKT - kt0 : kps) : K / BKT;
   auto issue = [&](int t) {
     unsigned char* buf = lds + (t % STAGES) * kStageBytes;
-    stage_tile<BKT>(W, N, K, n0, t * BKT, buf, tid);
-    stage_tile<BKT>(X, M, K, m0, t * BKT, buf + kTileBytes, tid);
+    stage_tile<BKT>(W, N, K, n0, (kt0 + t) * BKT, buf, tid);
+    stage_tile<BKT>(X, M, K, m0, (kt0 + t) * BKT, buf + kTileBytes, tid);
   };
 #pragma unroll
   for (int s0 = 0; s0 < STAGES - 1; ++s0)
@@ -260,6 +263,27 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
     }
   }
   __builtin_amdgcn_s_barrier();  // all fragment reads done (no DMA is in flight any more): LDS is free for the epilogue
+
+  if (SPLITK) {
+    float* part = reinterpret_cast<float*>(Y) + (size_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + ncol;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + frow;
+        if (m >= M || n >= N) continue;
+        if (vec_n) {
+          *reinterpret_cast<f32x4*>(part + (size_t)m * N + n) = acc[i][j];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < N) part[(size_t)m * N + n + r] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
 
   // ---- epilogue -------------------------------------------------------------------------------
   // accumulator layout: for MFMA tile (i, j) a lane holds n = wn*64 + i*16 + 4*(lane>>4) + r (r = 0..3),
@@ -374,10 +398,88 @@ int launch_cfg(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd);
-  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd);
-  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd);
-  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd);
+  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+// y = act(sum_z part[z] + bias) (masked rows -> 0) + residual, 4 columns per thread
+template <class T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
+                                                            const unsigned short* __restrict__ bias,
+                                                            const unsigned short* __restrict__ R,
+                                                            const unsigned char* __restrict__ row_mask,
+                                                            unsigned short* __restrict__ Y, int M, int N, int splits,
+                                                            int act) {
+  const int ngroups = (N + 3) / 4;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * ngroups) return;
+  const int m = (int)(idx / ngroups), n = (int)(idx % ngroups) * 4;
+  const size_t off = (size_t)m * N + n;
+  const bool vec = (N & 3) == 0;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < splits; ++z) {
+    const float* p = part + (size_t)z * M * N + off;
+    if (vec) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += q[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) v[r] += p[r];
+    }
+  }
+  const bool masked = row_mask && row_mask[m];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (n + r >= N) break;
+    float x = v[r] + (bias ? T::to_f32(bias[n + r]) : 0.f);
+    if (act == 1) x = x < 0.f ? 0.f : x;
+    if (act == 2) x = gelu_erf(x);
+    unsigned short h = masked ? (unsigned short)0 : T::from_f32(x);
+    if (R) h = T::from_f32(T::to_f32(h) + T::to_f32(R[off + r]));
+    Y[off + r] = h;
+  }
+}
+
+// Split-K plan: problems whose 128x128 output tiles cannot fill the chip but whose K is long (the neck's extra
+// 3x3/s2 level as a GEMM: 600 x 256 x 13824 = 10 tiles, 183 us in one pass) are cut along K into `splits` ranges of
+// whole 64-wide K tiles so that ~1.5 blocks per CU are in flight.  Returns 1 when a single pass is the better launch.
+int splitk_plan(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), ktiles = K / 64;
+  if (tiles > 64 || K < 2048 || K % 64 != 0) return 1;
+  int64_t splits = (384 + tiles - 1) / tiles;
+  if (splits > ktiles / 4) splits = ktiles / 4;
+  if (splits < 2) return 1;
+  const int64_t kps = (ktiles + splits - 1) / splits;
+  return (int)((ktiles + kps - 1) / kps);
+}
+
+template <class T>
+int launch_splitk(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
+                  const void* mask, int64_t M, int64_t N, int64_t K, int act, int splits, void* ws, int64_t ws_bytes) {
+  if (!X || !W || !Y || !ws || M <= 0 || N <= 0 || K <= 0 || splits < 2) return CODETR_E_BADARG;
+  if (K % 64 != 0 || act < 0 || act > 2) return CODETR_E_UNSUPPORTED;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL || K > 0x7fffffffLL || splits > 65535) return CODETR_E_TOO_LARGE;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(ws)) & 15)
+    return CODETR_E_BADARG;
+  if (ws_bytes < (int64_t)splits * M * N * 4) return CODETR_E_BADARG;
+  const int ktiles = (int)(K / 64), kps = (ktiles + splits - 1) / splits;
+  if ((int64_t)kps * (splits - 1) >= ktiles) return CODETR_E_BADARG;  // an empty last range
+  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits), block(kThreads);
+  hipLaunchKernelGGL((linear_kernel<T, 0, false, false, 64, 2, true>), grid, block, 0, st,
+                     static_cast<const unsigned short*>(X), static_cast<const unsigned short*>(W), nullptr, nullptr,
+                     static_cast<unsigned short*>(ws), nullptr, (int)M, (int)N, (int)K, tiles_n, 0, 0, kps);
+  const long groups = (long)M * ((N + 3) / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                     static_cast<const float*>(ws), static_cast<const unsigned short*>(bias),
+                     static_cast<const unsigned short*>(R), static_cast<const unsigned char*>(mask),
+                     static_cast<unsigned short*>(Y), (int)M, (int)N, splits, act);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -427,6 +529,26 @@ int codetr_linear_bf16(void* stream, const void* x_dev, const void* w_dev, const
                        int64_t K, int act, int64_t hm_rows, int hm_head_dim) {
   return launch<BFloatT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, row_mask_dev,
                          M, N, K, act, hm_rows, hm_head_dim);
+}
+
+int codetr_linear_splitk_plan(int64_t M, int64_t N, int64_t K, int64_t* workspace_bytes) {
+  const int splits = splitk_plan(M, N, K);
+  if (workspace_bytes) *workspace_bytes = splits > 1 ? (int64_t)splits * M * N * 4 : 0;
+  return splits;
+}
+
+int codetr_linear_splitk_f16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev,
+                             const void* residual_dev, const void* row_mask_dev, void* y_dev, int64_t M, int64_t N,
+                             int64_t K, int act, int splits, void* workspace_dev, int64_t workspace_bytes) {
+  return launch_splitk<HalfT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev,
+                              row_mask_dev, M, N, K, act, splits, workspace_dev, workspace_bytes);
+}
+
+int codetr_linear_splitk_bf16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev,
+                              const void* residual_dev, const void* row_mask_dev, void* y_dev, int64_t M, int64_t N,
+                              int64_t K, int act, int splits, void* workspace_dev, int64_t workspace_bytes) {
+  return launch_splitk<BFloatT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev,
+                                row_mask_dev, M, N, K, act, splits, workspace_dev, workspace_bytes);
 }
 
 }  // extern "C"

@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRowsPerSlab = 512;  // rows reduced by one workgroup in pass 1
+constexpr int kRowsPerSlab = 128;  // rows reduced by one workgroup in pass 1 (600 workgroups at the stride-8 level)
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float h2f(short b) {
@@ -71,23 +71,30 @@ __global__ __launch_bounds__(kThreads) void gn_partial_kernel(const short* __res
   }
 }
 
-// one thread per (b, group)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int B, int groups,
-                                   int nslab, double count, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * groups) return;
+// one wave per (b, group): lanes stride over the slabs, fp64 butterfly at the end (a single thread walking 600
+// dependent loads cost 22 us per level)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                         int B, int groups, int nslab, double count, float eps) {
+  const int i = blockIdx.x;
   const int b = i / groups, g = i % groups;
   double s = 0.0, q = 0.0;
-  for (int sl = 0; sl < nslab; ++sl) {
+  for (int sl = threadIdx.x; sl < nslab; sl += 64) {
     const float* p = partial + (((size_t)b * nslab + sl) * groups + g) * 2;
     s += (double)p[0];
     q += (double)p[1];
   }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
-  var = var < 0.0 ? 0.0 : var;
-  stats[2 * i] = (float)mean;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  if (threadIdx.x == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const short* __restrict__ x, const float* __restrict__ stats,
@@ -135,7 +142,7 @@ int codetr_groupnorm_tokens_f16(void* stream, const void* x_dev, const void* gam
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, (unsigned)B), dim3(kThreads), 0, st,
                      static_cast<const short*>(x_dev), partial, (int)HW, (int)C, nslab);
   const int nstat = (int)(B * groups);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 63) / 64), dim3(64), 0, st, partial, stats, (int)B, groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nstat), dim3(64), 0, st, partial, stats, (int)B, groups,
                      nslab, (double)HW * 8.0, eps);
   const int64_t chunks = B * HW * groups;
   int64_t blocks = (chunks + kThreads - 1) / kThreads;

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 12
+#define CODETR_HIP_ABI_VERSION 14
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -153,6 +153,45 @@ int codetr_linear_f16(void *stream, const void *x_dev, const void *w_dev, const 
 int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                        const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
                        int64_t K, int act, int64_t hm_rows, int hm_head_dim);
+
+/* Split-K form of the same layer for problems with few output tiles and a long K -- the neck's extra
+ * 3x3 / stride-2 level (codetr/codetr.py neck, mmdet ChannelMapper extra_convs) run as a GEMM over unfolded
+ * patches is [600, 13824] x [256, 13824]^T: 10 output tiles, one pass leaves 246 CUs idle.
+ *   codetr_linear_splitk_plan  returns the number of K ranges the library would use for (M, N, K) -- 1 means
+ *                              "call codetr_linear_*" -- and the fp32 workspace it needs (splits * M * N * 4 bytes).
+ *   codetr_linear_splitk_*     pass 1 writes one fp32 partial tile per (output tile, K range) into the workspace,
+ *                              pass 2 sums the ranges in fp32 and applies bias / activation / row mask / residual
+ *                              with the same semantics as codetr_linear_*.  `splits` must come from the plan.
+ * The workspace is caller-owned device memory (16-byte aligned) so that the calls stay allocation-free and
+ * hipGraph-capturable. */
+int codetr_linear_splitk_plan(int64_t M, int64_t N, int64_t K, int64_t *workspace_bytes);
+int codetr_linear_splitk_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                             const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
+                             int64_t K, int act, int splits, void *workspace_dev, int64_t workspace_bytes);
+int codetr_linear_splitk_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                              const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
+                              int64_t K, int act, int splits, void *workspace_dev, int64_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Padding-mask pyramid: everything the detection transformer derives from img_masks, one launch.
+ *
+ * Replaces, per level: F.interpolate(img_masks, size=feat.shape[-2:]).to(bool) (codetr/co_dino_head.py:155),
+ * not_mask.cumsum(1) / cumsum(2) (codetr/positional_encoding.py:78-79), the two sums of get_valid_ratio
+ * (codetr/transformer.py:384-399) and mask.flatten(1) + cat (codetr/transformer.py:513-520).
+ *
+ *   img_mask_dev        [B, H_img, W_img] uint8 / bool, non-zero = padding
+ *   level_shapes_host   HOST array of 2*num_levels int64: (H_l, W_l) per level (num_levels <= 8)
+ *   mask_flat_dev       [B, S] uint8, S = sum H_l*W_l: level masks (nearest-neighbour resize, ATen's index rule),
+ *                       levels concatenated -- the transformer's mask_flatten
+ *   ycum_dev, xcum_dev  fp32, S*B elements each; level l occupies [B, H_l, W_l] starting at element B*start_l:
+ *                       running count of valid pixels down the columns / along the rows (the inputs of
+ *                       codetr_sine_pos_tokens_f16)
+ *   valid_counts_dev    [B, num_levels, 2] fp32: valid pixels in the first row (w) and first column (h); the host
+ *                       divides by (W_l, H_l) in the model dtype to get valid_ratios
+ * ------------------------------------------------------------------------------------------ */
+int codetr_mask_pyramid(void *stream, const void *img_mask_dev, int64_t B, int64_t H_img, int64_t W_img,
+                        int num_levels, const int64_t *level_shapes_host, void *mask_flat_dev, float *ycum_dev,
+                        float *xcum_dev, float *valid_counts_dev);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension: y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta

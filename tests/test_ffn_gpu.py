@@ -43,7 +43,7 @@ def test_ffn_module_takes_fused_path_and_matches_two_gemm_path():
 
     torch.manual_seed(0)
     ffn = FFN(embed_dims=256, feedforward_channels=2048).to(DEV).half().eval()
-    x = torch.randn(2, 777, 256, device=DEV).half()
+    x = torch.randn(2, hip_ops.FFN_FUSED_MIN_ROWS // 2 + 77, 256, device=DEV).half()
     before = dict(_cabi.CALLS)
     with torch.no_grad():
         y = ffn(x)
@@ -56,3 +56,9 @@ def test_ffn_module_takes_fused_path_and_matches_two_gemm_path():
     with torch.no_grad():
         y3 = ffn(x, identity=torch.zeros_like(x))
     torch.testing.assert_close(y3.float(), (y2.float() - x.float()), rtol=2e-3, atol=6e-3)
+    # short inputs (the decoder's 900 queries) stay on the two-GEMM path: one fused block walks the whole hidden dim
+    before = dict(_cabi.CALLS)
+    with torch.no_grad():
+        ys = ffn(x[:, :450])
+    assert _cabi.CALLS["ffn_fused"] == before["ffn_fused"] and _cabi.CALLS["linear"] == before["linear"] + 2
+    torch.testing.assert_close(ys.float(), y2[:, :450].float(), rtol=2e-3, atol=4e-3)

@@ -138,3 +138,44 @@ def test_linear_head_major_output():
     y_hm = hip_ops.linear(x, w, b, row_mask=mask, head_major=hd)      # [B,H,S,hd]
     assert y_hm.shape == (B, Hh, S, hd)
     assert torch.equal(y_hm, y_rm.view(B, S, Hh, hd).permute(0, 2, 1, 3))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,bias,act,res", [
+    (600, 256, 13824, False, None, False),   # the neck's extra 3x3/s2 level over unfolded patches (1920x1280 input)
+    (900, 256, 2048, True, None, True),      # decoder FFN down-projection + identity
+    (77, 130, 4096, True, "relu", False),    # ragged M and N (scalar partial stores), K ranges of unequal length
+    (128, 8, 2112, True, "gelu", True),      # 33 K tiles
+])
+def test_linear_splitk(M, N, K, bias, act, res, dtype):
+    """Few output tiles + long K go through the two-pass split-K path (plan > 1) and match the fp32 reference."""
+    from codetr import _cabi
+
+    splits, nbytes = _cabi.linear_splitk_plan(M, N, K)
+    assert splits > 1 and nbytes == splits * M * N * 4
+    before = _cabi.CALLS["linear_splitk"]
+    _check(M, N, K, dtype, bias, act, res, seed=11)
+    assert _cabi.CALLS["linear_splitk"] == before + 1
+
+
+def test_linear_splitk_plan_and_row_mask():
+    from codetr import _cabi, hip_ops
+
+    assert _cabi.linear_splitk_plan(204600, 256, 2048) == (1, 0)   # plenty of tiles: single pass
+    assert _cabi.linear_splitk_plan(900, 256, 256) == (1, 0)       # short K
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(300, 2048, device=DEV, generator=g).half()
+    w = (torch.randn(64, 2048, device=DEV, generator=g) / 45).half()
+    b = torch.randn(64, device=DEV, generator=g).half()
+    mask = torch.rand(300, device=DEV, generator=g) < 0.3
+    before = _cabi.CALLS["linear_splitk"]
+    y = hip_ops.linear(x, w, b, row_mask=mask)
+    assert _cabi.CALLS["linear_splitk"] == before + 1
+    ref = _ref(x, w, b, None, None).masked_fill(mask[:, None], 0.0)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
+    assert (y[mask] == 0).all()
+    # a workspace smaller than the plan is refused, not overrun
+    out = torch.empty(300, 64, device=DEV, dtype=torch.float16)
+    splits, nbytes = _cabi.linear_splitk_plan(300, 64, 2048)
+    with pytest.raises(RuntimeError):
+        _cabi.linear_splitk(x, w, b, None, None, out, splits, torch.empty(nbytes - 16, dtype=torch.uint8, device=DEV))

@@ -269,6 +269,7 @@ def test_token_major_path_equals_nchw_path():
         before = dict(_cabi.CALLS)
         b1, s1, l1 = model(img, mask, forced_topk_indices=picks)                     # token-major route
     assert _cabi.CALLS["groupnorm_tokens"] - before["groupnorm_tokens"] == 5  # 4 mapped levels + the stride-2 extra level
+    assert _cabi.CALLS["mask_pyramid"] - before["mask_pyramid"] == 1
     torch.testing.assert_close(s1.float(), s0.float(), rtol=2e-2, atol=2e-3)
     # near-tied scores may swap ranks between the two routes (fp16 noise): match detections as sets --
     # same label, score within 2 %, box within 1 px (200 px wide image)
