@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 16
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -32,6 +32,9 @@ SIGNATURES = {
                                               _i32, _i32, _i32, _i64, _i32, _vp]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
+    "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp]),
+    "codetr_encoder_geometry_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "codetr_row_max_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
     "codetr_mask_pyramid": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "codetr_linear_splitk_plan": (_i32, [_i64, _i64, _i64, _vp]),
     "codetr_linear_splitk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
@@ -53,7 +56,8 @@ _lib = None
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
-         "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0}
+         "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
+         "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0}
 
 
 def load():
@@ -153,6 +157,46 @@ def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None, hm_rows=0, 
         out2d.data_ptr(), M, N, K, _ACT[act], hm_rows, hm_head_dim)
     check(rc, "codetr_linear")
     return out2d
+
+
+def query_sine_embed(ref, valid_ratios, pos_feat, temperature=10000.0, apply_sigmoid=True):
+    """ref [B,Nq,2|4] f16 (unactivated), valid_ratios [B,L,2] f16 -> (ref_in [B,Nq,L,d] f16, embed [B,Nq,d*pos_feat] f16)"""
+    CALLS["query_sine_embed"] += 1
+    B, Nq, d = ref.shape
+    L = valid_ratios.shape[1]
+    ref_in = torch.empty((B, Nq, L, d), dtype=ref.dtype, device=ref.device)
+    embed = torch.empty((B, Nq, d * pos_feat), dtype=ref.dtype, device=ref.device)
+    rc = load().codetr_query_sine_embed_f16(current_stream_ptr(ref.device), ref.data_ptr(), valid_ratios.data_ptr(), B, Nq,
+                                            d, L, pos_feat, float(temperature), 1 if apply_sigmoid else 0,
+                                            ref_in.data_ptr(), embed.data_ptr())
+    check(rc, "codetr_query_sine_embed_f16")
+    return ref_in, embed
+
+
+def encoder_geometry(valid_ratios, mask_flat, shapes):
+    """-> (reference_points [B,S,2], reference_by_level [B,S,L,2], proposals [B,S,4]) f16, row_state [B,S] uint8"""
+    CALLS["encoder_geometry"] += 1
+    B, S = mask_flat.shape
+    L = len(shapes)
+    dev = mask_flat.device
+    ref = torch.empty((B, S, 2), dtype=torch.float16, device=dev)
+    ref_lvl = torch.empty((B, S, L, 2), dtype=torch.float16, device=dev)
+    prop = torch.empty((B, S, 4), dtype=torch.float16, device=dev)
+    state = torch.empty((B, S), dtype=torch.uint8, device=dev)
+    hw = (ctypes.c_int64 * (2 * L))(*[int(v) for s in shapes for v in s])
+    rc = load().codetr_encoder_geometry_f16(current_stream_ptr(dev), valid_ratios.data_ptr(), mask_flat.data_ptr(), B, L, hw,
+                                            ref.data_ptr(), ref_lvl.data_ptr(), prop.data_ptr(), state.data_ptr())
+    check(rc, "codetr_encoder_geometry_f16")
+    return ref, ref_lvl, prop, state
+
+
+def row_max(x2d):
+    CALLS["row_max"] += 1
+    rows, C = x2d.shape
+    out = torch.empty((rows,), dtype=x2d.dtype, device=x2d.device)
+    rc = load().codetr_row_max_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), out.data_ptr(), rows, C)
+    check(rc, "codetr_row_max_f16")
+    return out
 
 
 def mask_pyramid(img_masks, shapes):

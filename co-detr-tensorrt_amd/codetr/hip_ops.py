@@ -19,7 +19,9 @@ from . import _cabi
 NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_window_attention(f16, head_dim 32)",
           "msda_fused(softmax + sampling locations in-kernel)", "groupnorm_tokens(f16, 8 ch/group)",
           "sine_pos_tokens(f16, + level_embed)", "ffn_fused(f16, 256 -> hidden -> 256, ReLU, + identity)",
-          "mask_pyramid(level masks + running valid counts + valid ratios)"}
+          "mask_pyramid(level masks + running valid counts + valid ratios)",
+          "query_sine_embed(f16: sigmoid x valid ratios + sine embedding of the decoder reference boxes)",
+          "encoder_geometry(f16: reference points, proposals, keep/drop state)", "row_max(f16)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -178,6 +180,39 @@ def groupnorm_tokens_into(x, gamma, beta, groups, eps, dest, row_start):
     with torch.cuda.device(x.device):
         _cabi.groupnorm_tokens(x, gamma, beta, groups, eps, dest[0, row_start:], dest.shape[1] * C)
     return dest
+
+
+def query_sine_embed_supported(ref, valid_ratios, pos_feat):
+    return (ref.is_cuda and ref.dtype == torch.float16 and valid_ratios.dtype == torch.float16
+            and ref.shape[-1] in (2, 4) and pos_feat % 8 == 0 and valid_ratios.shape[1] <= ref.shape[-1] * pos_feat // 8)
+
+
+def query_sine_embed(ref, valid_ratios, pos_feat, temperature=10000.0):
+    """Decoder layer head in one launch: (sigmoid(ref)[:, :, None] * valid_ratios (tiled to ref_dim)[:, None],
+    gen_sineembed_for_position of its level-0 row) -- see include/codetr_hip.h."""
+    _gpu(ref, "query_sine_embed")
+    with torch.cuda.device(ref.device):
+        return _cabi.query_sine_embed(ref.contiguous(), valid_ratios.contiguous(), pos_feat, temperature)
+
+
+def encoder_geometry(valid_ratios, mask_flat, shapes):
+    """Reference points, their per-level scaling, two-stage proposals (already masked) and the keep / drop state of
+    every encoder token in one launch (csrc/encoder_geometry.hip); f16 valid_ratios [B,L,2], mask_flat [B,S] bool."""
+    _gpu(mask_flat, "encoder_geometry")
+    if valid_ratios.dtype != torch.float16:
+        raise RuntimeError("encoder_geometry is the f16 inference path; fp32 parity runs use the ATen formulation")
+    with torch.cuda.device(mask_flat.device):
+        return _cabi.encoder_geometry(valid_ratios.contiguous(), mask_flat.contiguous(),
+                                      [tuple(int(v) for v in s) for s in shapes])
+
+
+def row_max(x):
+    """x.max(-1)[0] for a dense f16 tensor (NaN propagates)"""
+    _gpu(x, "row_max")
+    if x.dtype != torch.float16 or not x.is_contiguous():
+        return x.max(-1)[0]
+    with torch.cuda.device(x.device):
+        return _cabi.row_max(x.view(-1, x.shape[-1])).view(x.shape[:-1])
 
 
 def mask_pyramid(img_masks, shapes):

@@ -61,15 +61,18 @@ def build_MLP(input_dim, hidden_dim, output_dim, num_layers):
     return nn.Sequential(*layers)
 
 
-def run_mlp(seq, x):
-    """nn.Sequential of Linear/ReLU through hip_ops (ReLU fused into the producing linear)."""
+def run_mlp(seq, x, residual=None):
+    """nn.Sequential of Linear/ReLU through hip_ops (ReLU fused into the producing linear); `residual` is added to the
+    last Linear's (rounded) output in its epilogue: `seq(x) + residual`."""
     mods = list(seq)
     i = 0
     while i < len(mods):
         lin = mods[i]
         fused = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-        x = hip_ops.linear(x, lin.weight, lin.bias, act="relu" if fused else None)
-        i += 2 if fused else 1
+        nxt = i + (2 if fused else 1)
+        x = hip_ops.linear(x, lin.weight, lin.bias, act="relu" if fused else None,
+                           residual=residual if nxt >= len(mods) else None)
+        i = nxt
     return x
 
 
@@ -113,14 +116,18 @@ class DinoTransformerDecoder(nn.Module):
         out = query
         vr = torch.cat((valid_ratios, valid_ratios), -1) if reference_points.shape[-1] == 4 else valid_ratios
         for lid, layer in enumerate(self.layers):
-            ref_in = reference_points[:, :, None].sigmoid() * vr[:, None]  # [B,Nq,L,4]
-            qpos = run_mlp(self.ref_point_head, self.gen_sineembed_for_position(ref_in[:, :, 0, :], self.embed_dims // 2))
+            if hip_ops.query_sine_embed_supported(reference_points, valid_ratios, self.embed_dims // 2):
+                ref_in, sine = hip_ops.query_sine_embed(reference_points, valid_ratios, self.embed_dims // 2)
+            else:
+                ref_in = reference_points[:, :, None].sigmoid() * vr[:, None]  # [B,Nq,L,4]
+                sine = self.gen_sineembed_for_position(ref_in[:, :, 0, :], self.embed_dims // 2)
+            qpos = run_mlp(self.ref_point_head, sine)
             out = layer.forward_bf(out, None, value, query_pos=qpos, key_padding_mask=key_padding_mask,
                                    reference_points=ref_in, **kw)
             if reg_branches is not None:
                 if reference_points.shape[-1] != 4:
                     raise AssertionError("box refinement needs 4-d reference points")
-                reference_points = run_mlp(reg_branches[lid], out) + reference_points  # no detach / sigmoid
+                reference_points = run_mlp(reg_branches[lid], out, residual=reference_points)  # no detach / sigmoid
         out = hip_ops.layer_norm(out, self.norm.weight, self.norm.bias, self.norm.eps)
         return out, reference_points
 
@@ -322,26 +329,42 @@ class CoDinoTransformer(nn.Module):
             valid_ratios = valid_counts.to(feat.dtype) / _level_wh(shapes, feat.dtype, dev)  # [B,L,2]
         else:
             valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
-        reference_points = get_reference_points([tuple(s) for s in shapes], valid_ratios, device=dev)  # [B,S,2]
-        ref_by_level = reference_points[:, :, None] * valid_ratios[:, None]  # [B,S,L,2]
+        native_geom = feat.is_cuda and feat.dtype == torch.float16 and mask.dtype == torch.bool
+        if native_geom:
+            # reference points, per-level scaling, masked proposals and the keep / drop state of every token: one launch
+            reference_points, ref_by_level, proposals, row_state = hip_ops.encoder_geometry(valid_ratios, mask, shapes)
+        else:
+            reference_points = get_reference_points([tuple(s) for s in shapes], valid_ratios, device=dev)  # [B,S,2]
+            ref_by_level = reference_points[:, :, None] * valid_ratios[:, None]  # [B,S,L,2]
 
         memory = self.encoder.forward_bf(feat, pos, mask, reference_points=ref_by_level, spatial_shapes=spatial_shapes,
                                          level_start_index=level_start_index)
         B = memory.shape[0]
-        proposals = make_encoder_output_proposals_export(reference_points, mlvl_masks)
-        proposals, out_mem = apply_mask_to_proposal_and_memory(proposals, memory, mask)
-        out_mem = hip_ops.linear(out_mem, self.enc_output.weight, self.enc_output.bias)
+        if native_geom:
+            # `memory * keep` rides on the GEMM: dropped rows (state 2) read as zero input rows -> bias
+            out_mem = hip_ops.linear(memory, self.enc_output.weight, self.enc_output.bias, row_mask=row_state)
+        else:
+            proposals = make_encoder_output_proposals_export(reference_points, mlvl_masks)
+            proposals, out_mem = apply_mask_to_proposal_and_memory(proposals, memory, mask)
+            out_mem = hip_ops.linear(out_mem, self.enc_output.weight, self.enc_output.bias)
         out_mem = hip_ops.layer_norm(out_mem, self.enc_output_norm.weight, self.enc_output_norm.bias,
                                      self.enc_output_norm.eps)
         last = self.decoder.num_layers  # branch index 6 = the two-stage proposal head
         cls_head = cls_branches[last]
         enc_cls = hip_ops.linear(out_mem, cls_head.weight, cls_head.bias)
-        enc_coord = run_mlp(reg_branches[last], out_mem) + proposals
         if forced_topk_indices is None:
-            topk = torch.topk(enc_cls.max(-1)[0], self.two_stage_num_proposals, dim=1)[1]
+            topk = torch.topk(hip_ops.row_max(enc_cls), self.two_stage_num_proposals, dim=1)[1]
         else:
             topk = forced_topk_indices
-        topk_coords = torch.gather(enc_coord, 1, topk.unsqueeze(-1).repeat(1, 1, 4))
+        gidx = topk.unsqueeze(-1)
+        if capture is None:
+            # the box branch is row-wise: run it on the selected rows only (900 instead of all S tokens)
+            sel = torch.gather(out_mem, 1, gidx.expand(-1, -1, out_mem.shape[-1]))
+            topk_coords = run_mlp(reg_branches[last], sel, residual=torch.gather(proposals, 1, gidx.expand(-1, -1, 4)))
+            enc_coord = None
+        else:
+            enc_coord = run_mlp(reg_branches[last], out_mem) + proposals
+            topk_coords = torch.gather(enc_coord, 1, gidx.repeat(1, 1, 4))
         query = self.query_embed.weight[None].expand(B, -1, -1)
         if capture is not None:
             capture.update(memory=memory, enc_outputs_class=enc_cls, enc_outputs_coord_unact=enc_coord,

@@ -95,7 +95,10 @@ class MultiheadAttention(nn.Module):
         if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
             key_pos = query_pos
         q = query + query_pos if query_pos is not None else query
-        k = key + key_pos if key_pos is not None else key
+        if key is query and key_pos is query_pos:
+            k = q  # self-attention: one add, and q | k projected by one GEMM below
+        else:
+            k = key + key_pos if key_pos is not None else key
         C = self.embed_dims
         W, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         if q is k:

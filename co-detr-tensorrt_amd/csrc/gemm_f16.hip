@@ -320,7 +320,21 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
       const int m = m0 + wm * 64 + ml;
       if (m < M && n < N) {
         s16x8 v = *reinterpret_cast<const s16x8*>(stage + ml * kPitch + schunk * 16);
-        if (row_mask && row_mask[m]) v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};  // masked_fill(mask[..., None], 0) on the linear's output
+        if (row_mask) {
+          const unsigned char mk = row_mask[m];
+          if (mk == 2) {
+            // the INPUT row counts as zeros (`memory * keep` ahead of enc_output): y = act(bias)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = HAS_BIAS ? T::to_f32(bias[n + e]) : 0.f;
+              if (ACT == 1) x = x < 0.f ? 0.f : x;
+              if (ACT == 2) x = gelu_erf(x);
+              v[e] = (short)T::from_f32(x);
+            }
+          } else if (mk) {
+            v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};  // masked_fill(mask[..., None], 0) on the linear's output
+          }
+        }
         size_t off = (size_t)m * N + n;
         if (hm_hd > 0) {
           // head-major destination y[b][head][position][channel]: rows m = (b, position), columns n = (head, channel);
@@ -358,7 +372,15 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
           if (ACT == 1) v = v < 0.f ? 0.f : v;
           if (ACT == 2) v = gelu_erf(v);
           unsigned short h = T::from_f32(v);
-          if (row_mask && row_mask[m]) h = 0;
+          if (row_mask && row_mask[m]) {
+            h = 0;
+            if (row_mask[m] == 2) {
+              float x = HAS_BIAS ? T::to_f32(bias[n + r]) : 0.f;
+              if (ACT == 1) x = x < 0.f ? 0.f : x;
+              if (ACT == 2) x = gelu_erf(x);
+              h = T::from_f32(x);
+            }
+          }
           if (HAS_RES) h = T::from_f32(T::to_f32(h) + T::to_f32(R[off + r]));
           Y[off + r] = h;
         }
@@ -378,13 +400,15 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
 //   L2->LDS operand re-reads (3.35 GB at ~17 TB/s for the encoder FFN up-projection) + staging + stores -- not by
 //   exposed latency.  The lever that remains is a larger tile (fewer operand re-reads); see DESIGN.md section 4.
 // CODETR_GEMM_CFG=<bk><stages> (322, 324, 642) overrides, for A/B measurements only.
-int pipeline_cfg(int64_t K) {
+//   Grids of at most one workgroup per CU (the decoder's 900-query layers: 16 tiles) gain nothing from occupancy;
+//     their time is the chain of per-K-step DMA latencies, so they take the 64-deep step (half the steps) as well.
+int pipeline_cfg(int64_t K, int64_t tiles) {
   static const int forced = [] {
     const char* e = getenv("CODETR_GEMM_CFG");
     return e ? atoi(e) : 0;
   }();
   if (forced == 324 || forced == 322 || forced == 642) return forced;
-  return K <= 256 ? 322 : 642;
+  return (K <= 256 && tiles > 256) ? 322 : 642;
 }
 
 template <class T, int ACT, int BKT, int STAGES>
@@ -433,14 +457,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (n + r < N) v[r] += p[r];
     }
   }
-  const bool masked = row_mask && row_mask[m];
+  const unsigned char mk = row_mask ? row_mask[m] : 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (n + r >= N) break;
-    float x = v[r] + (bias ? T::to_f32(bias[n + r]) : 0.f);
+    float x = (mk == 2 ? 0.f : v[r]) + (bias ? T::to_f32(bias[n + r]) : 0.f);
     if (act == 1) x = x < 0.f ? 0.f : x;
     if (act == 2) x = gelu_erf(x);
-    unsigned short h = masked ? (unsigned short)0 : T::from_f32(x);
+    unsigned short h = (mk != 0 && mk != 2) ? (unsigned short)0 : T::from_f32(x);
     if (R) h = T::from_f32(T::to_f32(h) + T::to_f32(R[off + r]));
     Y[off + r] = h;
   }
@@ -487,7 +511,7 @@ int launch_splitk(hipStream_t st, const void* X, const void* W, const void* bias
 template <class T, int ACT>
 int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
                const void* mask, int M, int N, int K, int hm_rows, int hm_hd) {
-  switch (pipeline_cfg(K)) {
+  switch (pipeline_cfg(K, (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN))) {
     case 324: return launch_cfg<T, ACT, 32, 4>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
     case 322: return launch_cfg<T, ACT, 32, 2>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
     default: return launch_cfg<T, ACT, 64, 2>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);

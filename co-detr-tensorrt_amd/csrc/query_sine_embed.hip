@@ -1,0 +1,83 @@
+// Decoder query positions of one DINO decoder layer, one launch.
+//
+// Replaces the head of every DinoTransformerDecoder layer iteration (reference codetr/transformer.py:208-217:
+//   reference_points_input = reference_points[:, :, None].sigmoid()-space * cat([valid_ratios, valid_ratios], -1)[:, None]
+//   query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :], embed_dims // 2)
+// and gen_sineembed_for_position itself, codetr/transformer.py:157-190: arange / floor-div / pow for dim_t, then per
+// coordinate  * 2 pi, / dim_t, sin, cos, stack, flatten, and a final cat) -- 27 ATen launches of ~5 us each per
+// layer at 900 queries -- with
+//   ref_in[b, q, l, c]  = f16(f16(sigmoid(ref[b, q, c])) * valid_ratios[b, l, c & 1])           [B, Nq, L, ref_dim]
+//   embed[b, q, j*F + i] = sin | cos (ref_in[b, q, 0, order[j]] * 2 pi / T^(2 (i/2) / F)),  i even -> sin, odd -> cos
+//                          order = (y, x, w, h) = coordinate (1, 0, 2, 3)                       [B, Nq, ref_dim*F]
+// The trigonometry runs in fp32 on the fp16-rounded ref_in (the values the reference feeds it); one lane = 8 channels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codetr_hip.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void query_sine_embed_kernel(const _Float16* __restrict__ ref,
+                                                               const _Float16* __restrict__ valid_ratios,
+                                                               _Float16* __restrict__ ref_in, _Float16* __restrict__ embed,
+                                                               int64_t rows, int Nq, int ref_dim, int L, int F,
+                                                               float log2_temperature, int apply_sigmoid) {
+  const int chunks = ref_dim * F / 8;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * chunks) return;
+  const int c = (int)(i % chunks);
+  const int64_t row = i / chunks;  // b*Nq + q
+  const int b = (int)(row / Nq);
+  float s[4];
+  for (int k = 0; k < ref_dim; ++k) {
+    float v = (float)ref[row * ref_dim + k];
+    if (apply_sigmoid) v = (float)(_Float16)(1.0f / (1.0f + __expf(-v)));
+    s[k] = v;
+  }
+  const _Float16* vr = valid_ratios + (size_t)b * L * 2;
+  // level rows of ref_in: lanes c = 0..L-1 of this query write one level each
+  if (c < L)
+    for (int k = 0; k < ref_dim; ++k)
+      ref_in[(row * L + c) * ref_dim + k] = (_Float16)(s[k] * (float)vr[c * 2 + (k & 1)]);
+  const int j = (c * 8) / F;                          // coordinate block of this chunk
+  const int coord = j == 0 ? 1 : (j == 1 ? 0 : j);    // (y, x, w, h)
+  const float v0 = (float)(_Float16)(s[coord] * (float)vr[coord & 1]);  // ref_in[b, q, 0, coord]
+  const float e = v0 * 6.283185307179586f;
+  const int ch0 = c * 8 - j * F;
+  f16x8 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int f = (ch0 >> 1) + p;
+    const float a = e * __builtin_amdgcn_exp2f(-log2_temperature * (2.0f * (float)f / (float)F));
+    o[2 * p] = (_Float16)sinf(a);
+    o[2 * p + 1] = (_Float16)cosf(a);
+  }
+  *reinterpret_cast<f16x8*>(embed + row * (int64_t)(ref_dim * F) + c * 8) = o;
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_query_sine_embed_f16(void* stream, const void* ref_dev, const void* valid_ratios_dev, int64_t B, int64_t Nq,
+                                int ref_dim, int num_levels, int pos_feat, float temperature, int apply_sigmoid,
+                                void* ref_in_dev, void* embed_dev) {
+  if (!ref_dev || !valid_ratios_dev || !ref_in_dev || !embed_dev || B <= 0 || Nq <= 0 || num_levels <= 0 ||
+      temperature <= 0.f)
+    return CODETR_E_BADARG;
+  if ((ref_dim != 2 && ref_dim != 4) || pos_feat <= 0 || pos_feat % 8 != 0 || num_levels > ref_dim * pos_feat / 8)
+    return CODETR_E_UNSUPPORTED;
+  if (B * Nq > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  const int64_t threads = B * Nq * (ref_dim * pos_feat / 8);
+  hipLaunchKernelGGL(query_sine_embed_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const _Float16*>(ref_dev),
+                     static_cast<const _Float16*>(valid_ratios_dev), static_cast<_Float16*>(ref_in_dev),
+                     static_cast<_Float16*>(embed_dev), B * Nq, (int)Nq, ref_dim, num_levels, pos_feat, log2f(temperature),
+                     apply_sigmoid);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // extern "C"

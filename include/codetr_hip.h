@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 14
+#define CODETR_HIP_ABI_VERSION 16
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -134,9 +134,11 @@ const char *codetr_msda_variant(int elem_bytes, int M, int D, int L, int P);
  *   w_dev        [N, K]  row-major (nn.Linear.weight) T
  *   bias_dev     [N] or NULL                          T
  *   residual_dev [M, N] or NULL (added AFTER the activation, as `identity + ffn(x)` does)   T
- *   row_mask_dev [M] uint8/bool or NULL: rows with a non-zero mask are written as zeros (before the
- *                residual) -- `value.masked_fill(key_padding_mask[..., None], 0.0)` of
- *                codetr/multi_scale_deformable_attention.py:174-175 folded into value_proj
+ *   row_mask_dev [M] uint8/bool or NULL: rows with mask value 1 (any non-zero value but 2) are written as
+ *                zeros (before the residual) -- `value.masked_fill(key_padding_mask[..., None], 0.0)` of
+ *                codetr/multi_scale_deformable_attention.py:174-175 folded into value_proj.  Mask value 2: the
+ *                INPUT row counts as zeros, y = act(bias) -- `memory * keep` of apply_mask_to_proposal_and_memory
+ *                (codetr/transformer.py:365-380) folded into enc_output
  *   y_dev        [M, N]  (may alias residual_dev)     T
  *   act          0 = none, 1 = ReLU, 2 = GELU (erf form, nn.GELU default)
  *   hm_rows, hm_head_dim   0, 0: y is row-major [M, N].  Otherwise the rows are (batch, position) with
@@ -192,6 +194,51 @@ int codetr_linear_splitk_bf16(void *stream, const void *x_dev, const void *w_dev
 int codetr_mask_pyramid(void *stream, const void *img_mask_dev, int64_t B, int64_t H_img, int64_t W_img,
                         int num_levels, const int64_t *level_shapes_host, void *mask_flat_dev, float *ycum_dev,
                         float *xcum_dev, float *valid_counts_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder query positions: sigmoid + valid-ratio scaling of the reference boxes and their sine embedding.
+ *
+ * Replaces the head of each DinoTransformerDecoder layer iteration, codetr/transformer.py:208-217
+ * (reference_points_input = reference_points[:, :, None].sigmoid() * cat([valid_ratios, valid_ratios], -1)[:, None];
+ * query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :], embed_dims // 2)) and
+ * gen_sineembed_for_position, codetr/transformer.py:157-190 -- 27 ATen launches per layer.
+ *
+ *   ref_dev           [B, Nq, ref_dim] f16, ref_dim 2 or 4: reference points, unactivated (apply_sigmoid = 1)
+ *                     or already in [0, 1] (apply_sigmoid = 0)
+ *   valid_ratios_dev  [B, num_levels, 2] f16 (w, h)
+ *   ref_in_dev        out [B, Nq, num_levels, ref_dim] f16: the MSDA reference points of the layer
+ *   embed_dev         out [B, Nq, ref_dim * pos_feat] f16: blocks ordered (y, x[, w, h]); within a block channel
+ *                     2k = sin, 2k+1 = cos of  v * 2 pi / temperature^(2k / pos_feat),  v = ref_in[b, q, 0, coord]
+ * fp32 trigonometry on the f16-rounded ref_in; pos_feat % 8 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_query_sine_embed_f16(void *stream, const void *ref_dev, const void *valid_ratios_dev, int64_t B,
+                                int64_t Nq, int ref_dim, int num_levels, int pos_feat, float temperature,
+                                int apply_sigmoid, void *ref_in_dev, void *embed_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Token geometry of the deformable encoder / two-stage proposal head, one launch (f16 path).
+ *
+ * Replaces get_reference_points (codetr/transformer.py:280-305), reference_points[:, :, None] * valid_ratios[:, None]
+ * (:530), make_encoder_output_proposals_export (:331-339) and the proposal half of
+ * apply_mask_to_proposal_and_memory (:351-380); its memory half (`memory * total_mask`) is expressed as row
+ * state 2 for codetr_linear_*'s row mask on enc_output.
+ *
+ *   valid_ratios_dev        [B, L, 2] f16 (w, h)
+ *   mask_flat_dev           [B, S] uint8, non-zero = padding (codetr_mask_pyramid's output)
+ *   level_shapes_host       HOST array of 2*L int64 (H_l, W_l)
+ *   reference_points_dev    out [B, S, 2] f16 (x, y), the reference's own fp16 roundings
+ *   reference_by_level_dev  out [B, S, L, 2] f16
+ *   proposals_dev           out [B, S, 4] f16: logit of (x, y, 0.05*2^l, 0.05*2^l) where the token is kept,
+ *                           finfo(f16).max (NaN where the logit is not finite) where it is dropped
+ *   row_state_dev           out [B, S] uint8: 0 = kept, 2 = dropped (padding, or a logit outside (-4.6, 4.6))
+ * ------------------------------------------------------------------------------------------ */
+int codetr_encoder_geometry_f16(void *stream, const void *valid_ratios_dev, const void *mask_flat_dev, int64_t B,
+                                int num_levels, const int64_t *level_shapes_host, void *reference_points_dev,
+                                void *reference_by_level_dev, void *proposals_dev, void *row_state_dev);
+
+/* out[r] = max_c x[r, c] (NaN propagates, as torch.max): enc_outputs_class.max(-1)[0], the ranking score of
+ * the two-stage top-k (codetr/transformer.py:563).  x [rows, C] f16 dense, out [rows] f16. */
+int codetr_row_max_f16(void *stream, const void *x_dev, void *out_dev, int64_t rows, int64_t C);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension: y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta
