@@ -15,7 +15,12 @@
 //     Y^T[n][m] += W2c . relu(H)^T  (K = 64);
 //   * W1 / W2 chunks (32 KiB each) stream through a 2-stage LDS ring by LDS-DMA, XOR-swizzled on the source address
 //     so that the ds_read_b128 fragment reads are conflict-free; one barrier per chunk (128 MFMAs per wave);
-//     with one wave per SIMD nothing else hides LDS latency: fragments are read one step ahead of their MFMAs;
+//     with one wave per SIMD nothing else hides latency or issue cost, so the schedule is spelled out: fragments are
+//     read one step ahead of their MFMAs (behind the first two MFMAs of a group, so the wait in front of the group
+//     is for reads that landed long ago), and the 16 LDS-DMA pieces of the next chunk go out one per MFMA group
+//     instead of as a burst at the top of the chunk (~100 issue cycles per piece with the SIMD otherwise idle);
+//     ablation at M = 204 600: no DMA -13 %, no barrier -5 %; b1 sits in LDS so that no other vector-memory op
+//     (and no s_waitcnt vmcnt) lands between the DMA pieces;
 //   * the epilogue adds the residual X and streams whole rows out through LDS, like the linear kernel.
 // Algorithmic HBM traffic: X once in, Y once out (2 x M x 256 x 2 B) + 2 MB of weights re-read from L2 per workgroup.
 #include <hip/hip_runtime.h>
@@ -26,13 +31,13 @@
 namespace {
 
 constexpr int C = 256;         // model width (K of the first product, N of the second)
-constexpr int BM = 128;        // rows per workgroup
 constexpr int BH = 64;         // hidden units per chunk
 constexpr int kThreads = 256;
 constexpr int kW1Bytes = BH * C * 2;   // 32 KiB: [64 h][256 k]
 constexpr int kW2Bytes = C * BH * 2;   // 32 KiB: [256 n][64 h]
 constexpr int kStageBytes = kW1Bytes + kW2Bytes;
 constexpr int kOutPitch = C * 2 + 16;  // staged output row: 512 B + 16
+constexpr int kMaxHidden = 8192;       // b1 lives in LDS behind the two stages (16 KiB)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -45,24 +50,24 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// stage chunk `c` (hidden units c*64 .. c*64+63) of W1 [Hd, 256] and W2 [256, Hd] into one LDS stage
-__device__ __forceinline__ void stage_chunk(const unsigned short* __restrict__ W1, const unsigned short* __restrict__ W2,
+// One LDS-DMA piece (256 threads x 16 B = 4 KiB) of chunk `c` (hidden units c*64 .. c*64+63) of W1 [Hd, 256] and
+// W2 [256, Hd]: pieces 0..7 fill the W1 image, 8..15 the W2 image of one LDS stage.
+template <int PIECE>
+__device__ __forceinline__ void stage_piece(const unsigned short* __restrict__ W1, const unsigned short* __restrict__ W2,
                                             int Hd, int c, unsigned char* stage, int tid) {
   const int wave = tid >> 6;
-  // W1 chunk: 64 rows x 32 chunks of 16 B; LDS position p of row r holds source chunk p ^ (r & 15) (low 4 bits)
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int u = q * kThreads + tid;
+  if constexpr (PIECE < 8) {
+    // W1 chunk: 64 rows x 32 chunks of 16 B; LDS position p of row r holds source chunk p ^ (r & 15) (low 4 bits)
+    const int u = PIECE * kThreads + tid;
     const int r = u >> 5, pos = u & 31;
     const int chunk = pos ^ (r & 15);
     const unsigned short* g = W1 + (size_t)(c * BH + r) * C + chunk * 8;
-    unsigned char* l = stage + (q * kThreads + wave * 64) * 16;
+    unsigned char* l = stage + (PIECE * kThreads + wave * 64) * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-  }
-  // W2 chunk: 256 rows (n) x 8 chunks of 16 B (64 hidden units); position p of row n holds chunk p ^ ((n >> 1) & 7)
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  } else {
+    // W2 chunk: 256 rows (n) x 8 chunks of 16 B (64 hidden units); position p of row n holds chunk p ^ ((n >> 1) & 7)
+    constexpr int q = PIECE - 8;
     const int u = q * kThreads + tid;
     const int n = u >> 3, pos = u & 7;
     const int chunk = pos ^ ((n >> 1) & 7);
@@ -73,22 +78,52 @@ __device__ __forceinline__ void stage_chunk(const unsigned short* __restrict__ W
   }
 }
 
+template <int... P>
+__device__ __forceinline__ void stage_pieces(const unsigned short* __restrict__ W1, const unsigned short* __restrict__ W2,
+                                             int Hd, int c, unsigned char* stage, int tid) {
+  (stage_piece<P>(W1, W2, Hd, c, stage, tid), ...);
+}
+
+__device__ __forceinline__ void stage_chunk(const unsigned short* __restrict__ W1, const unsigned short* __restrict__ W2,
+                                            int Hd, int c, unsigned char* stage, int tid) {
+  stage_pieces<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(W1, W2, Hd, c, stage, tid);
+}
+
+// piece number as a loop variable of an unrolled loop
+template <int N>
+struct PieceSwitch {
+  static __device__ __forceinline__ void run(int piece, const unsigned short* __restrict__ W1,
+                                             const unsigned short* __restrict__ W2, int Hd, int c, unsigned char* stage,
+                                             int tid) {
+    if (piece == N) stage_piece<N>(W1, W2, Hd, c, stage, tid);
+    else PieceSwitch<N - 1>::run(piece, W1, W2, Hd, c, stage, tid);
+  }
+};
+template <>
+struct PieceSwitch<-1> {
+  static __device__ __forceinline__ void run(int, const unsigned short*, const unsigned short*, int, int, unsigned char*,
+                                             int) {}
+};
+
+// MT = 16-row tiles per wave (rows per workgroup = 64 * MT)
+template <int MT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
     int Hd) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes];  // 128 KiB, one object
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2];  // 144 KiB, one object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
-  const int m0 = (int)xcd_tile(blockIdx.x, gridDim.x) * BM + wave * 32;  // this wave's first row
+  constexpr int BM = 64 * MT, WR = 16 * MT;  // rows per workgroup / per wave
+  const int m0 = (int)xcd_tile(blockIdx.x, gridDim.x) * BM + wave * WR;  // this wave's first row
   const int nchunks = Hd / BH;
 
   stage_chunk(W1, W2, Hd, 0, lds, tid);
 
   // X fragments of this wave's 32 rows (B operand: lane (j = l15, g) holds X[m][32*ks + 8g .. +7]), kept for good
-  f16x8 xf[2][8];
+  f16x8 xf[MT][8];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     int m = m0 + mt * 16 + l15;
     m = m < M ? m : M - 1;
 #pragma unroll
@@ -96,38 +131,42 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       xf[mt][ks] = *reinterpret_cast<const f16x8*>(X + (size_t)m * C + ks * 32 + grp * 8);
   }
   // Y accumulators start at b2 (lane's 4 consecutive n of tile nt: n = 16*nt + 4*grp + r)
-  f32x4 yacc[16][2];
+  f32x4 yacc[16][MT];
 #pragma unroll
   for (int nt = 0; nt < 16; ++nt) {
     const f16x4 bb = *reinterpret_cast<const f16x4*>(b2 + nt * 16 + grp * 4);
     const f32x4 b4 = {(float)bb[0], (float)bb[1], (float)bb[2], (float)bb[3]};
-    yacc[nt][0] = b4;
-    yacc[nt][1] = b4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) yacc[nt][mt] = b4;
   }
 
-  // bias of a chunk's hidden units for this lane (4 consecutive h per 16-row tile); loaded one chunk ahead
-  f16x4 b1v[4], b1n[4];
-#pragma unroll
-  for (int ht = 0; ht < 4; ++ht) b1v[ht] = *reinterpret_cast<const f16x4*>(b1 + ht * 16 + grp * 4);
+  // b1 goes to LDS once (read per chunk by ds_read_b64: no vector-memory op in the main loop but the LDS-DMA pieces,
+  // so no s_waitcnt vmcnt lands between them)
+  unsigned short* sB1 = reinterpret_cast<unsigned short*>(lds + 2 * kStageBytes);
+  for (int i = tid; i < Hd / 8; i += kThreads)
+    *reinterpret_cast<s16x8*>(sB1 + i * 8) = *reinterpret_cast<const s16x8*>(b1 + i * 8);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // ... written before the first barrier below
 
   for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c landed (and the bias / X loads issued earlier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c landed (and the X loads issued earlier)
     __builtin_amdgcn_s_barrier();                      // ... for everyone; everyone is done with chunk c-1's stage
-    if (c + 1 < nchunks) {
-      stage_chunk(W1, W2, Hd, c + 1, lds + ((c + 1) & 1) * kStageBytes, tid);
-#pragma unroll
-      for (int ht = 0; ht < 4; ++ht) b1n[ht] = *reinterpret_cast<const f16x4*>(b1 + (c + 1) * BH + ht * 16 + grp * 4);
-    }
+    // the next chunk's 16 LDS-DMA pieces are issued one per MFMA group below (a burst here costs the wave ~100 issue
+    // cycles per piece with nothing else to run on its SIMD); past the last chunk they re-fetch it (no branch in the
+    // pinned schedule), which the s_waitcnt before the epilogue barrier drains
+    const int cn = c + 1 < nchunks ? c + 1 : c;
+    unsigned char* next_stage = lds + ((c + 1) & 1) * kStageBytes;
     const unsigned char* sW1 = lds + (c & 1) * kStageBytes;
     const unsigned char* sW2 = sW1 + kW1Bytes;
 
     // ---- H^T = W1c . X^T : D[i = h][j = m] ----
-    f32x4 hacc[4][2];
+    f32x4 hacc[4][MT];
 #pragma unroll
     for (int ht = 0; ht < 4; ++ht) {
-      const f32x4 b4 = {(float)b1v[ht][0], (float)b1v[ht][1], (float)b1v[ht][2], (float)b1v[ht][3]};
-      hacc[ht][0] = b4;
-      hacc[ht][1] = b4;
+      // bias of this lane's 4 consecutive hidden units of tile ht
+      const f16x4 bv = *reinterpret_cast<const f16x4*>(sB1 + c * BH + ht * 16 + grp * 4);
+      const f32x4 b4 = {(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = b4;
     }
     // one wave per SIMD: nobody else hides LDS latency, so the A fragments of k-step ks+1 are read while the
     // MFMAs of k-step ks issue (explicit register double buffering)
@@ -141,31 +180,47 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     };
     f16x8 aw[2][4];
     read_w1(0, aw[0]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // pin the schedule: 4 LDS reads of step ks+1, then the 8
-#pragma unroll                                          // MFMAs of step ks (hipcc otherwise serialises read->wait->2 MFMA)
-    for (int ks = 0; ks < 8; ++ks) {
-      if (ks + 1 < 8) read_w1(ks + 1, aw[(ks + 1) & 1]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int ht = 0; ht < 4; ++ht) {
-        hacc[ht][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks & 1][ht], xf[0][ks], hacc[ht][0], 0, 0, 0);
-        hacc[ht][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks & 1][ht], xf[1][ks], hacc[ht][1], 0, 0, 0);
+    for (int ks = 0; ks < 8; ++ks) {
+      // group ks: 2 MFMAs, then the 4 reads of step ks+1 (the reads of step ks, issued a group earlier, have landed
+      // by the time hipcc's s_waitcnt in front of the first MFMA runs), one LDS-DMA piece of the next chunk, then the
+      // other 4*MT-2 MFMAs.  The DMA instruction ends a scheduling region, so the order is spelled out in source and
+      // the pins only keep the reads behind the first two MFMAs.
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        hacc[i / MT][i % MT] =
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT], 0, 0, 0);
+      if (ks + 1 < 8) {
+        read_w1(ks + 1, aw[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       }
-      if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      PieceSwitch<7>::run(ks, W1, W2, Hd, cn, next_stage, tid);
+#pragma unroll
+      for (int i = 2; i < 4 * MT; ++i)
+        hacc[i / MT][i % MT] =
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT], 0, 0, 0);
     }
     // ---- ReLU + pack: B operand of the second product, k-slot 8g+j = rows 4g..4g+3 of tiles 2s and 2s+1 ----
-    f16x8 pf[2][2];
+    f16x8 pf[2][MT];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = hacc[2 * s + h][mt][r];
-            pf[s][mt][h * 4 + r] = (_Float16)(v < 0.f ? 0.f : v);
-          }
+          for (int r = 0; r < 4; ++r) pf[s][mt][h * 4 + r] = (_Float16)hacc[2 * s + h][mt][r];
+    // ReLU on the packed halves (v_pk_max_f16: one op per two values).  max(NaN, 0) = 0 drops a NaN of the hidden
+    // unit, but a NaN there can only come from a NaN / inf in this row of X, which the residual add puts back.
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        pf[s][mt] = __builtin_elementwise_max(pf[s][mt], z);
+      }
     // ---- Y^T += W2c . relu(H)^T : D[i = n][j = m], k = hidden unit (permuted identically on both operands) ----
     // W2 fragments (pre-packed: the 8 k-slots of lane group g are 16 contiguous bytes) are read two n-tiles
     // ahead of their MFMAs, same double buffering
@@ -185,37 +240,42 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
     for (int ntp = 0; ntp < 8; ++ntp) {
-      if (ntp + 1 < 8) read_w2(ntp + 1, a2[(ntp + 1) & 1]);
+      // same group shape: MFMA index i -> (t, s, mt)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int i = 0; i < 2; ++i) {
+        const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / 2;
+        yacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt], 0, 0, 0);
+      }
+      if (ntp + 1 < 8) {
+        read_w2(ntp + 1, a2[(ntp + 1) & 1]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      }
+      PieceSwitch<15>::run(8 + ntp, W1, W2, Hd, cn, next_stage, tid);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int nt = 2 * ntp + t;
-          yacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ntp & 1][t * 2 + s], pf[s][0], yacc[nt][0], 0, 0, 0);
-          yacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ntp & 1][t * 2 + s], pf[s][1], yacc[nt][1], 0, 0, 0);
-        }
-      if (ntp + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      for (int i = 2; i < 4 * MT; ++i) {
+        const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / 2;
+        yacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt], 0, 0, 0);
+      }
     }
-#pragma unroll
-    for (int ht = 0; ht < 4; ++ht) b1v[ht] = b1n[ht];
   }
-  __builtin_amdgcn_s_barrier();  // every wave is done with the last stage: LDS is free
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant DMA of the last iteration has landed
+  __builtin_amdgcn_s_barrier();                      // every wave is done with the last stage: LDS is free
 
   // ---- epilogue: Y tile of this wave (32 rows x 256) through LDS, + residual X, whole 512-byte rows out ----
-  unsigned char* stage = lds + wave * (32 * kOutPitch);
+  unsigned char* stage = lds + wave * (WR * kOutPitch);
 #pragma unroll
   for (int nt = 0; nt < 16; ++nt)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       const f16x4 o = {(_Float16)yacc[nt][mt][0], (_Float16)yacc[nt][mt][1], (_Float16)yacc[nt][mt][2],
                        (_Float16)yacc[nt][mt][3]};
       *reinterpret_cast<f16x4*>(stage + (mt * 16 + l15) * kOutPitch + (nt * 16 + grp * 4) * 2) = o;
     }
   __builtin_amdgcn_wave_barrier();
-  // 32 rows x 32 chunks of 16 B: lane -> (row = it*2 + lane/32, chunk = lane%32)
+  // WR rows x 32 chunks of 16 B: lane -> (row = it*2 + lane/32, chunk = lane%32)
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < WR / 2; ++it) {
     const int row = it * 2 + (lane >> 5), chunk = lane & 31;
     const int m = m0 + row;
     if (m < M) {
@@ -259,10 +319,13 @@ int codetr_ffn_relu_f16(void* stream, const void* x_dev, const void* w1_dev, con
                         int64_t hidden) {
   const void* w2_dev = w2_packed_dev;
   if (!x_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !y_dev || M <= 0 || hidden <= 0) return CODETR_E_BADARG;
-  if (C_in != C || hidden % BH != 0) return CODETR_E_UNSUPPORTED;
-  if (M > 0x7fffffffLL - BM || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  const unsigned blocks = (unsigned)((M + BM - 1) / BM);
-  hipLaunchKernelGGL(ffn_fused_kernel, dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+  if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
+  if (M > 0x7fffffffLL - 256 || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  // MT = 2 (128 rows per workgroup).  MT = 3 fits the register file only without the interleaved DMA issue (236 VGPR
+  // + 240 AGPR, 570 us at M = 204 600 against 545 us for this variant); with it hipcc spills (1147 us).
+  constexpr int kMT = 2;
+  const unsigned blocks = (unsigned)((M + 64 * kMT - 1) / (64 * kMT));
+  hipLaunchKernelGGL(ffn_fused_kernel<kMT>, dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      static_cast<const unsigned short*>(x_dev), static_cast<const unsigned short*>(w1_dev),
                      static_cast<const unsigned short*>(b1_dev), static_cast<const unsigned short*>(w2_dev),
                      static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
