@@ -134,6 +134,26 @@ __device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ sr
   }
 }
 
+// Per-thread source pointer (at k = 0) of LDS-DMA piece q of an operand tile: the same addressing as stage_tile,
+// computed once per kernel so that a piece inside the K loop is one pointer add and the DMA instruction.
+template <int BKT>
+__device__ __forceinline__ const unsigned short* piece_src(const unsigned short* __restrict__ src, int rows_total, int K,
+                                                           int row0, int q, int tid) {
+  constexpr int CH = BKT / 8;
+  const int u = q * kThreads + tid;
+  const int r = u / CH, pos = u % CH;
+  const int chunk = pos ^ sw<BKT>(r);
+  int grow = row0 + r;
+  grow = grow < rows_total ? grow : rows_total - 1;
+  return src + (size_t)grow * K + chunk * 8;
+}
+
+__device__ __forceinline__ void dma_piece(const unsigned short* g, unsigned char* lds_tile, int q, int wave) {
+  unsigned char* l = lds_tile + (q * kThreads + wave * 64) * 16;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 template <class T, int BKT>
 __device__ __forceinline__ typename T::frag read_frag(const unsigned char* lds_tile, int row, int chunk) {
   const int pos = chunk ^ sw<BKT>(row);
@@ -158,7 +178,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // s_waitcnt vmcnt: a __syncthreads() would drain the DMA queue, cdna_hip_programming.md section 5).
 // SPLITK: blockIdx.y picks a range of `kps` K tiles; the block's fp32 partial tile goes to Y viewed as
 // float[gridDim.y][M][N] (no bias / activation / residual: splitk_reduce_kernel applies them to the sum).
-template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, int BKT, int STAGES, bool SPLITK = false>
+template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, int BKT, int STAGES, bool SPLITK = false, bool SPREAD = false>
 __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* __restrict__ X,
                                                           const unsigned short* __restrict__ W,
                                                           const unsigned short* __restrict__ bias,
@@ -211,6 +231,86 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
 
   const int kt0 = SPLITK ? (int)blockIdx.y * kps : 0;
   const int nk = SPLITK ? (K / BKT - kt0 < kps ? K / BKT - kt0 : kps) : K / BKT;
+  const int frow = lane & 15, fchunk = lane >> 4;
+  constexpr int KS = BKT / 32;
+  if constexpr (STAGES == 2 && SPREAD) {
+    // ---- 2-buffer pipeline with the DMA of tile t+1 spread over the MFMAs of tile t ----------------------------
+    // Measured variant, NOT the default: instead of a burst of LPS LDS-DMA instructions behind the barrier, one piece
+    // per pair of MFMAs.  It is what makes the one-wave-per-SIMD FFN kernel fast (ffn_fused.hip), but here, with 2-3
+    // waves per SIMD to cover the issue cost, the same-box A/B over the model's 22 shapes came out 2.10 ms vs 2.05 ms
+    // for the burst (better only on K >= 768 / N >= 768 shapes, worse on every K <= 384 one).
+    // Source pointers are per-thread constants (piece_src), advanced by one K tile per iteration.
+    constexpr int PT = BKT / 16;  // pieces per operand tile
+    const unsigned short* gw[PT];
+    const unsigned short* gx[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+      gw[q] = piece_src<BKT>(W, N, K, n0, q, tid) + (size_t)kt0 * BKT;
+      gx[q] = piece_src<BKT>(X, M, K, m0, q, tid) + (size_t)kt0 * BKT;
+    }
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+      dma_piece(gw[q], lds, q, wave);
+      dma_piece(gx[q], lds + kTileBytes, q, wave);
+    }
+    for (int t = 0; t < nk; ++t) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // everyone's part of tile t is in LDS; everyone is done reading tile t-1
+      const unsigned char* bufW = lds + (t & 1) * kStageBytes;
+      const unsigned char* bufX = bufW + kTileBytes;
+      unsigned char* nextW = lds + ((t + 1) & 1) * kStageBytes;
+      // past the last tile the pieces re-fetch it into the idle buffer (no branch inside the pinned schedule); the
+      // s_waitcnt in front of the epilogue barrier drains them
+      const size_t koff = (size_t)(t + 1 < nk ? t + 1 : t) * BKT;
+      typename T::frag a[2][4], b[2][4];
+      auto read_frags = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[buf][i] = read_frag<T, BKT>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[buf][j] = read_frag<T, BKT>(bufX, wm * 64 + j * 16 + frow, ks * 4 + fchunk);
+      };
+      read_frags(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) read_frags(ks + 1, (ks + 1) & 1);
+        if (ks == 0) {
+#pragma unroll
+          for (int piece = 0; piece < 2 * PT; ++piece) {
+            if (piece < PT) dma_piece(gw[piece] + koff, nextW, piece, wave);
+            else dma_piece(gx[piece - PT] + koff, nextW + kTileBytes, piece - PT, wave);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e >> 2][e & 3] = T::mfma(a[ks & 1][e >> 2], b[ks & 1][e & 3], acc[e >> 2][e & 3]);
+        // Pinned order.  The DMA pieces go out early in the tile, one per pair of MFMAs, so that the last of them has
+        // the rest of the tile's MFMAs to land before the next barrier:
+        //   BK 64: step 0 = 2 MFMAs, the 8 fragment reads of step 1, 7 x (2 MFMAs, 1 piece); step 1 = 2 MFMAs, 1 piece,
+        //          14 MFMAs.     BK 32: 4 x (2 MFMAs, 1 piece), 8 MFMAs.
+        if (KS == 2 && ks == 0) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+          for (int g = 0; g < 7; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        } else if (KS == 2) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+      }
+    }
+    wait_vmcnt<0>();  // the redundant pieces of the last iteration have landed
+  } else {
   auto issue = [&](int t) {
     unsigned char* buf = lds + (t % STAGES) * kStageBytes;
     stage_tile<BKT>(W, N, K, n0, (kt0 + t) * BKT, buf, tid);
@@ -220,7 +320,6 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
   for (int s0 = 0; s0 < STAGES - 1; ++s0)
     if (s0 < nk) issue(s0);
 
-  const int frow = lane & 15, fchunk = lane >> 4;
   for (int t = 0; t < nk; ++t) {
     // tiles issued beyond t: t+1 .. min(nk-1, t+STAGES-2); tile t itself must have landed
     const int ahead = (nk - 1 < t + STAGES - 2 ? nk - 1 : t + STAGES - 2) - t;
@@ -231,10 +330,6 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
     if (t + STAGES - 1 < nk) issue(t + STAGES - 1);  // overwrites the buffer of tile t-1
     const unsigned char* bufW = lds + (t % STAGES) * kStageBytes;
     const unsigned char* bufX = bufW + kTileBytes;
-    // Fragment reads of k-step ks+1 are issued before the MFMAs of k-step ks (register double buffering), and the
-    // order is pinned with sched_group_barrier: left alone, hipcc emits read -> s_waitcnt lgkmcnt(0) -> a few MFMAs
-    // groups, which exposes the LDS latency whenever the co-resident waves are in the same phase.
-    constexpr int KS = BKT / 32;
     typename T::frag a[2][4], b[2][4];
     auto read_frags = [&](int ks, int buf) {
 #pragma unroll
@@ -261,6 +356,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
       }
     }
+  }
   }
   __builtin_amdgcn_s_barrier();  // all fragment reads done (no DMA is in flight any more): LDS is free for the epilogue
 
@@ -408,10 +504,11 @@ int pipeline_cfg(int64_t K, int64_t tiles) {
     return e ? atoi(e) : 0;
   }();
   if (forced == 324 || forced == 322 || forced == 642) return forced;
-  return (K <= 256 && tiles > 256) ? 322 : 642;
+  const int cfg = (K <= 256 && tiles > 256) ? 322 : 642;
+  return forced == 1 ? 1000 + cfg : cfg;  // CODETR_GEMM_CFG=1: DMA pieces spread over the MFMAs (A/B only, see kernel)
 }
 
-template <class T, int ACT, int BKT, int STAGES>
+template <class T, int ACT, int BKT, int STAGES, bool SPREAD = false>
 int launch_cfg(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
                const void* mask, int M, int N, int K, int hm_rows, int hm_hd) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -422,10 +519,10 @@ int launch_cfg(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
-  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
-  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
-  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES, false, SPREAD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES, false, SPREAD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES, false, SPREAD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES, false, SPREAD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -514,6 +611,8 @@ int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, c
   switch (pipeline_cfg(K, (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN))) {
     case 324: return launch_cfg<T, ACT, 32, 4>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
     case 322: return launch_cfg<T, ACT, 32, 2>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
+    case 1322: return launch_cfg<T, ACT, 32, 2, true>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
+    case 1642: return launch_cfg<T, ACT, 64, 2, true>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
     default: return launch_cfg<T, ACT, 64, 2>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
   }
 }
