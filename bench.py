@@ -14,10 +14,12 @@ barrier + torch.cuda.synchronize() on both sides, MAX over ranks.  Rank 0 prints
 
 Extra objects on that line (N=1 only): ``roofline`` -- the dominant kernel of the forward, the hand-written
 MFMA linear, every launch of one forward timed live with HIP events on its launch stream and priced with
-2*M*N*K flops against the 2.5 PF dense fp16 MFMA peak; ``roofline_msda`` -- the MSDA gather kernel at the
-encoder shape of the same workload, priced with the algorithmic bytes of BASELINE.md section 3 against
-8 TB/s; ``cpu_baseline`` -- the fp32 CPU oracle
-(oracle/codetr_fp32.py + the C MSDA restatement) timed on the host cores on a bounded sample.
+2*M*N*K flops against the 2.5 PF dense fp16 MFMA peak; ``roofline_ffn`` -- the fused encoder FFN kernel, same
+peak; ``roofline_msda`` -- the fused MSDA gather kernel as the model launches it at the encoder shape, priced with
+the algorithmic bytes of BASELINE.md section 3 against 8 TB/s (``roofline_msda_op``: the same for the stand-alone
+operator ``torch.ops.codetr.multi_scale_deformable_attention`` on synthetic sampling locations); ``traffic`` in each
+= HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json); ``cpu_baseline`` -- the
+fp32 CPU oracle (oracle/codetr_fp32.py + the C MSDA restatement) timed on the host cores on a bounded sample.
 """
 import argparse
 import json
@@ -100,33 +102,78 @@ def msda_roofline(B, H, W, dtype, device, iters=30):
     }
 
 
-def linear_roofline(model, images, masks, device):
-    """The dominant kernel of the workload is the hand-written MFMA linear (`linear_kernel`, ~58 % of the GPU time
-    of a forward): one eager forward with every launch bracketed by HIP events on its launch stream.
-    achieved = sum of algorithmic flops (2*M*N*K per launch) / sum of launch durations."""
+def _pmc_traffic():
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
+    workload (profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py; reads corrected x2 as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"]
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+def kernel_rooflines(model, images, masks, device):
+    """One eager forward with every launch of the three heavy hand-written kernels bracketed by HIP events on its
+    launch stream (hip_ops.LINEAR_PROFILE / KERNEL_PROFILE):
+      roofline       linear_kernel, the dominant kernel (~40 % of the GPU time of a forward): sum of 2*M*N*K over its
+                     launches / sum of their durations, against the dense fp16 MFMA peak
+      roofline_ffn   ffn_fused_kernel (encoder FFN, 4*M*256*2048 flops per launch), same peak
+      roofline_msda  the fused MSDA gather kernel at the encoder shape (Nq = S), algorithmic bytes of BASELINE.md
+                     section 3 (value + offsets + logits + output, each once) against the 8 TB/s HBM peak."""
     from codetr import hip_ops
 
-    hip_ops.LINEAR_PROFILE = []
+    hip_ops.LINEAR_PROFILE, hip_ops.KERNEL_PROFILE = [], {}
     try:
         with torch.no_grad():
             model(images, masks)
         torch.cuda.synchronize(device)
-        prof = hip_ops.LINEAR_PROFILE
+        prof, kprof = hip_ops.LINEAR_PROFILE, hip_ops.KERNEL_PROFILE
     finally:
-        hip_ops.LINEAR_PROFILE = None
+        hip_ops.LINEAR_PROFILE = hip_ops.KERNEL_PROFILE = None
+    pmc = _pmc_traffic()
+    out = {}
     flops = sum(p[2] for p in prof)
     secs = sum(p[0].elapsed_time(p[1]) for p in prof) * 1e-3
     achieved = flops / secs / 1e12
     big = max(prof, key=lambda p: p[0].elapsed_time(p[1]))
-    return {
+    out["roofline"] = {
         "kernel": "linear_kernel<f16> (all %d launches of one forward)" % len(prof),
         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+        "traffic": pmc.get("linear_kernel", {}).get("hbm_bytes_per_launch"),
+        "traffic_note": "HBM-side bytes per launch, average over the launches of a forward (committed PMC pass)",
         "algorithmic_flops_per_forward": flops, "sum_launch_ms": round(secs * 1e3, 3),
         "avg_launch_us": round(secs / len(prof) * 1e6, 1),
         "longest_launch": {"M": big[3], "N": big[4], "K": big[5], "us": round(big[0].elapsed_time(big[1]) * 1e3, 1),
                            "TFLOP/s": round(big[2] / (big[0].elapsed_time(big[1]) * 1e-3) / 1e12, 1)},
     }
+    ffn = kprof.get("ffn_fused", [])
+    if ffn:
+        fl = sum(4.0 * m["M"] * m["C"] * m["hidden"] for _, _, m in ffn)
+        t = sum(a.elapsed_time(b) for a, b, _ in ffn) * 1e-3
+        out["roofline_ffn"] = {
+            "kernel": "ffn_fused_kernel<2> (%d encoder launches, M = %d)" % (len(ffn), ffn[0][2]["M"]),
+            "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(fl / t / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "traffic": pmc.get("ffn_fused", {}).get("hbm_bytes_per_launch"),
+            "avg_launch_us": round(t / len(ffn) * 1e6, 1),
+        }
+    enc = [(a, b, m) for a, b, m in kprof.get("msda_fused", []) if m["Nq"] == m["S"]]
+    if enc:
+        m = enc[0][2]
+        e = 2
+        # value + offsets (2 per point) + logits (1 per point) + output, each touched once
+        nbytes = e * m["B"] * (m["S"] * m["M"] * m["D"] + 3 * m["Nq"] * m["M"] * m["L"] * m["P"] + m["Nq"] * m["M"] * m["D"])
+        t = sum(a.elapsed_time(b) for a, b, _ in enc) * 1e-3 / len(enc)
+        out["roofline_msda"] = {
+            "kernel": "msda_tiled_kernel<F16,4,fused> (the %d encoder launches of one forward, Nq = S = %d)" % (len(enc), m["S"]),
+            "bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": pmc.get("msda", {}).get("hbm_bytes_largest_launch"),
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(t * 1e6, 1),
+        }
+    return out
 
 
 def cpu_baseline(model, H=608, W=608, full_hw=(1280, 1920)):
@@ -275,11 +322,12 @@ def main():
                               "not the same hardware, so vs_baseline stays null",
         }
         if world == 1 and not a.no_roofline:
-            if dtype != torch.float32:
-                out["roofline"] = linear_roofline(model, images, masks, device)
-            out["roofline_msda"] = msda_roofline(a.batch, H, W, dtype, device)
-            if "roofline" not in out:
-                out["roofline"] = out["roofline_msda"]
+            op = msda_roofline(a.batch, H, W, dtype, device)
+            if dtype == torch.float16:
+                out.update(kernel_rooflines(model, images, masks, device))
+                out["roofline_msda_op"] = op
+            else:
+                out["roofline"] = op
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))

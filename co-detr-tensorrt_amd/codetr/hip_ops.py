@@ -27,6 +27,21 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
 # (entries: (start_event, end_event, flops, M, N, K)); None in normal operation
 LINEAR_PROFILE = None
+# same hook for the other two heavy kernels: dict name -> list of (start_event, end_event, meta dict); None normally
+KERNEL_PROFILE = None
+
+
+def _timed(name, meta, launch, device):
+    """run `launch()`; when bench.py has armed KERNEL_PROFILE, bracket it with HIP events on the launch stream"""
+    if KERNEL_PROFILE is None:
+        return launch()
+    st = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    r = launch()
+    e1.record(st)
+    KERNEL_PROFILE.setdefault(name, []).append((e0, e1, meta))
+    return r
 
 
 def _gpu(x, what):
@@ -141,7 +156,8 @@ def ffn_fused(x, w1, b1, w2, b2):
     out = torch.empty_like(x2)
     if x2.shape[0] > 0:
         with torch.cuda.device(x.device):
-            _cabi.ffn_fused(x2, w1.contiguous(), b1, _packed_w2(w2), b2, out)
+            _timed("ffn_fused", {"M": x2.shape[0], "C": x2.shape[1], "hidden": w1.shape[0]},
+                   lambda: _cabi.ffn_fused(x2, w1.contiguous(), b1, _packed_w2(w2), b2, out), x.device)
     return out.view(x.shape)
 
 
@@ -336,9 +352,10 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
     out = torch.empty((B, proj.shape[1], M * D), dtype=value.dtype, device=value.device)
     if out.numel():
         with torch.cuda.device(value.device):
-            _cabi.msda_fused(value.contiguous(), spatial_shapes, level_start_index, proj.contiguous(), off_col,
-                             logit_col, reference_points.to(value.dtype).contiguous(), num_levels, num_points, out,
-                             head_major=head_major)
+            _timed("msda_fused", {"B": B, "S": S, "Nq": proj.shape[1], "M": M, "D": D, "L": num_levels, "P": num_points},
+                   lambda: _cabi.msda_fused(value.contiguous(), spatial_shapes, level_start_index, proj.contiguous(),
+                                            off_col, logit_col, reference_points.to(value.dtype).contiguous(),
+                                            num_levels, num_points, out, head_major=head_major), value.device)
     return out
 
 

@@ -72,10 +72,35 @@ class PatchMerging(nn.Module):
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         H2, W2 = (H + 1) // 2, (W + 1) // 2
+        if x.is_cuda and not torch.is_grad_enabled():
+            # Same merge with the 4C axis ordered (ky, kx, c) instead of nn.Unfold's (c, ky, kx): the gather then moves
+            # whole C-vectors (>= 384 contiguous bytes) instead of single elements, and LayerNorm / Linear see their
+            # parameters permuted the same way (LN is invariant under a joint permutation; the Linear's columns follow).
+            nw, nb, rw = self._permuted_params(C)
+            x = x.view(B, H2, 2, W2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H2 * W2, 4 * C)
+            if self.norm is not None:
+                x = hip_ops.layer_norm(x, nw, nb, self.norm.eps)
+            return hip_ops.linear(x, rw, self.reduction.bias), (H2, W2)
         x = x.view(B, H2, 2, W2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H2 * W2, 4 * C)
         if self.norm is not None:
             x = hip_ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return hip_ops.linear(x, self.reduction.weight, self.reduction.bias), (H2, W2)
+
+    def _permuted_params(self, C):
+        """(norm.weight, norm.bias, reduction.weight) with the 4C axis re-ordered from (c, ky, kx) to (ky, kx, c);
+        rebuilt only when a parameter tensor changes"""
+        ps = [self.reduction.weight] + ([self.norm.weight, self.norm.bias] if self.norm is not None else [])
+        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
+        hit = getattr(self, "_perm_cache", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                # new index (k, c) <- old index c*4 + k
+                idx = (torch.arange(C, device=ps[0].device)[None, :] * 4 + torch.arange(4, device=ps[0].device)[:, None]).reshape(-1)
+                rw = self.reduction.weight.detach()[:, idx].contiguous()
+                nw = self.norm.weight.detach()[idx].contiguous() if self.norm is not None else None
+                nb = self.norm.bias.detach()[idx].contiguous() if self.norm is not None else None
+            hit = self._perm_cache = (key, (nw, nb, rw))
+        return hit[1]
 
 
 class WindowMSA(nn.Module):

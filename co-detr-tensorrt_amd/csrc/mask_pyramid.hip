@@ -15,8 +15,9 @@
 // Byte work, one thread per token in both passes (a first version that walked each column / row with one thread
 // -- 160 dependent iterations at the stride-8 level -- took 267 us):
 //   pass 1  level_mask_kernel : mask_flat[b, s] = img[b, src(y), src(x)] != 0
-//   pass 2  level_cums_kernel : thread (y, x) sums mask_flat down its column (<= y) and along its row (<= x); the
-//                               reads are coalesced / broadcast and L1-resident (<= 400 byte loads per thread)
+//   pass 2  level_cums_kernel : one wave per level row (ballot + popcount prefix -> xcum) and one per 64-column
+//                               strip (running count down the strip -> ycum); a thread-per-token version that
+//                               re-summed its column and row (<= 400 byte loads per thread) still took 93 us
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -56,27 +57,46 @@ __global__ __launch_bounds__(256) void level_mask_kernel(const unsigned char* __
   mask_flat[i] = img[((size_t)b * Hi + src_index(y, sy, Hi)) * Wi + src_index(x, sx, Wi)] != 0;
 }
 
-__global__ __launch_bounds__(256) void level_cums_kernel(const unsigned char* __restrict__ mask_flat, int B, Levels lv,
-                                                         int L, int64_t S, int64_t total, float* __restrict__ ycum,
-                                                         float* __restrict__ xcum, float* __restrict__ valid_counts) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int b = (int)(i / S);
-  const int64_t s = i - (int64_t)b * S;
-  const int l = level_of(lv, L, s);
-  const int r = (int)(s - lv.start[l]);
+// One wave per task.  Tasks of image b: first every row of every level (xcum: ballot + popcount prefix, 64 columns
+// per step), then every 64-column strip of every level (ycum: running count down the strip, coalesced 64-byte loads).
+__global__ __launch_bounds__(64) void level_cums_kernel(const unsigned char* __restrict__ mask_flat, int B, Levels lv,
+                                                        int L, int64_t S, int rows_total, float* __restrict__ ycum,
+                                                        float* __restrict__ xcum, float* __restrict__ valid_counts) {
+  const int b = blockIdx.y, lane = threadIdx.x;
+  int task = blockIdx.x;
+  if (task < rows_total) {
+    int l = 0;
+    while (task >= lv.h[l]) task -= lv.h[l++];
+    const int y = task, H = lv.h[l], W = lv.w[l];
+    const unsigned char* row = mask_flat + (size_t)b * S + lv.start[l] + (size_t)y * W;
+    float* out = xcum + (size_t)B * lv.start[l] + ((size_t)b * H + y) * W;
+    int carry = 0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+      const int x = x0 + lane;
+      const bool valid = x < W && row[x] == 0;
+      const unsigned long long bal = __ballot(valid);
+      const int incl = __popcll(bal & (~0ull >> (63 - lane)));
+      if (x < W) out[x] = (float)(carry + incl);
+      carry += __popcll(bal);
+    }
+    if (y == 0 && lane == 0) valid_counts[((size_t)b * L + l) * 2 + 0] = (float)carry;  // valid columns of the first row
+    return;
+  }
+  task -= rows_total;
+  int l = 0;
+  while (task >= (lv.w[l] + 63) / 64) task -= (lv.w[l++] + 63) / 64;
   const int H = lv.h[l], W = lv.w[l];
-  const int y = r / W, x = r - y * W;
-  const unsigned char* m = mask_flat + (size_t)b * S + lv.start[l];
-  int cy = 0, cx = 0;
-  for (int yy = 0; yy <= y; ++yy) cy += m[(size_t)yy * W + x] == 0;
-  const unsigned char* row = m + (size_t)y * W;
-  for (int xx = 0; xx <= x; ++xx) cx += row[xx] == 0;
-  const size_t o = (size_t)B * lv.start[l] + (size_t)b * H * W + r;  // level block [B, H, W] of the cum buffers
-  ycum[o] = (float)cy;
-  xcum[o] = (float)cx;
-  if (x == 0 && y == H - 1) valid_counts[((size_t)b * L + l) * 2 + 1] = (float)cy;  // valid rows of the first column
-  if (y == 0 && x == W - 1) valid_counts[((size_t)b * L + l) * 2 + 0] = (float)cx;  // valid columns of the first row
+  const int x = task * 64 + lane;
+  if (x >= W) return;
+  const unsigned char* col = mask_flat + (size_t)b * S + lv.start[l] + x;
+  float* out = ycum + (size_t)B * lv.start[l] + (size_t)b * H * W + x;
+  int run = 0;
+#pragma unroll 8
+  for (int y = 0; y < H; ++y) {
+    run += col[(size_t)y * W] == 0;
+    out[(size_t)y * W] = (float)run;
+  }
+  if (x == 0) valid_counts[((size_t)b * L + l) * 2 + 1] = (float)run;  // valid rows of the first column
 }
 
 }  // namespace
@@ -108,8 +128,14 @@ int codetr_mask_pyramid(void* stream, const void* img_mask_dev, int64_t B, int64
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(level_mask_kernel, grid, block, 0, st, static_cast<const unsigned char*>(img_mask_dev), (int)H_img,
                      (int)W_img, lv, num_levels, S, total, static_cast<unsigned char*>(mask_flat_dev));
-  hipLaunchKernelGGL(level_cums_kernel, grid, block, 0, st, static_cast<const unsigned char*>(mask_flat_dev), (int)B, lv,
-                     num_levels, S, total, ycum_dev, xcum_dev, valid_counts_dev);
+  int rows_total = 0, strips_total = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    rows_total += lv.h[l];
+    strips_total += (lv.w[l] + 63) / 64;
+  }
+  hipLaunchKernelGGL(level_cums_kernel, dim3((unsigned)(rows_total + strips_total), (unsigned)B), dim3(64), 0, st,
+                     static_cast<const unsigned char*>(mask_flat_dev), (int)B, lv, num_levels, S, rows_total, ycum_dev,
+                     xcum_dev, valid_counts_dev);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
