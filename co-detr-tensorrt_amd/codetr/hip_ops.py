@@ -146,18 +146,30 @@ def _packed_w2(w2):
     return hit[1]
 
 
-def ffn_fused(x, w1, b1, w2, b2):
+def ffn_fused(x, w1, b1, w2, b2, ln=None, pos=None):
     """y = x + relu(x @ w1.T + b1) @ w2.T + b2 in one kernel (hidden activation stays on-chip); x [..., 256].
-    w2 is the plain nn.Linear weight; its packed form is cached."""
+    w2 is the plain nn.Linear weight; its packed form is cached.
+    ln = (weight, bias, eps): y = LayerNorm(y) in the same epilogue.  pos (same shape as x): also returns y + pos,
+    i.e. the result is (y, y + pos)."""
     _gpu(x, "ffn_fused")
     x2 = x.reshape(-1, x.shape[-1])
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     out = torch.empty_like(x2)
+    p2 = out2 = None
+    if pos is not None:
+        p2 = pos.reshape(-1, pos.shape[-1])
+        if p2.shape != x2.shape or p2.dtype != x2.dtype:
+            raise ValueError("pos must match x in shape and dtype")
+        if not p2.is_contiguous():
+            p2 = p2.contiguous()
+        out2 = torch.empty_like(x2)
     if x2.shape[0] > 0:
         with torch.cuda.device(x.device):
             _timed("ffn_fused", {"M": x2.shape[0], "C": x2.shape[1], "hidden": w1.shape[0]},
-                   lambda: _cabi.ffn_fused(x2, w1.contiguous(), b1, _packed_w2(w2), b2, out), x.device)
+                   lambda: _cabi.ffn_fused(x2, w1.contiguous(), b1, _packed_w2(w2), b2, out, ln, p2, out2), x.device)
+    if pos is not None:
+        return out.view(x.shape), out2.view(x.shape)
     return out.view(x.shape)
 
 

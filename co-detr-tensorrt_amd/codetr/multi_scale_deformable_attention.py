@@ -98,9 +98,12 @@ class MultiScaleDeformableAttention(nn.Module):
 
     # ------------------------------------------------------------------ batch-first core
     def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
-                   level_start_index):
-        """query [B,Nq,C]; value [B,S,C]; returns output_proj(msda(...)) + identity, [B,Nq,C]."""
-        if query_pos is not None:
+                   level_start_index, query_plus_pos=None):
+        """query [B,Nq,C]; value [B,S,C]; returns output_proj(msda(...)) + identity, [B,Nq,C].
+        query_plus_pos: `query + query_pos` if the caller already holds it."""
+        if query_plus_pos is not None:
+            query = query_plus_pos
+        elif query_pos is not None:
             query = query + query_pos
         B, Nq, _ = query.shape
         S = value.shape[1]

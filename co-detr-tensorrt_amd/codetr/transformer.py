@@ -37,9 +37,15 @@ class DetrTransformerEncoder(nn.Module):
             self.post_norm = None
 
     def forward_bf(self, query, query_pos, query_key_padding_mask, **kw):
-        for layer in self.layers:
-            query = layer.forward_bf(query, None, None, query_pos=query_pos,
-                                     query_key_padding_mask=query_key_padding_mask, **kw)
+        plus_pos = None
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            # every layer but the last also hands over `out + query_pos`, the next layer's attention input, from its
+            # fused FFN + LayerNorm epilogue (None when that kernel does not apply: the next layer then adds itself)
+            query, plus_pos = layer.forward_bf(query, None, None, query_pos=query_pos,
+                                               query_key_padding_mask=query_key_padding_mask,
+                                               query_plus_pos=plus_pos, want_plus_pos=True, want_pos_output=i < last,
+                                               **kw)
         return query
 
     def forward(self, query, key, value, query_pos=None, key_pos=None, attn_masks=None, query_key_padding_mask=None,

@@ -60,10 +60,21 @@ class FFN(nn.Module):
         )
         self.add_identity = add_identity
 
+    def fused_supported(self, x, identity=None):
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        return (self.add_identity and identity is None and fc1.bias is not None and fc2.bias is not None
+                and hip_ops.ffn_fused_supported(x, fc1.weight, fc2.weight, self.act))
+
+    def forward_norm(self, x, norm, pos=None):
+        """LayerNorm(x + ffn(x)) -- and, with `pos`, also that + pos -- in the fused kernel's epilogue
+        (call only when fused_supported(x))."""
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        return hip_ops.ffn_fused(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln=(norm.weight, norm.bias, norm.eps),
+                                 pos=pos)
+
     def forward(self, x, identity=None):
         fc1, fc2 = self.layers[0][0], self.layers[1]
-        if (self.add_identity and identity is None and fc1.bias is not None and fc2.bias is not None
-                and hip_ops.ffn_fused_supported(x, fc1.weight, fc2.weight, self.act)):
+        if self.fused_supported(x, identity):
             # encoder / decoder FFN (256 -> 2048 -> 256, ReLU): one kernel, the hidden activation never reaches HBM
             return hip_ops.ffn_fused(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
         h = hip_ops.linear(x, fc1.weight, fc1.bias, act=self.act)
@@ -170,20 +181,32 @@ class BaseTransformerLayer(nn.Module):
         self.norms = nn.ModuleList(build_norm(norm_cfg, self.embed_dims) for _ in range(operation_order.count("norm")))
 
     def forward_bf(self, query, key=None, value=None, query_pos=None, key_pos=None, query_key_padding_mask=None,
-                   key_padding_mask=None, **kw):
+                   key_padding_mask=None, query_plus_pos=None, want_plus_pos=False, want_pos_output=True, **kw):
         """batch-first walk of operation_order; `kw` carries reference_points / spatial_shapes /
-        level_start_index for the deformable attentions."""
+        level_start_index for the deformable attentions.
+        query_plus_pos: `query + query_pos` when the caller already has it (the previous layer's fused FFN epilogue);
+        want_plus_pos: return a pair (out, out + query_pos); the second member is produced when the layer ends in
+        'ffn', 'norm', the fused kernel applies and want_pos_output is set -- None otherwise."""
         ni = ai = fi = 0
         identity = query
-        for op in self.operation_order:
+        plus_pos_out = None
+        ops = self.operation_order
+        skip_norm = False
+        for oi, op in enumerate(ops):
+            if skip_norm and op == "norm":
+                skip_norm = False
+                ni += 1
+                continue
             if op in ("self_attn", "cross_attn"):
                 att = self.attentions[ai]
                 res = identity if self.pre_norm else None
                 if isinstance(att, MultiScaleDeformableAttention):
                     val = query if op == "self_attn" else value
                     mask = query_key_padding_mask if op == "self_attn" else key_padding_mask
+                    qpp = query_plus_pos if (ai == 0 and oi == 0) else None  # valid for the layer's input only
                     query = att.forward_bf(query, val, query if res is None else res, query_pos, mask,
-                                           kw["reference_points"], kw["spatial_shapes"], kw["level_start_index"])
+                                           kw["reference_points"], kw["spatial_shapes"], kw["level_start_index"],
+                                           query_plus_pos=qpp)
                 else:
                     if op == "self_attn":
                         query = att.forward_bf(query, query, query, res, query_pos, query_pos)
@@ -196,8 +219,26 @@ class BaseTransformerLayer(nn.Module):
                 query = hip_ops.layer_norm(query, n.weight, n.bias, n.eps)
                 ni += 1
             else:  # ffn
-                query = self.ffns[fi](query, identity if self.pre_norm else None)
+                ffn = self.ffns[fi]
+                last_pair = oi + 2 == len(ops) and ops[oi + 1] == "norm"
+                if (not self.pre_norm and oi + 1 < len(ops) and ops[oi + 1] == "norm" and ffn.fused_supported(query)
+                        and isinstance(self.norms[ni], nn.LayerNorm) and self.norms[ni].weight is not None
+                        and self.norms[ni].weight.dtype == query.dtype):
+                    # post-norm layer: the LayerNorm that follows (and, at the end of the layer, the next layer's
+                    # `+ query_pos`) ride in the fused FFN kernel's epilogue
+                    pos = query_pos if (want_plus_pos and want_pos_output and last_pair and query_pos is not None
+                                        and query_pos.shape == query.shape) else None
+                    r = ffn.forward_norm(query, self.norms[ni], pos)
+                    if pos is not None:
+                        query, plus_pos_out = r
+                    else:
+                        query = r
+                    skip_norm = True
+                else:
+                    query = ffn(query, identity if self.pre_norm else None)
                 fi += 1
+        if want_plus_pos:
+            return query, plus_pos_out
         return query
 
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,

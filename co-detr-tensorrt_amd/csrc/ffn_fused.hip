@@ -110,7 +110,8 @@ template <int MT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
-    int Hd) {
+    int Hd, const unsigned short* __restrict__ ln_g, const unsigned short* __restrict__ ln_b, float ln_eps,
+    const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2];  // 144 KiB, one object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
@@ -273,18 +274,69 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       *reinterpret_cast<f16x4*>(stage + (mt * 16 + l15) * kOutPitch + (nt * 16 + grp * 4) * 2) = o;
     }
   __builtin_amdgcn_wave_barrier();
-  // WR rows x 32 chunks of 16 B: lane -> (row = it*2 + lane/32, chunk = lane%32)
+  // WR rows x 32 chunks of 16 B: lane -> (row = it*2 + lane/32, chunk = lane%32).  With one wave per SIMD a
+  // load -> add -> store chain per row pair would expose one memory latency per iteration (measured +85 us per launch
+  // once the epilogue also read pos): all residual / pos rows are requested first -- the accumulators are dead by
+  // now, the registers are free -- and consumed afterwards.
+  const int chunk = lane & 31;
+  f16x8 xr[WR / 2], pr[WR / 2];
 #pragma unroll
   for (int it = 0; it < WR / 2; ++it) {
-    const int row = it * 2 + (lane >> 5), chunk = lane & 31;
-    const int m = m0 + row;
-    if (m < M) {
-      const f16x8 y = *reinterpret_cast<const f16x8*>(stage + row * kOutPitch + chunk * 16);
-      const f16x8 x = *reinterpret_cast<const f16x8*>(X + (size_t)m * C + chunk * 8);
-      f16x8 o;
+    int m = m0 + it * 2 + (lane >> 5);
+    m = m < M ? m : M - 1;
+    xr[it] = *reinterpret_cast<const f16x8*>(X + (size_t)m * C + chunk * 8);
+  }
+  if (Y2) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)y[e] + (float)x[e]);  // identity + ffn(x): fp16 + fp16 -> fp16
+    for (int it = 0; it < WR / 2; ++it) {
+      int m = m0 + it * 2 + (lane >> 5);
+      m = m < M ? m : M - 1;
+      pr[it] = *reinterpret_cast<const f16x8*>(pos + (size_t)m * C + chunk * 8);
+    }
+  }
+  f16x8 gw, gb;
+  if (ln_g) {
+    gw = *reinterpret_cast<const f16x8*>(ln_g + chunk * 8);
+    gb = *reinterpret_cast<const f16x8*>(ln_b + chunk * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < WR / 2; ++it) {
+    const int row = it * 2 + (lane >> 5);
+    const int m = m0 + row;
+    const f16x8 y = *reinterpret_cast<const f16x8*>(stage + row * kOutPitch + chunk * 16);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)y[e] + (float)xr[it][e]);  // identity + ffn(x): fp16 + fp16 -> fp16
+    if (ln_g) {
+      // LayerNorm over the row (its 256 values sit in the 32 lanes of this half-wave): the arithmetic of
+      // layernorm_kernel<LnHalf, 32, 1>, statement for statement, so the result is bit-identical to running that
+      // kernel on the stored sum
+      float sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm += (float)o[e];
+#pragma unroll
+      for (int d = 16; d > 0; d >>= 1) sm += __shfl_xor(sm, d, 64);
+      const float mean = sm * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dv = (float)o[e] - mean;
+        q = fmaf(dv, dv, q);
+      }
+#pragma unroll
+      for (int d = 16; d > 0; d >>= 1) q += __shfl_xor(q, d, 64);
+      const float rstd = rsqrtf(q * (1.0f / C) + ln_eps);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaf(((float)o[e] - mean) * rstd, (float)gw[e], (float)gb[e]);
+    }
+    if (m < M) {
       *reinterpret_cast<f16x8*>(Y + (size_t)m * C + chunk * 8) = o;
+      if (Y2) {  // the next layer's attention input: this row + its positional encoding (fp16 + fp16 -> fp16)
+        f16x8 o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o2[e] = (_Float16)((float)o[e] + (float)pr[it][e]);
+        *reinterpret_cast<f16x8*>(Y2 + (size_t)m * C + chunk * 8) = o2;
+      }
     }
   }
 }
@@ -314,11 +366,14 @@ int codetr_ffn_pack_w2_f16(void* stream, const void* w2_dev, void* w2_packed_dev
   return err == hipSuccess ? 0 : (int)err;
 }
 
-int codetr_ffn_relu_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
-                        const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
-                        int64_t hidden) {
+int codetr_ffn_relu_ln_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
+                           const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                           int64_t hidden, const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps,
+                           const void* pos_dev, void* y_plus_pos_dev) {
   const void* w2_dev = w2_packed_dev;
   if (!x_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !y_dev || M <= 0 || hidden <= 0) return CODETR_E_BADARG;
+  if ((ln_gamma_dev == nullptr) != (ln_beta_dev == nullptr) || (pos_dev == nullptr) != (y_plus_pos_dev == nullptr))
+    return CODETR_E_BADARG;
   if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
   if (M > 0x7fffffffLL - 256 || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   // MT = 2 (128 rows per workgroup).  MT = 3 fits the register file only without the interleaved DMA issue (236 VGPR
@@ -329,9 +384,18 @@ int codetr_ffn_relu_f16(void* stream, const void* x_dev, const void* w1_dev, con
                      static_cast<const unsigned short*>(x_dev), static_cast<const unsigned short*>(w1_dev),
                      static_cast<const unsigned short*>(b1_dev), static_cast<const unsigned short*>(w2_dev),
                      static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
-                     (int)hidden);
+                     (int)hidden, static_cast<const unsigned short*>(ln_gamma_dev),
+                     static_cast<const unsigned short*>(ln_beta_dev), ln_eps,
+                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev));
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+int codetr_ffn_relu_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
+                        const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                        int64_t hidden) {
+  return codetr_ffn_relu_ln_f16(stream, x_dev, w1_dev, b1_dev, w2_packed_dev, b2_dev, y_dev, M, C_in, hidden, nullptr,
+                                nullptr, 0.f, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 16
+#define CODETR_HIP_ABI_VERSION 17
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -326,6 +326,18 @@ int codetr_sine_pos_tokens_f16(void *stream, const float *ycum_dev, const float 
 int codetr_ffn_relu_f16(void *stream, const void *x_dev, const void *w1_dev, const void *b1_dev,
                         const void *w2_packed_dev, const void *b2_dev, void *y_dev, int64_t M, int64_t C_in,
                         int64_t hidden);
+
+/* The same kernel with the layer's next two steps folded into its epilogue (post-norm encoder layer,
+ * operation_order (..., 'ffn', 'norm'), codetr/transformer_mmcv.py:640-700, and the `query + query_pos` at the head
+ * of the next layer's attention, codetr/multi_scale_deformable_attention.py:160-161):
+ *   y      = LayerNorm(x + ffn(x)) * gamma + beta        ln_gamma_dev / ln_beta_dev [256] f16, both or neither
+ *   y_plus_pos = y + pos                                  pos_dev / y_plus_pos_dev [M, 256] f16, both or neither
+ * The LayerNorm arithmetic is that of codetr_layernorm_f16 (fp32 two-pass statistics over the f16-rounded sum),
+ * bit-identical to running the three kernels one after another. */
+int codetr_ffn_relu_ln_f16(void *stream, const void *x_dev, const void *w1_dev, const void *b1_dev,
+                           const void *w2_packed_dev, const void *b2_dev, void *y_dev, int64_t M, int64_t C_in,
+                           int64_t hidden, const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps,
+                           const void *pos_dev, void *y_plus_pos_dev);
 /* one-time weight pre-pack for the call above: w2_dev [C_out, hidden] f16 -> w2_packed_dev (same shape) */
 int codetr_ffn_pack_w2_f16(void *stream, const void *w2_dev, void *w2_packed_dev, int64_t C_out, int64_t hidden);
 

@@ -62,3 +62,66 @@ def test_ffn_module_takes_fused_path_and_matches_two_gemm_path():
         ys = ffn(x[:, :450])
     assert _cabi.CALLS["ffn_fused"] == before["ffn_fused"] and _cabi.CALLS["linear"] == before["linear"] + 2
     torch.testing.assert_close(ys.float(), y2[:, :450].float(), rtol=2e-3, atol=4e-3)
+
+
+def test_ffn_layernorm_pos_epilogue_is_bit_identical_to_three_kernels():
+    """codetr_ffn_relu_ln_f16 == fused FFN -> codetr_layernorm_f16 -> fp16 add, bit for bit."""
+    from codetr import _cabi, hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(3)
+    M = hip_ops.FFN_FUSED_MIN_ROWS + 333
+    x = torch.randn(M, 256, device=DEV, generator=g).half()
+    pos = torch.randn(M, 256, device=DEV, generator=g).half()
+    w1 = (torch.randn(2048, 256, device=DEV, generator=g) / 16).half()
+    b1 = torch.randn(2048, device=DEV, generator=g).half()
+    w2 = (torch.randn(256, 2048, device=DEV, generator=g) / 45).half()
+    b2 = torch.randn(256, device=DEV, generator=g).half()
+    gam = (1 + 0.1 * torch.randn(256, device=DEV, generator=g)).half()
+    bet = (0.1 * torch.randn(256, device=DEV, generator=g)).half()
+    y0 = hip_ops.ffn_fused(x, w1, b1, w2, b2)
+    n0 = hip_ops.layer_norm(y0, gam, bet, 1e-5)
+    before = _cabi.CALLS["layernorm"]
+    n1 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5))
+    n2, q2 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), pos=pos)
+    assert _cabi.CALLS["layernorm"] == before
+    assert torch.equal(n1, n0) and torch.equal(n2, n0)
+    assert torch.equal(q2, n0 + pos)
+    y3, q3 = hip_ops.ffn_fused(x, w1, b1, w2, b2, pos=pos)  # second output without the norm
+    assert torch.equal(y3, y0) and torch.equal(q3, y0 + pos)
+
+
+def test_encoder_layers_chain_through_the_fused_epilogue():
+    """A post-norm (self_attn, norm, ffn, norm) encoder: LN2 and the next layer's `+ query_pos` come out of the FFN
+    kernel (no separate layer-norm / add launches for them) and the result equals the unfused walk."""
+    from codetr import _cabi, hip_ops
+    from codetr.transformer import DetrTransformerEncoder
+
+    torch.manual_seed(0)
+    cfg = dict(type="BaseTransformerLayer",
+               attn_cfgs=dict(type="MultiScaleDeformableAttention", embed_dims=256, num_levels=2, dropout=0.0),
+               feedforward_channels=2048, ffn_dropout=0.0, operation_order=("self_attn", "norm", "ffn", "norm"))
+    enc = DetrTransformerEncoder(transformerlayers=cfg, num_layers=3).to(DEV).half().eval()
+    shapes = [(160, 160), (40, 40)]
+    S = sum(h * w for h, w in shapes)
+    assert S >= hip_ops.FFN_FUSED_MIN_ROWS
+    g = torch.Generator(device=DEV).manual_seed(1)
+    q = torch.randn(1, S, 256, device=DEV, generator=g).half()
+    pos = torch.randn(1, S, 256, device=DEV, generator=g).half()
+    ref = torch.rand(1, S, 2, 2, device=DEV, generator=g).half()
+    ss = torch.tensor(shapes, device=DEV)
+    ls = torch.tensor([0, shapes[0][0] * shapes[0][1]], device=DEV)
+    mask = torch.zeros(1, S, dtype=torch.bool, device=DEV)
+    kw = dict(reference_points=ref, spatial_shapes=ss, level_start_index=ls)
+    before = dict(_cabi.CALLS)
+    with torch.no_grad():
+        out = enc.forward_bf(q, pos, mask, **kw)
+    assert _cabi.CALLS["ffn_fused"] - before["ffn_fused"] == 3
+    assert _cabi.CALLS["layernorm"] - before["layernorm"] == 3      # LN1 of each layer only
+    saved = hip_ops.FFN_FUSED_MIN_ROWS
+    try:
+        hip_ops.FFN_FUSED_MIN_ROWS = 1 << 60                      # two-GEMM FFN, separate norms and adds
+        with torch.no_grad():
+            out0 = enc.forward_bf(q, pos, mask, **kw)
+    finally:
+        hip_ops.FFN_FUSED_MIN_ROWS = saved
+    torch.testing.assert_close(out.float(), out0.float(), rtol=2e-2, atol=2e-2)

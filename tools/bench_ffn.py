@@ -17,6 +17,14 @@ for M in (204600, 73656, 30785):
     w2 = (torch.randn(256, 2048, device="cuda") / 45).half()
     b2 = torch.randn(256, device="cuda").half()
     tf = timeit(lambda: hip_ops.ffn_fused(x, w1, b1, w2, b2))
+    gam, bet, pos = torch.ones(256, device="cuda").half(), torch.zeros(256, device="cuda").half(), torch.randn_like(x)
+    tl = timeit(lambda: hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), pos=pos))
+
+    def three():
+        y = hip_ops.layer_norm(hip_ops.ffn_fused(x, w1, b1, w2, b2), gam, bet, 1e-5)
+        return y, y + pos
+
+    t3 = timeit(three)
 
     def two():
         h = hip_ops.linear(x, w1, b1, act="relu")
@@ -24,4 +32,5 @@ for M in (204600, 73656, 30785):
 
     t2 = timeit(two)
     fl = 2 * 2.0 * M * 256 * 2048
+    print(f"M={M}: FFN+LN+pos one kernel {tl * 1e6:.1f} us, as three kernels {t3 * 1e6:.1f} us")
     print(f"M={M}: fused FFN {tf * 1e6:.1f} us ({fl / tf / 1e12:.0f} TF/s)   two native GEMMs {t2 * 1e6:.1f} us ({fl / t2 / 1e12:.0f} TF/s)")
