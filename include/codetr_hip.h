@@ -237,7 +237,7 @@ int codetr_encoder_geometry_f16(void *stream, const void *valid_ratios_dev, cons
                                 void *reference_by_level_dev, void *proposals_dev, void *row_state_dev);
 
 /* out[r] = max_c x[r, c] (NaN propagates, as torch.max): enc_outputs_class.max(-1)[0], the ranking score of
- * the two-stage top-k (codetr/transformer.py:563).  x [rows, C] f16 dense, out [rows] f16. */
+ * the two-stage top-k (codetr/transformer.py:560).  x [rows, C] f16 dense, out [rows] f16. */
 int codetr_row_max_f16(void *stream, const void *x_dev, void *out_dev, int64_t rows, int64_t C);
 
 /* ------------------------------------------------------------------------------------------
@@ -328,8 +328,8 @@ int codetr_ffn_relu_f16(void *stream, const void *x_dev, const void *w1_dev, con
                         int64_t hidden);
 
 /* The same kernel with the layer's next two steps folded into its epilogue (post-norm encoder layer,
- * operation_order (..., 'ffn', 'norm'), codetr/transformer_mmcv.py:640-700, and the `query + query_pos` at the head
- * of the next layer's attention, codetr/multi_scale_deformable_attention.py:160-161):
+ * operation_order (..., 'ffn', 'norm'), codetr/transformer_mmcv.py:649-760, and the `query + query_pos` at the head
+ * of the next layer's attention, codetr/multi_scale_deformable_attention.py:161-162):
  *   y      = LayerNorm(x + ffn(x)) * gamma + beta        ln_gamma_dev / ln_beta_dev [256] f16, both or neither
  *   y_plus_pos = y + pos                                  pos_dev / y_plus_pos_dev [M, 256] f16, both or neither
  * The LayerNorm arithmetic is that of codetr_layernorm_f16 (fp32 two-pass statistics over the f16-rounded sum),
