@@ -617,6 +617,224 @@ int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// X-stationary kernel for the short-K layers (K = 192, 256, 384: Swin stages 0-1 and every 256-wide transformer
+// layer -- a third of the model's GEMM time).  The tiled kernel above re-reads each 128 x K activation tile from L2
+// once per 128-column output tile and pays its fixed per-tile cost (first loads, staging, stores) N/128 times; with
+// K this short the whole K extent of 32 rows fits a wave's registers.  So, as in the first product of
+// ffn_fused.hip: a 256-thread workgroup owns 128 rows for ALL N; each wave loads its 32 rows of X once, as MFMA B
+// fragments straight from global memory (KS k-steps x 2 m-tiles), and keeps them; W streams through a 2-stage LDS
+// ring in chunks of 32 output columns (32 x K, LDS-DMA, XOR-swizzled on the source address), D[n][m] = W . X^T, so
+// a lane again owns 4 consecutive n of one row.  Per chunk: bias from LDS into the accumulator init, 16*KS/8 MFMAs
+// per wave, activation, fp16 image of the wave's 32 x 32 piece in its private LDS region, row-wise read-back,
+// residual (requested before the MFMAs) / row mask, 16-B stores.  X is read from HBM exactly once, Y written once,
+// W (<= 1.2 MB) comes from L2.
+template <class T, int KS, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __restrict__ X,
+                                                        const unsigned short* __restrict__ W,
+                                                        const unsigned short* __restrict__ bias,
+                                                        const unsigned short* __restrict__ R,
+                                                        unsigned short* __restrict__ Y,
+                                                        const unsigned char* __restrict__ row_mask, int M, int N) {
+  constexpr int K = KS * 32, CH = K / 8;          // 16-byte chunks per row
+  constexpr int CN = 32;                          // output columns per W chunk
+  constexpr int kChunkBytes = CN * K * 2;         // 12 / 16 / 24 KiB
+  constexpr int kPieces = kChunkBytes / 4096;     // LDS-DMA instructions per thread per chunk (3 / 4 / 6)
+  constexpr int kXsPitch = 2 * CN * 2 + 16;       // staged output row: two chunks side by side, 128 B + 16
+  constexpr int kStage = 4 * 32 * kXsPitch;       // 18 KiB: 4 waves x 32 rows
+  constexpr int kMaxBias = 1024;
+  constexpr int SWZ = (CH % 16 == 0) ? 15 : 7;    // XOR mask that keeps a swizzled chunk inside its row
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kChunkBytes + kStage + kMaxBias * 2];
+  unsigned char* stage_base = lds + 2 * kChunkBytes;
+  unsigned short* sBias = reinterpret_cast<unsigned short*>(lds + 2 * kChunkBytes + kStage);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, grp = lane >> 4;
+  const int m0 = (int)xcd_tile(blockIdx.x, gridDim.x) * 128 + wave * 32;
+  const int nchunks = (N + CN - 1) / CN;
+
+  auto stage_chunk = [&](int c, unsigned char* dst) {
+#pragma unroll
+    for (int q = 0; q < kPieces; ++q) {
+      const int u = q * 256 + tid;
+      const int r = u / CH, pos = u % CH;
+      const int chunk = pos ^ (r & SWZ);
+      int n = c * CN + r;
+      n = n < N ? n : N - 1;  // ragged last chunk: re-read the last row, its columns are never stored
+      const unsigned short* g = W + (size_t)n * K + chunk * 8;
+      unsigned char* l = dst + (q * 256 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+  };
+  stage_chunk(0, lds);
+
+  // this wave's 32 rows of X, B-operand fragments: lane (j = l15, g = grp) holds X[m][32*ks + 8g .. +7]
+  typename T::frag xf[2][KS];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int m = m0 + mt * 16 + l15;
+    m = m < M ? m : M - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      xf[mt][ks] = *reinterpret_cast<const typename T::frag*>(X + (size_t)m * K + ks * 32 + grp * 8);
+  }
+  if (bias) {
+    for (int i = tid; i < N / 8; i += 256)
+      *reinterpret_cast<s16x8*>(sBias + i * 8) = *reinterpret_cast<const s16x8*>(bias + i * 8);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  unsigned char* my_stage = stage_base + wave * (32 * kXsPitch);
+  // Outputs leave two chunks at a time: 64 columns = 128 contiguous bytes per row, i.e. whole cache lines (a single
+  // 32-column chunk would write half lines and leave the merge to the L2).  Read-back of a pair: 8 rows x 8 chunks of
+  // 16 B per step, 4 steps.
+  const int srow = lane >> 3, schunk = lane & 7;
+  s16x8 rr[4];
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c landed (and X, first iteration)
+    __builtin_amdgcn_s_barrier();                      // ... for everyone; chunk c-1's buffer is free
+    const int n0 = c * CN;
+    const int np = (c & ~1) * CN;  // first column of the pair
+    // residual rows of this pair of chunks, requested ahead of the DMA burst so that waiting for them later leaves
+    // the DMA of the next chunk in flight
+    if (HAS_RES && !(c & 1)) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        int m = m0 + it * 8 + srow;
+        m = m < M ? m : M - 1;
+        int n = np + schunk * 8;
+        n = n + 8 <= N ? n : N - 8;
+        rr[it] = *reinterpret_cast<const s16x8*>(R + (size_t)m * N + n);
+      }
+    }
+    if (c + 1 < nchunks) stage_chunk(c + 1, lds + ((c + 1) & 1) * kChunkBytes);
+    const unsigned char* sW = lds + (c & 1) * kChunkBytes;
+
+    f32x4 acc[2][2];  // [n-tile][m-tile]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+        const s16x4 bv = *reinterpret_cast<const s16x4*>(sBias + n0 + nt * 16 + grp * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[r] = T::to_f32((unsigned short)bv[r]);
+      }
+      acc[nt][0] = b4;
+      acc[nt][1] = b4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      typename T::frag a[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int row = nt * 16 + l15;
+        const int chunk = (ks * 4 + grp) ^ (row & SWZ);
+        a[nt] = *reinterpret_cast<const typename T::frag*>(sW + row * (K * 2) + chunk * 16);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = T::mfma(a[nt], xf[mt][ks], acc[nt][mt]);
+    }
+    // ---- chunk epilogue: this wave's 32 rows x 32 columns into its half of the staged pair ----
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[nt][mt][r];
+          if (ACT == 1) x = x < 0.f ? 0.f : x;
+          if (ACT == 2) x = gelu_erf(x);
+          v[r] = x;
+        }
+        *reinterpret_cast<s16x4*>(my_stage + (mt * 16 + l15) * kXsPitch + ((c & 1) * CN + nt * 16 + grp * 4) * 2) =
+            T::pack4(v);
+      }
+    if (!(c & 1) && c + 1 < nchunks) continue;  // the pair's second chunk follows
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int ml = it * 8 + srow;
+      const int m = m0 + ml;
+      const int n = np + schunk * 8;
+      s16x8 v = *reinterpret_cast<const s16x8*>(my_stage + ml * kXsPitch + schunk * 16);
+      if (m < M && n < N) {  // N % 8 == 0: a chunk of 8 columns is inside or outside as a whole
+        if (row_mask) {
+          const unsigned char mk = row_mask[m];
+          if (mk == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = bias ? T::to_f32(sBias[n + e]) : 0.f;
+              if (ACT == 1) x = x < 0.f ? 0.f : x;
+              if (ACT == 2) x = gelu_erf(x);
+              v[e] = (short)T::from_f32(x);
+            }
+          } else if (mk) {
+            v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          }
+        }
+        if (HAS_RES) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[it][e]));
+        }
+        *reinterpret_cast<s16x8*>(Y + (size_t)m * N + n) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the staging region is rewritten by the next pair
+  }
+}
+
+// The short-K kernel serves f16 / bf16, K in {192, 256}, N % 8 == 0 (16-byte row chunks), 128 <= N <= 992 (bias in
+// LDS; narrower outputs measured equal or slower), at least one workgroup per CU (below that the tiled kernel's
+// N-parallelism wins), no head-major output.  K = 384 (Swin stage 1) fits the registers but measured 20-30 % slower
+// than the tiled kernel (2 workgroups per CU, 48 MFMAs per barrier) and stays there.
+bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
+  static const int off = [] {
+    const char* e = getenv("CODETR_GEMM_XS");
+    return e ? atoi(e) == 0 : 0;
+  }();
+  if (off) return false;
+  return (K == 192 || K == 256) && N % 8 == 0 && N >= 128 && N <= 992 && M >= 128 * 256 && hm_hd == 0;
+}
+
+template <class T, int KS, int ACT>
+int launch_xs_res(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
+                  const void* mask, int M, int N) {
+  const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+  auto x = static_cast<const unsigned short*>(X);
+  auto w = static_cast<const unsigned short*>(W);
+  auto b = static_cast<const unsigned short*>(bias);
+  auto r = static_cast<const unsigned short*>(R);
+  auto y = static_cast<unsigned short*>(Y);
+  auto mk = static_cast<const unsigned char*>(mask);
+  if (R) hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N);
+  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+template <class T, int KS>
+int launch_xs_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
+                  const void* mask, int M, int N, int act) {
+  switch (act) {
+    case 0: return launch_xs_res<T, KS, 0>(st, X, W, bias, R, Y, mask, M, N);
+    case 1: return launch_xs_res<T, KS, 1>(st, X, W, bias, R, Y, mask, M, N);
+    default: return launch_xs_res<T, KS, 2>(st, X, W, bias, R, Y, mask, M, N);
+  }
+}
+
+template <class T>
+int launch_xs(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
+              int M, int N, int K, int act) {
+  switch (K) {
+    case 192: return launch_xs_act<T, 6>(st, X, W, bias, R, Y, mask, M, N, act);
+    default: return launch_xs_act<T, 8>(st, X, W, bias, R, Y, mask, M, N, act);
+  }
+}
+
 template <class T>
 int launch(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
            int64_t M, int64_t N, int64_t K, int act, int64_t hm_rows, int hm_hd) {
@@ -629,6 +847,9 @@ int launch(hipStream_t st, const void* X, const void* W, const void* bias, const
     if (hm_hd <= 0 || hm_rows <= 0 || hm_hd % 8 != 0 || N % hm_hd != 0 || N % 8 != 0 || M % hm_rows != 0 || R)
       return CODETR_E_UNSUPPORTED;
   }
+  if (xs_applicable(M, N, K, hm_hd) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0))
+    return launch_xs<T>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, act);
   switch (act) {
     case 0: return launch_act<T, 0>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, (int)hm_rows, hm_hd);
     case 1: return launch_act<T, 1>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, (int)hm_rows, hm_hd);

@@ -328,7 +328,7 @@ int codetr_ffn_relu_f16(void *stream, const void *x_dev, const void *w1_dev, con
                         int64_t hidden);
 
 /* The same kernel with the layer's next two steps folded into its epilogue (post-norm encoder layer,
- * operation_order (..., 'ffn', 'norm'), codetr/transformer_mmcv.py:649-760, and the `query + query_pos` at the head
+ * operation_order (..., 'ffn', 'norm'), codetr/transformer_mmcv.py:649-749, and the `query + query_pos` at the head
  * of the next layer's attention, codetr/multi_scale_deformable_attention.py:161-162):
  *   y      = LayerNorm(x + ffn(x)) * gamma + beta        ln_gamma_dev / ln_beta_dev [256] f16, both or neither
  *   y_plus_pos = y + pos                                  pos_dev / y_plus_pos_dev [M, 256] f16, both or neither

@@ -179,3 +179,45 @@ def test_linear_splitk_plan_and_row_mask():
     splits, nbytes = _cabi.linear_splitk_plan(300, 64, 2048)
     with pytest.raises(RuntimeError):
         _cabi.linear_splitk(x, w, b, None, None, out, splits, torch.empty(nbytes - 16, dtype=torch.uint8, device=DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,bias,act,res", [
+    (32768, 256, 256, True, None, False),      # exactly 256 workgroups
+    (40000, 480, 256, True, None, False),      # offsets | logits: N % 32 != 0 (ragged last W chunk)
+    (33001, 256, 256, True, None, True),       # out_proj + identity, ragged M
+    (35000, 136, 256, True, None, False),      # odd number of 32-column chunks + a partial one
+    (34000, 128, 256, False, "relu", True),    # no bias
+    (36000, 576, 192, True, None, False),      # Swin stage-0 qkv (K = 192: 24 chunks per row)
+    (36000, 768, 192, True, "gelu", False),    # Swin stage-0 fc1
+    (33000, 192, 192, True, None, True),       # Swin stage-0 proj + identity
+    (33000, 1152, 384, True, None, False),     # Swin stage-1 qkv (K = 384: stays on the tiled kernel)
+])
+def test_linear_short_k_x_stationary_kernel(M, N, K, bias, act, res, dtype):
+    """M >= 32768 rows with K in {192, 256} and 128 <= N <= 992 run the X-stationary kernel (linear_xs_kernel); same
+    tolerance."""
+    _check(M, N, K, dtype, bias, act, res, seed=21)
+
+
+def test_linear_short_k_row_masks():
+    from codetr import hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(9)
+    M = 33333
+    x = torch.randn(M, 256, device=DEV, generator=g).half()
+    w = (torch.randn(256, 256, device=DEV, generator=g) / 16).half()
+    b = torch.randn(256, device=DEV, generator=g).half()
+    r = torch.randn(M, 256, device=DEV, generator=g).half()
+    state = torch.zeros(M, dtype=torch.uint8, device=DEV)
+    state[::3] = 1
+    state[1::7] = 2
+    y = hip_ops.linear(x, w, b, act="relu", residual=r, row_mask=state)
+    ref = torch.relu(x.float() @ w.float().t() + b.float()).half()
+    ref[state == 1] = 0
+    ref[state == 2] = torch.relu(b.float()).half()
+    ref = (ref.float() + r.float())
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=4e-3)
+    # the two kernels agree bit for bit on the masked rows and to rounding elsewhere
+    import os
+    y_small = hip_ops.linear(x[:1000], w, b, act="relu", residual=r[:1000], row_mask=state[:1000])  # tiled kernel (M < 32768)
+    torch.testing.assert_close(y[:1000].float(), y_small.float(), rtol=2e-3, atol=2e-3)

@@ -19,7 +19,7 @@ SHAPES = [  # (name, M, N, K, act, residual)
     ("swin3.qkv", 2880, 4608, 1536, None, False), ("swin3.fc1", 2400, 6144, 1536, "gelu", False),
     ("swin3.fc2", 2400, 1536, 6144, None, True),
     ("enc.value_proj", 204600, 256, 256, None, False), ("enc.offsets", 204600, 320, 256, None, False),
-    ("enc.attw", 204600, 160, 256, None, False), ("enc.out_proj", 204600, 256, 256, None, True),
+    ("enc.attw", 204600, 160, 256, None, False), ("enc.off|attw", 204600, 480, 256, None, False), ("enc.out_proj", 204600, 256, 256, None, True),
     ("enc.ffn1", 204600, 2048, 256, "relu", False), ("enc.ffn2", 204600, 256, 2048, None, True),
     ("head.cls", 204600, 80, 256, None, False), ("dec.q", 900, 256, 256, None, False),
 ]
