@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -35,6 +35,9 @@ SIGNATURES = {
     "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp]),
     "codetr_encoder_geometry_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "codetr_row_max_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
+    "codetr_preprocess_u8_f16": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "codetr_preprocess_u8_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "codetr_batched_nms_f32": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float, _vp]),
     "codetr_mask_pyramid": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "codetr_linear_splitk_plan": (_i32, [_i64, _i64, _i64, _vp]),
     "codetr_linear_splitk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
@@ -59,7 +62,7 @@ _lib = None
 # that the HIP kernels -- not a library path -- served a run
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
-         "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0}
+         "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0}
 
 
 def load():
@@ -199,6 +202,35 @@ def row_max(x2d):
     rc = load().codetr_row_max_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), out.data_ptr(), rows, C)
     check(rc, "codetr_row_max_f16")
     return out
+
+
+def preprocess_u8(src, resized_hw, pad_hw, mean, std, pad_value, dtype, with_mask=True):
+    """src [H, W, 3] uint8 on the device -> (inputs [3, Hp, Wp] dtype, mask [Hp, Wp] dtype or None)"""
+    CALLS["preprocess"] += 1
+    if dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("preprocess_u8 writes f16 or f32")
+    Hs, Ws, _ = src.shape
+    (Hr, Wr), (Hp, Wp) = resized_hw, pad_hw
+    dst = torch.empty((3, Hp, Wp), dtype=dtype, device=src.device)
+    mask = torch.empty((Hp, Wp), dtype=dtype, device=src.device) if with_mask else None
+    f3 = ctypes.c_float * 3
+    fn = load().codetr_preprocess_u8_f16 if dtype == torch.float16 else load().codetr_preprocess_u8_f32
+    rc = fn(current_stream_ptr(src.device), src.data_ptr(), Hs, Ws, Hr, Wr, Hp, Wp, f3(*[float(v) for v in mean]),
+            f3(*[float(v) for v in std]), (ctypes.c_int * 3)(*[int(v) for v in pad_value]), dst.data_ptr(),
+            mask.data_ptr() if mask is not None else None)
+    check(rc, "codetr_preprocess_u8")
+    return dst, mask
+
+
+def batched_nms_sorted(boxes_sorted, labels_sorted, iou_threshold):
+    """boxes [N,4] fp32 / labels [N] int64 in descending score order -> keep flags [N] bool"""
+    CALLS["batched_nms"] += 1
+    N = boxes_sorted.shape[0]
+    keep = torch.empty((N,), dtype=torch.bool, device=boxes_sorted.device)
+    rc = load().codetr_batched_nms_f32(current_stream_ptr(boxes_sorted.device), boxes_sorted.data_ptr(),
+                                       labels_sorted.data_ptr(), N, float(iou_threshold), keep.data_ptr())
+    check(rc, "codetr_batched_nms_f32")
+    return keep
 
 
 def mask_pyramid(img_masks, shapes):

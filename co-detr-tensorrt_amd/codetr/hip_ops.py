@@ -21,7 +21,8 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "sine_pos_tokens(f16, + level_embed)", "ffn_fused(f16, 256 -> hidden -> 256, ReLU, + identity)",
           "mask_pyramid(level masks + running valid counts + valid ratios)",
           "query_sine_embed(f16: sigmoid x valid ratios + sine embedding of the decoder reference boxes)",
-          "encoder_geometry(f16: reference points, proposals, keep/drop state)", "row_max(f16)"}
+          "encoder_geometry(f16: reference points, proposals, keep/drop state)", "row_max(f16)",
+          "preprocess_image(u8 -> f16/f32, cv2-exact resize + pad + normalise + mask)", "batched_nms(f32)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -241,6 +242,29 @@ def row_max(x):
         return x.max(-1)[0]
     with torch.cuda.device(x.device):
         return _cabi.row_max(x.view(-1, x.shape[-1])).view(x.shape[:-1])
+
+
+def preprocess_image(src_u8, resized_hw, pad_hw, mean, std, pad_value=(0, 0, 0), dtype=torch.float16):
+    """uint8 HWC RGB image on the GPU -> (normalised [3, Hp, Wp], mask [Hp, Wp]): cv2-exact bilinear resize to
+    `resized_hw`, right / bottom padding with `pad_value` to `pad_hw`, (x - mean) / std (csrc/prepost.hip)."""
+    _gpu(src_u8, "preprocess_image")
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 3 or src_u8.shape[2] != 3:
+        raise ValueError("expected a uint8 [H, W, 3] image")
+    with torch.cuda.device(src_u8.device):
+        return _cabi.preprocess_u8(src_u8.contiguous(), resized_hw, pad_hw, mean, std, pad_value, dtype)
+
+
+def batched_nms(boxes, scores, labels, iou_threshold):
+    """torchvision.ops.batched_nms semantics (per-class greedy hard NMS): indices of the kept boxes in descending
+    score order.  IoU arithmetic in fp32 on the given boxes."""
+    _gpu(boxes, "batched_nms")
+    if boxes.shape[0] == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    order = torch.sort(scores.float(), descending=True, stable=True)[1]
+    with torch.cuda.device(boxes.device):
+        keep = _cabi.batched_nms_sorted(boxes.float()[order].contiguous(), labels.to(torch.int64)[order].contiguous(),
+                                        iou_threshold)
+    return order[keep]
 
 
 def mask_pyramid(img_masks, shapes):

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 17
+#define CODETR_HIP_ABI_VERSION 18
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -239,6 +239,34 @@ int codetr_encoder_geometry_f16(void *stream, const void *valid_ratios_dev, cons
 /* out[r] = max_c x[r, c] (NaN propagates, as torch.max): enc_outputs_class.max(-1)[0], the ranking score of
  * the two-stage top-k (codetr/transformer.py:560).  x [rows, C] f16 dense, out [rows] f16. */
 int codetr_row_max_f16(void *stream, const void *x_dev, void *out_dev, int64_t rows, int64_t C);
+
+/* ------------------------------------------------------------------------------------------
+ * Pre- and post-processing either side of CoDETR.forward (the reference's Inferencer, codetr/inferencer.py).
+ *
+ * codetr_preprocess_u8_*: one image, uint8 HWC RGB on the device -> normalised CHW in the model dtype + padding mask.
+ *   Replaces the CPU test pipeline + DetDataPreprocessor + mask loop (codetr/inferencer.py:439-452, 354-358; configs
+ *   co_dino_5scale_swin_l_16xb1_16e_o365tococo.py:88-96): mmdet Resize(keep_ratio) = cv2.resize(INTER_LINEAR) with
+ *   OpenCV's 8-bit fixed-point arithmetic, Pad(size, pad_val) to the right / bottom, (x - mean) / std in fp32.
+ *     src_dev            [H_src, W_src, 3] uint8
+ *     H_resized/W_resized  size of the resized image (host: int(dim * factor + 0.5), mmcv.imrescale)
+ *     H_pad/W_pad        output size (>= resized size)
+ *     mean_host/std_host/pad_value_host   HOST arrays of 3 (per channel, in 0..255 units; pad value is a uint8 pixel
+ *                        value that is normalised like the image, as Pad runs before the normalisation)
+ *     dst_dev            [3, H_pad, W_pad]; mask_dev [H_pad, W_pad] (same dtype, 0 inside the image, 1 in the padding)
+ *                        or NULL
+ * codetr_batched_nms_f32: torchvision.ops.batched_nms of postprocess_predictions (codetr/inferencer.py:388-398):
+ *   greedy per-class hard NMS, IoU > iou_threshold suppresses.  boxes_sorted_dev [N, 4] fp32 xyxy and
+ *   labels_sorted_dev [N] int64 in DESCENDING SCORE ORDER; keep_dev [N] uint8 out (1 = kept).  One workgroup (N is
+ *   <= 300 on this path; up to 60 000 accepted).
+ * ------------------------------------------------------------------------------------------ */
+int codetr_preprocess_u8_f16(void *stream, const void *src_dev, int64_t H_src, int64_t W_src, int64_t H_resized,
+                             int64_t W_resized, int64_t H_pad, int64_t W_pad, const float *mean_host,
+                             const float *std_host, const int *pad_value_host, void *dst_dev, void *mask_dev);
+int codetr_preprocess_u8_f32(void *stream, const void *src_dev, int64_t H_src, int64_t W_src, int64_t H_resized,
+                             int64_t W_resized, int64_t H_pad, int64_t W_pad, const float *mean_host,
+                             const float *std_host, const int *pad_value_host, void *dst_dev, void *mask_dev);
+int codetr_batched_nms_f32(void *stream, const float *boxes_sorted_dev, const int64_t *labels_sorted_dev, int64_t N,
+                           float iou_threshold, void *keep_dev);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension: y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta
