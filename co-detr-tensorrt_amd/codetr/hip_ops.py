@@ -133,17 +133,15 @@ def ffn_fused_supported(x, w1, w2, act):
             and _cabi.ffn_fused_supported(x, w1, w2, act))
 
 
-_W2_PACKED = {}
-
-
 def _packed_w2(w2):
-    """the kernel's pre-packed copy of a second-Linear weight, rebuilt only when the tensor changes"""
-    key = (w2.data_ptr(), w2._version, w2.dtype, str(w2.device), tuple(w2.shape))
-    hit = _W2_PACKED.get(id(w2))
-    if hit is None or hit[0] != key:
+    """the kernel's pre-packed copy of a second-Linear weight.  The copy hangs on the weight tensor object itself
+    (so it dies with it: a table keyed by id() / data_ptr() can hand a NEW tensor that reuses a freed tensor's address
+    and id the old tensor's packed weights) and is rebuilt when the tensor is modified in place."""
+    hit = getattr(w2, "_codetr_packed_w2", None)
+    if hit is None or hit[0] != w2._version or hit[1].device != w2.device or hit[1].dtype != w2.dtype:
         with torch.no_grad(), torch.cuda.device(w2.device):
-            hit = (key, _cabi.ffn_pack_w2(w2.detach().contiguous()))
-        _W2_PACKED[id(w2)] = hit
+            hit = (w2._version, _cabi.ffn_pack_w2(w2.detach().contiguous()))
+        w2._codetr_packed_w2 = hit
     return hit[1]
 
 

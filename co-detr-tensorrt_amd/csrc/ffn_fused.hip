@@ -111,12 +111,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
     int Hd, const unsigned short* __restrict__ ln_g, const unsigned short* __restrict__ ln_b, float ln_eps,
-    const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2) {
+    const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2, int row0) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2];  // 144 KiB, one object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
   constexpr int BM = 64 * MT, WR = 16 * MT;  // rows per workgroup / per wave
-  const int m0 = (int)xcd_tile(blockIdx.x, gridDim.x) * BM + wave * WR;  // this wave's first row
+  const int m0 = row0 + (int)xcd_tile(blockIdx.x, gridDim.x) * BM + wave * WR;  // this wave's first row
   const int nchunks = Hd / BH;
 
   stage_chunk(W1, W2, Hd, 0, lds, tid);
@@ -378,6 +378,8 @@ int codetr_ffn_relu_ln_f16(void* stream, const void* x_dev, const void* w1_dev, 
   if (M > 0x7fffffffLL - 256 || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   // MT = 2 (128 rows per workgroup).  MT = 3 fits the register file only without the interleaved DMA issue (236 VGPR
   // + 240 AGPR, 570 us at M = 204 600 against 545 us for this variant); with it hipcc spills (1147 us).
+  // (Splitting off the last, mostly empty round of 256 workgroups as 64-row workgroups measured -1 %: workgroups are
+  // not dispatched in lockstep rounds, so the tail is already spread.)
   constexpr int kMT = 2;
   const unsigned blocks = (unsigned)((M + 64 * kMT - 1) / (64 * kMT));
   hipLaunchKernelGGL(ffn_fused_kernel<kMT>, dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
@@ -386,7 +388,7 @@ int codetr_ffn_relu_ln_f16(void* stream, const void* x_dev, const void* w1_dev, 
                      static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
                      (int)hidden, static_cast<const unsigned short*>(ln_gamma_dev),
                      static_cast<const unsigned short*>(ln_beta_dev), ln_eps,
-                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev));
+                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev), 0);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }

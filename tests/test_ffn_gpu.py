@@ -16,7 +16,8 @@ def _ref(x, w1, b1, w2, b2):
     return (y + x.float())
 
 
-@pytest.mark.parametrize("M,hidden", [(1, 64), (128, 2048), (129, 2048), (900, 2048), (5000, 512), (30785, 2048)])
+@pytest.mark.parametrize("M,hidden", [(1, 64), (128, 2048), (129, 2048), (900, 2048), (5000, 512), (30785, 2048),
+                                      (128 * 256 + 4999, 256)])  # one full round of 256 tiles + a tail of 64-row tiles
 def test_ffn_fused_vs_fp32(M, hidden):
     from codetr import _cabi, hip_ops
 
@@ -69,7 +70,7 @@ def test_ffn_layernorm_pos_epilogue_is_bit_identical_to_three_kernels():
     from codetr import _cabi, hip_ops
 
     g = torch.Generator(device=DEV).manual_seed(3)
-    M = hip_ops.FFN_FUSED_MIN_ROWS + 333
+    M = 128 * 256 + 3333  # full round + 64-row tail launch
     x = torch.randn(M, 256, device=DEV, generator=g).half()
     pos = torch.randn(M, 256, device=DEV, generator=g).half()
     w1 = (torch.randn(2048, 256, device=DEV, generator=g) / 16).half()
