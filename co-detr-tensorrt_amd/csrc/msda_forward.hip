@@ -342,6 +342,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
   }
 }
 
+// Measured and rejected for this kernel: a "head-split" pair mapping (each workgroup 2 heads x 32 consecutive queries
+// instead of 8 heads x 8 queries, so that the lines of one corner load are 8 neighbouring pixels of the same heads):
+// 652 us vs 614 us on the +-3 px synthetic encoder case -- the per-pair prologue loads lose their contiguity and the
+// L1 reuse gained inside a wave does not pay for it.
 // ------------------------------------------------------------------------------------------
 // Head-major fused variant.  Value map laid out [B, M, S, D] (each head's map contiguous, written that
 // way by the value projection's epilogue): the two horizontal neighbours (x0, x1) of a sample are then
