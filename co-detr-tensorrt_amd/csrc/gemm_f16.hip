@@ -618,6 +618,217 @@ int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, c
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile for the large layers (Swin stages 2-3 at 8 images per GPU: M = 77-81 k rows).  A 128 x 128 x 64 tile
+// step moves 32 KB of operands through the CU's vector-memory path per 2.1 MFLOP -- 64 B/clk per CU at MFMA peak,
+// which IS that path's rate, so the tiled kernel above tops out near 0.9 PF while hipBLASLt's 256-wide macro tiles
+// reach 1.1-1.4 PF on these shapes.  Here: 512 threads = 8 waves (2 along m x 4 along n), each wave 128(m) x 64(n) =
+// 8 x 4 MFMA tiles (128 accumulator registers); one workgroup per CU (2 x 64 KiB of LDS: W tile 256 x 64 + X tile
+// 256 x 64 per stage); 32 B/clk per CU of operand traffic and 12 fragment reads per 32 MFMAs.  Same LDS image,
+// swizzle, bias-in-accumulator and LDS-staged epilogue (in two 64-row halves) as linear_kernel.
+template <class T, int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* __restrict__ X,
+                                                         const unsigned short* __restrict__ W,
+                                                         const unsigned short* __restrict__ bias,
+                                                         const unsigned short* __restrict__ R,
+                                                         unsigned short* __restrict__ Y,
+                                                         const unsigned char* __restrict__ row_mask, int M, int N, int K,
+                                                         int tiles_n) {
+  constexpr int BKT = 64, NT = 512;
+  constexpr int kTileBytes = 256 * BKT * 2;   // 32 KiB: one operand tile
+  constexpr int kStageBytes = 2 * kTileBytes;  // W tile + X tile
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes];  // 128 KiB, one object
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int frow = lane & 15, fchunk = lane >> 4, ncol = 4 * (lane >> 4);
+
+  f32x4 acc[4][8];  // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_BIAS) {
+      const int n = n0 + wn * 64 + i * 16 + ncol;
+      if (n < N) {  // N % 8 == 0 on this path
+        const s16x4 bb = *reinterpret_cast<const s16x4*>(bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[r] = T::to_f32((unsigned short)bb[r]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = b4;
+  }
+
+  // per-thread source pointers of the 4 + 4 LDS-DMA pieces of a stage (piece q covers rows q*64 + tid/8)
+  const unsigned short* gw[4];
+  const unsigned short* gx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = q * 64 + (tid >> 3), pos = tid & 7;
+    const int chunk = pos ^ sw<BKT>(r);
+    int gn = n0 + r, gm = m0 + r;
+    gn = gn < N ? gn : N - 1;
+    gm = gm < M ? gm : M - 1;
+    gw[q] = W + (size_t)gn * K + chunk * 8;
+    gx[q] = X + (size_t)gm * K + chunk * 8;
+  }
+  auto issue = [&](int t) {
+    unsigned char* buf = lds + (t & 1) * kStageBytes;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned char* l = buf + (q * NT + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[q] + (size_t)t * BKT),
+                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned char* l = buf + kTileBytes + (q * NT + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx[q] + (size_t)t * BKT),
+                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+  };
+  const int nk = K / BKT;
+  issue(0);
+  for (int t = 0; t < nk; ++t) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // tile t is in LDS for everyone; everyone is done reading tile t-1
+    const unsigned char* bufW = lds + (t & 1) * kStageBytes;
+    const unsigned char* bufX = bufW + kTileBytes;
+    // One workgroup per CU: its 8 waves reach this point together, so nothing else covers a burst of DMA issue or an
+    // LDS wait.  The schedule is pinned: fragments of k-step 1 are read behind the first two MFMAs of step 0, and the
+    // 8 DMA pieces of tile t+1 go out one per 3 MFMAs of step 0 (early enough to land under step 1).  Past the last
+    // tile the pieces re-fetch it into the idle buffer (no branch in the pinned region); drained before the epilogue.
+    const size_t koff = (size_t)(t + 1 < nk ? t + 1 : t) * BKT;
+    unsigned char* nbuf = lds + ((t + 1) & 1) * kStageBytes;
+    typename T::frag a[2][4], b[2][8];
+    auto read_frags = [&](int ks, int buf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[buf][i] = read_frag<T, BKT>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[buf][j] = read_frag<T, BKT>(bufX, wm * 128 + j * 16 + frow, ks * 4 + fchunk);
+    };
+    read_frags(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+    // ---- k-step 0 ----
+    read_frags(1, 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[q] + koff),
+                                       (__attribute__((address_space(3))) void*)(nbuf + (q * NT + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx[q] + koff),
+                                       (__attribute__((address_space(3))) void*)(nbuf + kTileBytes + (q * NT + wave * 64) * 16),
+                                       16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = T::mfma(a[0][i], b[0][j], acc[i][j]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    // ---- k-step 1 ----
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = T::mfma(a[1][i], b[1][j], acc[i][j]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+  }
+  wait_vmcnt<0>();  // the redundant pieces of the last iteration have landed
+  __builtin_amdgcn_s_barrier();  // all fragment reads done, no DMA in flight: LDS is free for the epilogue
+
+  // epilogue in two 64-row halves per wave through its private staging region (64 rows x 144 B)
+  constexpr int kPitch = kStagePitch;
+  unsigned char* stage = lds + wave * (64 * kPitch);
+  const int srow = lane >> 3, schunk = lane & 7;
+  const int n = n0 + wn * 64 + schunk * 8;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[i][h * 4 + j][r];
+          if (ACT == 1) x = x < 0.f ? 0.f : x;
+          if (ACT == 2) x = gelu_erf(x);
+          v[r] = x;
+        }
+        *reinterpret_cast<s16x4*>(stage + (j * 16 + frow) * kPitch + (i * 16 + ncol) * 2) = T::pack4(v);
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int ml = it * 8 + srow;
+      const int m = m0 + wm * 128 + h * 64 + ml;
+      if (m < M && n < N) {
+        s16x8 v = *reinterpret_cast<const s16x8*>(stage + ml * kPitch + schunk * 16);
+        if (row_mask) {
+          const unsigned char mk = row_mask[m];
+          if (mk == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = HAS_BIAS ? T::to_f32(bias[n + e]) : 0.f;
+              if (ACT == 1) x = x < 0.f ? 0.f : x;
+              if (ACT == 2) x = gelu_erf(x);
+              v[e] = (short)T::from_f32(x);
+            }
+          } else if (mk) {
+            v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          }
+        }
+        const size_t off = (size_t)m * N + n;
+        if (HAS_RES) {
+          const s16x8 rr = *reinterpret_cast<const s16x8*>(R + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[e]));
+        }
+        *reinterpret_cast<s16x8*>(Y + off) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the region is rewritten by the second half
+  }
+}
+
+// the 256-tile kernel is used when it fills the chip at least twice over and N wastes little of a 256-wide tile
+bool big_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
+  static const int off = [] {
+    const char* e = getenv("CODETR_GEMM_BIG");
+    return e ? atoi(e) == 0 : 0;
+  }();
+  if (off || hm_hd != 0 || K < 512 || K % 64 != 0 || N % 8 != 0) return false;
+  const int64_t tn = (N + 255) / 256, tm = (M + 255) / 256;
+  return tm * tn >= 512 && N * 8 >= tn * 256 * 7;  // >= 87.5 % of the tile columns are real
+}
+
+template <class T, int ACT>
+int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
+               int M, int N, int K) {
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
+  auto x = static_cast<const unsigned short*>(X);
+  auto w = static_cast<const unsigned short*>(W);
+  auto b = static_cast<const unsigned short*>(bias);
+  auto r = static_cast<const unsigned short*>(R);
+  auto y = static_cast<unsigned short*>(Y);
+  auto mk = static_cast<const unsigned char*>(mask);
+  if (bias && R) hipLaunchKernelGGL((linear_256_kernel<T, ACT, true, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else if (bias) hipLaunchKernelGGL((linear_256_kernel<T, ACT, true, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else if (R) hipLaunchKernelGGL((linear_256_kernel<T, ACT, false, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  else hipLaunchKernelGGL((linear_256_kernel<T, ACT, false, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // X-stationary kernel for the short-K layers (K = 192, 256, 384: Swin stages 0-1 and every 256-wide transformer
 // layer -- a third of the model's GEMM time).  The tiled kernel above re-reads each 128 x K activation tile from L2
 // once per 128-column output tile and pays its fixed per-tile cost (first loads, staging, stores) N/128 times; with
@@ -846,6 +1057,14 @@ int launch(hipStream_t st, const void* X, const void* W, const void* bias, const
   if (hm_hd != 0 || hm_rows != 0) {
     if (hm_hd <= 0 || hm_rows <= 0 || hm_hd % 8 != 0 || N % hm_hd != 0 || N % 8 != 0 || M % hm_rows != 0 || R)
       return CODETR_E_UNSUPPORTED;
+  }
+  if (big_applicable(M, N, K, hm_hd) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0)) {
+    switch (act) {
+      case 0: return launch_big<T, 0>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
+      case 1: return launch_big<T, 1>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
+      default: return launch_big<T, 2>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
+    }
   }
   if (xs_applicable(M, N, K, hm_hd) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
       (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0))

@@ -221,3 +221,34 @@ def test_linear_short_k_row_masks():
     import os
     y_small = hip_ops.linear(x[:1000], w, b, act="relu", residual=r[:1000], row_mask=state[:1000])  # tiled kernel (M < 32768)
     torch.testing.assert_close(y[:1000].float(), y_small.float(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,bias,act,res", [
+    (32768, 1024, 512, True, None, False),      # exactly 512 tiles of 256 x 256
+    (33000, 1000, 768, True, "gelu", False),    # ragged M and N (N % 8 == 0), GELU epilogue
+    (40000, 768, 1024, True, None, True),       # + identity
+    (36000, 1024, 576, False, "relu", True),    # no bias, K = 9 steps of 64
+])
+def test_linear_256_tile_kernel(M, N, K, bias, act, res, dtype):
+    """>= 512 tiles of 256 x 256 with K >= 512 run linear_256_kernel (8 waves, 128 x 64 per wave); same tolerance."""
+    _check(M, N, K, dtype, bias, act, res, seed=31)
+
+
+def test_linear_256_tile_row_states():
+    from codetr import hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(12)
+    M, N, K = 33333, 1024, 512
+    x = torch.randn(M, K, device=DEV, generator=g).half()
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).half()
+    b = torch.randn(N, device=DEV, generator=g).half()
+    state = torch.zeros(M, dtype=torch.uint8, device=DEV)
+    state[::5] = 1
+    state[2::11] = 2
+    y = hip_ops.linear(x, w, b, row_mask=state)
+    ref = (x.float() @ w.float().t() + b.float()).half()
+    ref[state == 1] = 0
+    ref[state == 2] = b
+    torch.testing.assert_close(y.float(), ref.float(), rtol=2e-3, atol=4e-3)
+    assert torch.equal(y[state == 1], torch.zeros_like(y[state == 1])) and torch.equal(y[state == 2], ref[state == 2])

@@ -1,0 +1,18 @@
+import sys, os
+sys.path.insert(0, "tools"); sys.path.insert(0, "co-detr-tensorrt_amd")
+import torch, torch.nn.functional as F
+from bench_linear import timeit
+from codetr import hip_ops
+S = [("swin2.qkv", 80640, 2304, 768, None, False), ("swin2.proj", 80640, 768, 768, None, True),
+     ("swin2.fc1", 76800, 3072, 768, "gelu", False), ("swin2.fc2", 76800, 768, 3072, None, True),
+     ("swin3.qkv", 23040, 4608, 1536, None, False), ("swin3.fc1", 19200, 6144, 1536, "gelu", False),
+     ("swin3.fc2", 19200, 1536, 6144, None, True), ("swin1.qkv", 322560, 1152, 384, None, False),
+     ("swin1.fc1", 307200, 1536, 384, "gelu", False), ("swin1.fc2", 307200, 384, 1536, None, True),
+     ("swin0.fc2", 1228800, 192, 768, None, True)]
+for name, M, N, K, act, res in S:
+    x = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda").half(); r = torch.randn(M, N, device="cuda").half() if res else None
+    tn = timeit(lambda: hip_ops.linear(x, w, b, act=act, residual=r))
+    tg = timeit(lambda: F.linear(x, w, b))   # GEMM + bias only (no act / residual kernels)
+    fl = 2.0 * M * N * K
+    print(f"{name:12s} M={M:8d} N={N:5d} K={K:5d}  native {tn*1e6:8.1f} us {fl/tn/1e12:7.1f} TF/s | hipBLASLt gemm+bias only {tg*1e6:8.1f} us {fl/tg/1e12:7.1f} TF/s")
