@@ -625,6 +625,15 @@ int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, c
 // 8 x 4 MFMA tiles (128 accumulator registers); one workgroup per CU (2 x 64 KiB of LDS: W tile 256 x 64 + X tile
 // 256 x 64 per stage); 32 B/clk per CU of operand traffic and 12 fragment reads per 32 MFMAs.  Same LDS image,
 // swizzle, bias-in-accumulator and LDS-staged epilogue (in two 64-row halves) as linear_kernel.
+// Ablation at 8 images (M = 80 640, us): main loop only / full kernel = qkv 287 / 379, proj+res 87 / 161, fc1+GELU
+// 314 / 520, fc2+res 355 / 412 -- the main loop runs at 1.0-1.15 PF (hipBLASLt: 1.1-1.2 PF including its store), the
+// epilogue costs 25-40 % on top.  Two attempts to hide it, both measured slower and removed: (a) a 256 x 128 / 4-wave /
+// BK 32 variant with two workgroups per CU so that one's epilogue overlaps the other's MFMAs (423 vs 384 us on qkv:
+// the main loop loses more than the overlap returns); (b) a persistent variant that parks the finished fp16 tile in
+// 96 KiB of LDS + 16 registers and writes it back one store per K step of the next tile, with the stores allowed to
+// stay in flight across barriers (450 vs 376 us: the write-back costs the same trickled as in bulk, so it is not
+// issue latency -- most likely the 372 MB of output passing through the L2 / Infinity Cache evicts the activation
+// rows every column tile re-reads).  Next thing to try: non-temporal stores with a column-major tile walk.
 template <class T, int ACT, bool HAS_BIAS, bool HAS_RES>
 __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* __restrict__ X,
                                                          const unsigned short* __restrict__ W,
