@@ -410,6 +410,18 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
     __builtin_amdgcn_wave_barrier();  // same wave writes then reads: DS ops retire in order
     const int srow = lane >> 3, schunk = lane & 7;
     const int n = n0 + wn * 64 + schunk * 8;
+    // residual rows, all requested before the first use (one exposed latency instead of eight); the head-major
+    // destination never carries a residual
+    s16x8 rres[8];
+    if (HAS_RES) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        int m = m0 + wm * 64 + it * 8 + srow;
+        m = m < M ? m : M - 1;
+        const int nn = n + 8 <= N ? n : (N >= 8 ? N - 8 : 0);
+        rres[it] = *reinterpret_cast<const s16x8*>(R + (size_t)m * N + nn);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int ml = it * 8 + srow;
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
           off = (((size_t)bb * (N / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
         }
         if (HAS_RES) {
-          const s16x8 rr = *reinterpret_cast<const s16x8*>(R + off);
+          const s16x8 rr = rres[it];
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[e]));
@@ -773,6 +785,17 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
         *reinterpret_cast<s16x4*>(stage + (j * 16 + frow) * kPitch + (i * 16 + ncol) * 2) = T::pack4(v);
       }
     __builtin_amdgcn_wave_barrier();
+    // residual rows of this half, all requested before the first use (one exposed latency instead of eight)
+    s16x8 rres[8];
+    if (HAS_RES) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        int m = m0 + wm * 128 + h * 64 + it * 8 + srow;
+        m = m < M ? m : M - 1;
+        const int nn = n + 8 <= N ? n : N - 8;
+        rres[it] = *reinterpret_cast<const s16x8*>(R + (size_t)m * N + nn);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int ml = it * 8 + srow;
@@ -795,7 +818,7 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
         }
         const size_t off = (size_t)m * N + n;
         if (HAS_RES) {
-          const s16x8 rr = *reinterpret_cast<const s16x8*>(R + off);
+          const s16x8 rr = rres[it];
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[e]));
