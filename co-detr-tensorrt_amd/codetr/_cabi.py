@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -25,6 +25,12 @@ SIGNATURES = {
     "codetr_msda_forward_bf16": (_i32, _MSDA_ARGS),
     "codetr_msda_forward_f32": (_i32, _MSDA_ARGS),
     "codetr_msda_forward_f64": (_i32, _MSDA_ARGS),
+    "codetr_msda_backward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i32, _i64,
+                                        _vp, _vp, _vp]),
+    "codetr_msda_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i32, _i64,
+                                        _vp, _vp, _vp]),
+    "codetr_msda_backward_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i32, _i64,
+                                        _vp, _vp, _vp]),
     "codetr_msda_variant": (_cp, [_i32, _i32, _i32, _i32, _i32]),
     "codetr_msda_fused_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _i64,
                                              _i32, _i32, _i32, _i64, _i32, _vp]),
@@ -62,7 +68,8 @@ _lib = None
 # that the HIP kernels -- not a library path -- served a run
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
-         "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0}
+         "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
+         "msda_backward": 0}
 
 
 def load():
@@ -176,6 +183,28 @@ def query_sine_embed(ref, valid_ratios, pos_feat, temperature=10000.0, apply_sig
                                             ref_in.data_ptr(), embed.data_ptr())
     check(rc, "codetr_query_sine_embed_f16")
     return ref_in, embed
+
+
+_MSDA_BWD = {torch.float16: "codetr_msda_backward_f16", torch.float32: "codetr_msda_backward_f32",
+             torch.float64: "codetr_msda_backward_f64"}
+
+
+def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
+                  grad_sampling_loc, grad_attn_weight, im2col_step):
+    """gradients accumulated into the three (pre-zeroed) output tensors, see include/codetr_hip.h"""
+    if value.dtype not in _MSDA_BWD:
+        raise RuntimeError(f"multi_scale_deformable_attention_backward: unsupported dtype {value.dtype} (f16 / f32 / f64)")
+    CALLS["msda_backward"] += 1
+    B, S, M, D = value.shape
+    Nq, L, P = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+    rc = getattr(load(), _MSDA_BWD[value.dtype])(
+        current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+        sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(), B, S, M, D, L, Nq, P, int(im2col_step),
+        grad_value.data_ptr(), grad_sampling_loc.data_ptr(), grad_attn_weight.data_ptr())
+    if rc == -2:
+        step = min(B, int(im2col_step))
+        raise RuntimeError(f"batch({B}) must divide im2col_step({step})")
+    check(rc, "codetr_msda_backward")
 
 
 def encoder_geometry(valid_ratios, mask_flat, shapes):

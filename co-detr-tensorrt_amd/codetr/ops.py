@@ -15,8 +15,9 @@ Host-side mirror of the reference's operator layer for the inference hot path:
 * the argument contract enforced before the launch is the reference's AT_ASSERTM list
   (ms_deform_attn.cu:902-933): contiguous, on device, ``batch % min(batch, im2col_step) == 0``.
 
-Out of scope here: the backward op.  Its schema is defined so the
-namespace matches, and calling it raises.
+The backward op is implemented too (csrc/msda_backward.hip) and wired into autograd exactly as
+the reference does (reference codetr/ops.py:90-126): zero-filled gradient tensors, one call of
+``multi_scale_deformable_attention_backward``, gradients for value / sampling_loc / attn_weight.
 """
 import torch
 from torch import Tensor
@@ -95,11 +96,31 @@ def _msda_forward_hip(
     return out
 
 
-def _msda_backward_hip(*args, **kwargs):
-    raise NotImplementedError(
-        "codetr::multi_scale_deformable_attention_backward: training backward is outside the "
-        "inference hot path of this build (SURVEY.md 8(f)-4)"
-    )
+def _msda_backward_hip(
+    value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor, sampling_loc: Tensor, attn_weight: Tensor,
+    grad_output: Tensor, grad_value: Tensor, grad_sampling_loc: Tensor, grad_attn_weight: Tensor, im2col_step: int,
+) -> None:
+    """reference ms_deform_attn_backward (ms_deform_attn.cu:975-1028): accumulates into the caller's zero-filled
+    gradient tensors"""
+    _check_contract(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    for name, t, ref in (("grad_output", grad_output, None), ("grad_value", grad_value, value),
+                         ("grad_sampling_loc", grad_sampling_loc, sampling_loc),
+                         ("grad_attn_weight", grad_attn_weight, attn_weight)):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+        if not t.is_cuda or t.device != value.device or t.dtype != value.dtype:
+            raise RuntimeError(f"{name} must be a CUDA tensor of value's dtype on value's device")
+        if ref is not None and t.shape != ref.shape:
+            raise RuntimeError(f"{name} must have the shape of its primal {tuple(ref.shape)}")
+    B, _, M, D = value.shape
+    Nq = sampling_loc.shape[1]
+    if tuple(grad_output.shape) != (B, Nq, M * D):
+        raise RuntimeError(f"grad_output shape {tuple(grad_output.shape)} != {(B, Nq, M * D)}")
+    if grad_output.numel() == 0:
+        return
+    with torch.cuda.device(value.device):
+        _cabi.msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            grad_value, grad_sampling_loc, grad_attn_weight, im2col_step)
 
 
 _lib.impl("multi_scale_deformable_attention", _msda_forward_hip, "CUDA")
@@ -134,6 +155,29 @@ def _multi_scale_deformable_attention_fake(value, spatial_shapes, level_start_in
     torch._check(attn_weight.shape[3] == num_levels)
     torch._check(attn_weight.shape[4] == num_points)
     return torch.empty((bs, num_queries, num_heads * dim_per_head), dtype=value.dtype, device=value.device)
+
+
+def _msda_autograd_backward(ctx, grad):
+    # reference codetr/ops.py:90-113
+    value, spatial_shapes, level_start_index, sampling_loc, attn_weight = ctx.saved_tensors
+    grad_value = torch.zeros_like(value)
+    grad_sampling_loc = torch.zeros_like(sampling_loc)
+    grad_attn_weight = torch.zeros_like(attn_weight)
+    torch.ops.codetr.multi_scale_deformable_attention_backward(
+        value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad.contiguous(), grad_value,
+        grad_sampling_loc, grad_attn_weight, im2col_step=ctx.im2col_step)
+    return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+
+def _msda_autograd_setup(ctx, inputs, output):
+    # reference codetr/ops.py:116-120
+    value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step = inputs
+    ctx.im2col_step = im2col_step
+    ctx.save_for_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+
+
+torch.library.register_autograd("codetr::multi_scale_deformable_attention", _msda_autograd_backward,
+                                setup_context=_msda_autograd_setup)
 
 
 def multi_scale_deformable_attention(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,

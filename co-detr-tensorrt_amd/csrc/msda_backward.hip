@@ -1,0 +1,184 @@
+// Backward of multi-scale deformable attention: gradients w.r.t. the value map, the
+// sampling locations and the attention weights.
+//
+// Arithmetic of the reference's col2im kernels (reference codetr/csrc/ms_deform_attn.cu:79-146 bilinear gradient,
+// :263-760 kernel family, :781-897 launcher, :975-1028 wrapper): per output channel and sample point
+//   grad_value[corner]      += bilinear weight * attention weight * grad_out          (atomic: corners are shared)
+//   grad_attn_weight[point]  = sum_c grad_out * bilinear(value)
+//   grad_sampling_loc[point] = sum_c grad_out * attention weight * (W * d bilinear/dx, H * d bilinear/dy)
+// with the same range gate and per-corner bounds tests as the forward.  The caller pre-zeroes the three gradients
+// (reference ops.py:94-96).
+//
+// One lane per (image, query, head, channel), the D lanes of a pair adjacent: the reference's shared-memory serial
+// reduction over the block (cu:320-336) becomes log2(D) xor-shuffles inside the D-lane group, and lane 0 of the
+// group stores the two location gradients and the weight gradient (each point belongs to exactly one pair: plain
+// stores).  fp16: arithmetic in fp32, value-gradient atomics as packed 2 x f16 adds (global_atomic_pk_add_f16), even
+// lane carrying its neighbour's channel.  Training-path kernel: written for correctness, not tuned.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codetr_hip.h"
+
+namespace {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <class ST> struct BwdTraits;
+template <> struct BwdTraits<float> {
+  using AT = float;
+  static __device__ float ld(const float* p) { return *p; }
+  static __device__ void st(float* p, float v) { *p = v; }
+};
+template <> struct BwdTraits<double> {
+  using AT = double;
+  static __device__ double ld(const double* p) { return *p; }
+  static __device__ void st(double* p, double v) { *p = v; }
+};
+template <> struct BwdTraits<_Float16> {
+  using AT = float;
+  static __device__ float ld(const _Float16* p) { return (float)*p; }
+  static __device__ void st(_Float16* p, float v) { *p = (_Float16)v; }
+};
+
+template <class AT>
+__device__ __forceinline__ AT group_sum(AT v, int D) {
+  for (int o = D >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// value-gradient accumulation of one corner for this lane's channel
+template <class ST>
+__device__ __forceinline__ void add_value(ST* g, typename BwdTraits<ST>::AT v, int c) {
+  atomicAdd(g, v);
+}
+template <>
+__device__ __forceinline__ void add_value<_Float16>(_Float16* g, float v, int c) {
+  // even channel lanes add (own, neighbour) as one packed atomic; D is even and the address 4-byte aligned
+  const float nb = __shfl_down(v, 1, 64);
+  if ((c & 1) == 0) {
+    const f16x2 pk = {(_Float16)v, (_Float16)nb};
+    __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) f16x2*)g, pk);
+  }
+}
+
+template <class ST>
+__global__ __launch_bounds__(256) void msda_backward_kernel(const ST* __restrict__ grad_out, const ST* __restrict__ value,
+                                                            const int64_t* __restrict__ spatial_shapes,
+                                                            const int64_t* __restrict__ level_start,
+                                                            const ST* __restrict__ loc, const ST* __restrict__ weight,
+                                                            int64_t n_total, int S, int M, int D, int L, int Nq, int P,
+                                                            ST* __restrict__ grad_value, ST* __restrict__ grad_loc,
+                                                            ST* __restrict__ grad_w) {
+  using TR = BwdTraits<ST>;
+  using AT = typename TR::AT;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_total) return;  // n_total is a multiple of D: D-lane groups are all-in or all-out
+  const int c = (int)(idx % D);
+  const int64_t pair = idx / D;
+  const int m = (int)(pair % M);
+  const int64_t b = pair / ((int64_t)M * Nq);
+  const AT top = TR::ld(grad_out + idx);
+  const int64_t pt0 = pair * L * P;
+  const int w_stride = M * D;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)spatial_shapes[2 * l], W = (int)spatial_shapes[2 * l + 1];
+    const int64_t base = (b * S + level_start[l]) * (int64_t)w_stride + m * D + c;
+    const ST* vptr = value + base;
+    ST* gptr = grad_value + base;
+    for (int p = 0; p < P; ++p) {
+      const int64_t pt = pt0 + l * P + p;
+      const AT loc_w = TR::ld(loc + 2 * pt), loc_h = TR::ld(loc + 2 * pt + 1);
+      const AT aw = TR::ld(weight + pt);
+      const AT h_im = loc_h * H - (AT)0.5, w_im = loc_w * W - (AT)0.5;
+      AT g_a = 0, g_x = 0, g_y = 0;
+      const bool gate = h_im > -1 && w_im > -1 && h_im < H && w_im < W;  // wave-uniform inside a pair
+      if (gate) {
+        const AT hf = floor(h_im), wf = floor(w_im);
+        const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
+        const AT lh = h_im - hf, lw = w_im - wf, hh = 1 - lh, hw = 1 - lw;
+        const AT w1c = hh * hw, w2c = hh * lw, w3c = lh * hw, w4c = lh * lw;
+        const AT tgv = top * aw;
+        AT gh = 0, gw = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+        const int64_t o00 = ((int64_t)h0 * W + w0) * w_stride;
+        if (h0 >= 0 && w0 >= 0) {
+          v1 = TR::ld(vptr + o00);
+          gh -= hw * v1;
+          gw -= hh * v1;
+          add_value<ST>(gptr + o00, w1c * tgv, c);
+        }
+        if (h0 >= 0 && w1 <= W - 1) {
+          v2 = TR::ld(vptr + o00 + w_stride);
+          gh -= lw * v2;
+          gw += hh * v2;
+          add_value<ST>(gptr + o00 + w_stride, w2c * tgv, c);
+        }
+        if (h1 <= H - 1 && w0 >= 0) {
+          v3 = TR::ld(vptr + o00 + (int64_t)W * w_stride);
+          gh += hw * v3;
+          gw -= lh * v3;
+          add_value<ST>(gptr + o00 + (int64_t)W * w_stride, w3c * tgv, c);
+        }
+        if (h1 <= H - 1 && w1 <= W - 1) {
+          v4 = TR::ld(vptr + o00 + (int64_t)W * w_stride + w_stride);
+          gh += lw * v4;
+          gw += lh * v4;
+          add_value<ST>(gptr + o00 + (int64_t)W * w_stride + w_stride, w4c * tgv, c);
+        }
+        g_a = top * (w1c * v1 + w2c * v2 + w3c * v3 + w4c * v4);
+        g_x = W * gw * tgv;
+        g_y = H * gh * tgv;
+      }
+      g_a = group_sum<AT>(g_a, D);
+      g_x = group_sum<AT>(g_x, D);
+      g_y = group_sum<AT>(g_y, D);
+      if (c == 0) {
+        TR::st(grad_w + pt, g_a);
+        TR::st(grad_loc + 2 * pt, g_x);
+        TR::st(grad_loc + 2 * pt + 1, g_y);
+      }
+    }
+  }
+}
+
+template <class ST>
+int launch_bwd(void* stream, const void* value, const void* ss, const void* ls, const void* loc, const void* w,
+               const void* go, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step,
+               void* gv, void* gl, void* gw) {
+  if (!value || !ss || !ls || !loc || !w || !go || !gv || !gl || !gw) return CODETR_E_BADARG;
+  if (B < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Nq < 0 || P <= 0 || im2col_step <= 0) return CODETR_E_BADARG;
+  const int64_t step = B < im2col_step ? B : im2col_step;
+  if (B > 0 && B % step != 0) return CODETR_E_IM2COL_STEP;
+  if (B == 0 || Nq == 0) return 0;
+  if (D > 64 || (D & (D - 1)) != 0) return CODETR_E_UNSUPPORTED;         // the D lanes of a pair reduce by xor-shuffle
+  if (sizeof(ST) == 2 && D < 2) return CODETR_E_UNSUPPORTED;              // packed f16 atomics need channel pairs
+  if (S > 0x7fffffffLL || Nq > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  const int64_t n_total = B * Nq * M * D;
+  const int64_t blocks = (n_total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  hipLaunchKernelGGL((msda_backward_kernel<ST>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const ST*>(go), static_cast<const ST*>(value), static_cast<const int64_t*>(ss),
+                     static_cast<const int64_t*>(ls), static_cast<const ST*>(loc), static_cast<const ST*>(w), n_total,
+                     (int)S, M, D, L, (int)Nq, P, static_cast<ST*>(gv), static_cast<ST*>(gl), static_cast<ST*>(gw));
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define CODETR_MSDA_BWD_ENTRY(NAME, ST)                                                                               \
+  int NAME(void* stream, const void* value_dev, const int64_t* spatial_shapes_dev, const int64_t* level_start_dev,    \
+           const void* sampling_loc_dev, const void* attn_weight_dev, const void* grad_output_dev, int64_t B,         \
+           int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step, void* grad_value_dev,              \
+           void* grad_sampling_loc_dev, void* grad_attn_weight_dev) {                                                 \
+    return launch_bwd<ST>(stream, value_dev, spatial_shapes_dev, level_start_dev, sampling_loc_dev, attn_weight_dev,  \
+                          grad_output_dev, B, S, M, D, L, Nq, P, im2col_step, grad_value_dev, grad_sampling_loc_dev,  \
+                          grad_attn_weight_dev);                                                                      \
+  }
+
+CODETR_MSDA_BWD_ENTRY(codetr_msda_backward_f16, _Float16)
+CODETR_MSDA_BWD_ENTRY(codetr_msda_backward_f32, float)
+CODETR_MSDA_BWD_ENTRY(codetr_msda_backward_f64, double)
+
+}  // extern "C"

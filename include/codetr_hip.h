@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 18
+#define CODETR_HIP_ABI_VERSION 19
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -267,6 +267,34 @@ int codetr_preprocess_u8_f32(void *stream, const void *src_dev, int64_t H_src, i
                              const float *std_host, const int *pad_value_host, void *dst_dev, void *mask_dev);
 int codetr_batched_nms_f32(void *stream, const float *boxes_sorted_dev, const int64_t *labels_sorted_dev, int64_t N,
                            float iou_threshold, void *keep_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of multi-scale deformable attention (training path).
+ *
+ * Replaces ms_deformable_col2im_cuda<T> / ms_deform_attn_backward (codetr/csrc/ms_deform_attn.cu:781-897, 975-1028;
+ * arithmetic of ms_deform_attn_col2im_bilinear :79-146): same operands as the forward plus
+ *   grad_output_dev        [B, Nq, M*D]          T
+ *   grad_value_dev         [B, S, M, D]          T   accumulated with atomics -- the CALLER zero-fills all three
+ *   grad_sampling_loc_dev  [B, Nq, M, L, P, 2]   T   gradients first (reference codetr/ops.py:94-96)
+ *   grad_attn_weight_dev   [B, Nq, M, L, P]      T
+ * T in {f16, f32, f64}; f16 computes in fp32 and accumulates grad_value with packed f16 atomics.  D must be a
+ * power of two <= 64 (>= 2 for f16).  im2col_step: the reference's contract (batch % min(batch, step) == 0).
+ * ------------------------------------------------------------------------------------------ */
+int codetr_msda_backward_f16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                             const int64_t *level_start_dev, const void *sampling_loc_dev, const void *attn_weight_dev,
+                             const void *grad_output_dev, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,
+                             int64_t im2col_step, void *grad_value_dev, void *grad_sampling_loc_dev,
+                             void *grad_attn_weight_dev);
+int codetr_msda_backward_f32(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                             const int64_t *level_start_dev, const void *sampling_loc_dev, const void *attn_weight_dev,
+                             const void *grad_output_dev, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,
+                             int64_t im2col_step, void *grad_value_dev, void *grad_sampling_loc_dev,
+                             void *grad_attn_weight_dev);
+int codetr_msda_backward_f64(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                             const int64_t *level_start_dev, const void *sampling_loc_dev, const void *attn_weight_dev,
+                             const void *grad_output_dev, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,
+                             int64_t im2col_step, void *grad_value_dev, void *grad_sampling_loc_dev,
+                             void *grad_attn_weight_dev);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension: y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta
