@@ -768,6 +768,7 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
   unsigned char* stage = lds + wave * (64 * kPitch);
   const int srow = lane >> 3, schunk = lane & 7;
   const int n = n0 + wn * 64 + schunk * 8;
+  unsigned char* ytile = reinterpret_cast<unsigned char*>(Y) + ((size_t)m0 * N + n0) * 2;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -816,14 +817,15 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
             v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
           }
         }
-        const size_t off = (size_t)m * N + n;
         if (HAS_RES) {
           const s16x8 rr = rres[it];
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[e]));
         }
-        *reinterpret_cast<s16x8*>(Y + off) = v;
+        // uniform 64-bit tile base (SGPRs) + 32-bit lane offset: the store carries half the address bytes
+        const unsigned loff = ((unsigned)(wm * 128 + h * 64 + ml) * (unsigned)N + (unsigned)(wn * 64 + schunk * 8)) * 2u;
+        *reinterpret_cast<s16x8*>(ytile + loff) = v;
       }
     }
     __builtin_amdgcn_wave_barrier();  // the region is rewritten by the second half
