@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -58,6 +58,8 @@ SIGNATURES = {
     "codetr_ffn_relu_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_ffn_relu_ln_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float,
                                       _vp, _vp]),
+    "codetr_ffn_relu_ln2_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float,
+                                       _vp, _vp, ctypes.c_float, _vp, _vp]),
     "codetr_ffn_pack_w2_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
 }
@@ -415,22 +417,24 @@ def ffn_pack_w2(w2):
     return out
 
 
-def ffn_fused(x2d, w1, b1, w2, b2, out2d, ln=None, pos2d=None, out_plus_pos2d=None):
+def ffn_fused(x2d, w1, b1, w2, b2, out2d, ln=None, pos2d=None, out_plus_pos2d=None, ln_in=None):
     """w2 must be the PACKED weight (ffn_pack_w2).  ln = (gamma, beta, eps): LayerNorm folded into the epilogue;
-    pos2d / out_plus_pos2d: second output `out + pos`."""
+    pos2d / out_plus_pos2d: second output `out + pos`; ln_in = (gamma, beta, eps): LayerNorm of the input rows."""
     CALLS["ffn_fused"] += 1
-    if ln is None and pos2d is None:
+    if ln is None and pos2d is None and ln_in is None:
         rc = load().codetr_ffn_relu_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), w1.data_ptr(), b1.data_ptr(),
                                         w2.data_ptr(), b2.data_ptr(), out2d.data_ptr(), x2d.shape[0], x2d.shape[1],
                                         w1.shape[0])
         check(rc, "codetr_ffn_relu_f16")
         return out2d
     g, b, eps = ln if ln is not None else (None, None, 0.0)
-    rc = load().codetr_ffn_relu_ln_f16(
+    gi, bi, epsi = ln_in if ln_in is not None else (None, None, 0.0)
+    rc = load().codetr_ffn_relu_ln2_f16(
         current_stream_ptr(x2d.device), x2d.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
         out2d.data_ptr(), x2d.shape[0], x2d.shape[1], w1.shape[0],
+        gi.data_ptr() if gi is not None else None, bi.data_ptr() if bi is not None else None, float(epsi),
         g.data_ptr() if g is not None else None, b.data_ptr() if b is not None else None, float(eps),
         pos2d.data_ptr() if pos2d is not None else None,
         out_plus_pos2d.data_ptr() if out_plus_pos2d is not None else None)
-    check(rc, "codetr_ffn_relu_ln_f16")
+    check(rc, "codetr_ffn_relu_ln2_f16")
     return out2d

@@ -145,11 +145,12 @@ def _packed_w2(w2):
     return hit[1]
 
 
-def ffn_fused(x, w1, b1, w2, b2, ln=None, pos=None):
+def ffn_fused(x, w1, b1, w2, b2, ln=None, pos=None, ln_in=None):
     """y = x + relu(x @ w1.T + b1) @ w2.T + b2 in one kernel (hidden activation stays on-chip); x [..., 256].
     w2 is the plain nn.Linear weight; its packed form is cached.
     ln = (weight, bias, eps): y = LayerNorm(y) in the same epilogue.  pos (same shape as x): also returns y + pos,
-    i.e. the result is (y, y + pos)."""
+    i.e. the result is (y, y + pos).  ln_in = (weight, bias, eps): the input rows are LayerNorm'ed first (in
+    registers; that norm's output is both the FFN input and the identity and is never written)."""
     _gpu(x, "ffn_fused")
     x2 = x.reshape(-1, x.shape[-1])
     if not x2.is_contiguous():
@@ -166,7 +167,7 @@ def ffn_fused(x, w1, b1, w2, b2, ln=None, pos=None):
     if x2.shape[0] > 0:
         with torch.cuda.device(x.device):
             _timed("ffn_fused", {"M": x2.shape[0], "C": x2.shape[1], "hidden": w1.shape[0]},
-                   lambda: _cabi.ffn_fused(x2, w1.contiguous(), b1, _packed_w2(w2), b2, out, ln, p2, out2), x.device)
+                   lambda: _cabi.ffn_fused(x2, w1.contiguous(), b1, _packed_w2(w2), b2, out, ln, p2, out2, ln_in), x.device)
     if pos is not None:
         return out.view(x.shape), out2.view(x.shape)
     return out.view(x.shape)

@@ -65,12 +65,13 @@ class FFN(nn.Module):
         return (self.add_identity and identity is None and fc1.bias is not None and fc2.bias is not None
                 and hip_ops.ffn_fused_supported(x, fc1.weight, fc2.weight, self.act))
 
-    def forward_norm(self, x, norm, pos=None):
+    def forward_norm(self, x, norm, pos=None, norm_in=None):
         """LayerNorm(x + ffn(x)) -- and, with `pos`, also that + pos -- in the fused kernel's epilogue
-        (call only when fused_supported(x))."""
+        (call only when fused_supported(x)).  norm_in: a LayerNorm applied to x first, inside the kernel."""
         fc1, fc2 = self.layers[0][0], self.layers[1]
+        ln_in = None if norm_in is None else (norm_in.weight, norm_in.bias, norm_in.eps)
         return hip_ops.ffn_fused(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln=(norm.weight, norm.bias, norm.eps),
-                                 pos=pos)
+                                 pos=pos, ln_in=ln_in)
 
     def forward(self, x, identity=None):
         fc1, fc2 = self.layers[0][0], self.layers[1]
@@ -192,6 +193,7 @@ class BaseTransformerLayer(nn.Module):
         plus_pos_out = None
         ops = self.operation_order
         skip_norm = False
+        norm_in = None  # a LayerNorm deferred into the fused FFN kernel
         for oi, op in enumerate(ops):
             if skip_norm and op == "norm":
                 skip_norm = False
@@ -216,7 +218,16 @@ class BaseTransformerLayer(nn.Module):
                 identity = query
             elif op == "norm":
                 n = self.norms[ni]
-                query = hip_ops.layer_norm(query, n.weight, n.bias, n.eps)
+                if (not self.pre_norm and oi + 2 < len(ops) and ops[oi + 1] == "ffn" and ops[oi + 2] == "norm"
+                        and isinstance(n, nn.LayerNorm) and n.weight is not None and n.weight.dtype == query.dtype
+                        and isinstance(self.norms[ni + 1], nn.LayerNorm) and self.norms[ni + 1].weight is not None
+                        and self.norms[ni + 1].weight.dtype == query.dtype
+                        and self.ffns[fi].fused_supported(query)):
+                    # (norm, ffn, norm): this norm's output is read by the FFN alone (operand and identity), so the
+                    # fused FFN kernel applies it to its input rows in registers
+                    norm_in = n
+                else:
+                    query = hip_ops.layer_norm(query, n.weight, n.bias, n.eps)
                 ni += 1
             else:  # ffn
                 ffn = self.ffns[fi]
@@ -228,13 +239,16 @@ class BaseTransformerLayer(nn.Module):
                     # `+ query_pos`) ride in the fused FFN kernel's epilogue
                     pos = query_pos if (want_plus_pos and want_pos_output and last_pair and query_pos is not None
                                         and query_pos.shape == query.shape) else None
-                    r = ffn.forward_norm(query, self.norms[ni], pos)
+                    r = ffn.forward_norm(query, self.norms[ni], pos, norm_in)
+                    norm_in = None
                     if pos is not None:
                         query, plus_pos_out = r
                     else:
                         query = r
                     skip_norm = True
                 else:
+                    if norm_in is not None:
+                        raise AssertionError("a LayerNorm was deferred into a fused FFN that did not run")
                     query = ffn(query, identity if self.pre_norm else None)
                 fi += 1
         if want_plus_pos:

@@ -111,8 +111,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
     int Hd, const unsigned short* __restrict__ ln_g, const unsigned short* __restrict__ ln_b, float ln_eps,
-    const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2, int row0) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2];  // 144 KiB, one object
+    const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2, int row0,
+    const unsigned short* __restrict__ lnin_g, const unsigned short* __restrict__ lnin_b, float lnin_eps) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2 + 256 * 8];  // 146 KiB, one object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
   constexpr int BM = 64 * MT, WR = 16 * MT;  // rows per workgroup / per wave
@@ -130,6 +131,48 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
       xf[mt][ks] = *reinterpret_cast<const f16x8*>(X + (size_t)m * C + ks * 32 + grp * 8);
+  }
+  // Optional LayerNorm of the INPUT rows (the post-norm layer's first norm, whose output nothing else reads): the
+  // 256 values of row (mt, l15) sit in the four lanes l15 + 16 g of this wave (8 k-steps x 8 values each), so the
+  // statistics are two xor-shuffles away; fp32 two-pass like layernorm_kernel, result rounded to f16 = the operand the
+  // separate kernel would have written.  (mean, rstd) go to LDS so that the epilogue rebuilds exactly the same rows
+  // for the residual.
+  float* sStat = reinterpret_cast<float*>(lds + 2 * kStageBytes + kMaxHidden * 2) + wave * (WR * 2);
+  if (lnin_g) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float sm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += (float)xf[mt][ks][e];
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mean = sm * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)xf[mt][ks][e] - mean;
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = rsqrtf(q * (1.0f / C) + lnin_eps);
+      if (grp == 0) {
+        sStat[(mt * 16 + l15) * 2] = mean;
+        sStat[(mt * 16 + l15) * 2 + 1] = rstd;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const f16x8 gw = *reinterpret_cast<const f16x8*>(lnin_g + ks * 32 + grp * 8);
+        const f16x8 gb = *reinterpret_cast<const f16x8*>(lnin_b + ks * 32 + grp * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          xf[mt][ks][e] = (_Float16)fmaf(((float)xf[mt][ks][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
+      }
+    }
   }
   // Y accumulators start at b2 (lane's 4 consecutive n of tile nt: n = 16*nt + 4*grp + r)
   f32x4 yacc[16][MT];
@@ -294,19 +337,29 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       pr[it] = *reinterpret_cast<const f16x8*>(pos + (size_t)m * C + chunk * 8);
     }
   }
-  f16x8 gw, gb;
+  f16x8 gw, gb, gin_w, gin_b;
   if (ln_g) {
     gw = *reinterpret_cast<const f16x8*>(ln_g + chunk * 8);
     gb = *reinterpret_cast<const f16x8*>(ln_b + chunk * 8);
+  }
+  if (lnin_g) {
+    gin_w = *reinterpret_cast<const f16x8*>(lnin_g + chunk * 8);
+    gin_b = *reinterpret_cast<const f16x8*>(lnin_b + chunk * 8);
   }
 #pragma unroll
   for (int it = 0; it < WR / 2; ++it) {
     const int row = it * 2 + (lane >> 5);
     const int m = m0 + row;
     const f16x8 y = *reinterpret_cast<const f16x8*>(stage + row * kOutPitch + chunk * 16);
+    f16x8 xrow = xr[it];
+    if (lnin_g) {  // identity = LayerNorm(input row), the same arithmetic on the same statistics as the prologue
+      const float mean = sStat[row * 2], rstd = sStat[row * 2 + 1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xrow[e] = (_Float16)fmaf(((float)xrow[e] - mean) * rstd, (float)gin_w[e], (float)gin_b[e]);
+    }
     f16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)y[e] + (float)xr[it][e]);  // identity + ffn(x): fp16 + fp16 -> fp16
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)y[e] + (float)xrow[e]);  // identity + ffn(x): fp16 + fp16 -> fp16
     if (ln_g) {
       // LayerNorm over the row (its 256 values sit in the 32 lanes of this half-wave): the arithmetic of
       // layernorm_kernel<LnHalf, 32, 1>, statement for statement, so the result is bit-identical to running that
@@ -366,13 +419,15 @@ int codetr_ffn_pack_w2_f16(void* stream, const void* w2_dev, void* w2_packed_dev
   return err == hipSuccess ? 0 : (int)err;
 }
 
-int codetr_ffn_relu_ln_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
-                           const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
-                           int64_t hidden, const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps,
-                           const void* pos_dev, void* y_plus_pos_dev) {
+int codetr_ffn_relu_ln2_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
+                            const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                            int64_t hidden, const void* ln_in_gamma_dev, const void* ln_in_beta_dev, float ln_in_eps,
+                            const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps, const void* pos_dev,
+                            void* y_plus_pos_dev) {
   const void* w2_dev = w2_packed_dev;
   if (!x_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !y_dev || M <= 0 || hidden <= 0) return CODETR_E_BADARG;
-  if ((ln_gamma_dev == nullptr) != (ln_beta_dev == nullptr) || (pos_dev == nullptr) != (y_plus_pos_dev == nullptr))
+  if ((ln_gamma_dev == nullptr) != (ln_beta_dev == nullptr) || (pos_dev == nullptr) != (y_plus_pos_dev == nullptr) ||
+      (ln_in_gamma_dev == nullptr) != (ln_in_beta_dev == nullptr))
     return CODETR_E_BADARG;
   if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
   if (M > 0x7fffffffLL - 256 || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
@@ -388,9 +443,19 @@ int codetr_ffn_relu_ln_f16(void* stream, const void* x_dev, const void* w1_dev, 
                      static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
                      (int)hidden, static_cast<const unsigned short*>(ln_gamma_dev),
                      static_cast<const unsigned short*>(ln_beta_dev), ln_eps,
-                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev), 0);
+                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev), 0,
+                     static_cast<const unsigned short*>(ln_in_gamma_dev),
+                     static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+int codetr_ffn_relu_ln_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
+                           const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                           int64_t hidden, const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps,
+                           const void* pos_dev, void* y_plus_pos_dev) {
+  return codetr_ffn_relu_ln2_f16(stream, x_dev, w1_dev, b1_dev, w2_packed_dev, b2_dev, y_dev, M, C_in, hidden, nullptr,
+                                 nullptr, 0.f, ln_gamma_dev, ln_beta_dev, ln_eps, pos_dev, y_plus_pos_dev);
 }
 
 int codetr_ffn_relu_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,

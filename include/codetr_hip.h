@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 19
+#define CODETR_HIP_ABI_VERSION 20
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -394,6 +394,17 @@ int codetr_ffn_relu_ln_f16(void *stream, const void *x_dev, const void *w1_dev, 
                            const void *w2_packed_dev, const void *b2_dev, void *y_dev, int64_t M, int64_t C_in,
                            int64_t hidden, const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps,
                            const void *pos_dev, void *y_plus_pos_dev);
+
+/* ... and with the layer's PRECEDING LayerNorm folded in as well (operation_order (..., 'norm', 'ffn', 'norm')): the
+ * kernel normalises its input rows in registers (fp32 two-pass statistics, f16 result = the MFMA operand and the
+ * identity), so that norm's output is never written:
+ *   x1 = LayerNorm(x) * ln_in_gamma + ln_in_beta;  y = LayerNorm(x1 + ffn(x1)) * gamma + beta;  y_plus_pos = y + pos
+ * ln_in_gamma_dev / ln_in_beta_dev [256] f16, both or neither (NULL: codetr_ffn_relu_ln_f16). */
+int codetr_ffn_relu_ln2_f16(void *stream, const void *x_dev, const void *w1_dev, const void *b1_dev,
+                            const void *w2_packed_dev, const void *b2_dev, void *y_dev, int64_t M, int64_t C_in,
+                            int64_t hidden, const void *ln_in_gamma_dev, const void *ln_in_beta_dev, float ln_in_eps,
+                            const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps, const void *pos_dev,
+                            void *y_plus_pos_dev);
 /* one-time weight pre-pack for the call above: w2_dev [C_out, hidden] f16 -> w2_packed_dev (same shape) */
 int codetr_ffn_pack_w2_f16(void *stream, const void *w2_dev, void *w2_packed_dev, int64_t C_out, int64_t hidden);
 
