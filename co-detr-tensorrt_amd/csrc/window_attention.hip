@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "codetr_hip.h"
 
 namespace {
@@ -104,21 +106,36 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   unsigned char* ldsR = ldsV + VR * 64;
 
   // ---------------- stage K and V (+ region ids) ----------------
-  for (int c = lane; c < VR * 4; c += 64) {
+  // all 2 * ITER row loads are requested before the first LDS write (one exposed latency instead of ITER: a rolled
+  // load -> write loop cost ~10 us of a ~27 us problem)
+  constexpr int ITER = (VR * 4 + 63) / 64;
+  s16x8 kv[ITER], vv[ITER];
+  unsigned char regv[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int c = lane + it * 64;
     const int row = c >> 2, chunk = c & 3;
-    s16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < N) {
+    kv[it] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    vv[it] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    regv[it] = 0;
+    if (c < VR * 4 && row < N) {
       const Tok<WS> t = map_token<WS>(row, wy, wx, g);
       const _Float16* src = t.valid ? qkv_b + (size_t)t.token * row_elems : qkv_bias;
-      kv = *reinterpret_cast<const s16x8*>(src + C + hoff + chunk * 8);
-      vv = *reinterpret_cast<const s16x8*>(src + 2 * C + hoff + chunk * 8);
-      if (chunk == 0) ldsR[row] = (unsigned char)t.region;
-    } else if (row < NP && chunk == 0) {
-      ldsR[row] = 0;
+      kv[it] = *reinterpret_cast<const s16x8*>(src + C + hoff + chunk * 8);
+      vv[it] = *reinterpret_cast<const s16x8*>(src + 2 * C + hoff + chunk * 8);
+      regv[it] = (unsigned char)t.region;
     }
-    const int pos = swz(row, chunk) * 16;
-    if (row < NP) *reinterpret_cast<s16x8*>(ldsK + row * 64 + pos) = kv;
-    *reinterpret_cast<s16x8*>(ldsV + row * 64 + pos) = vv;
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int c = lane + it * 64;
+    const int row = c >> 2, chunk = c & 3;
+    if (c < VR * 4) {
+      if (chunk == 0 && row < NP) ldsR[row] = regv[it];
+      const int pos = swz(row, chunk) * 16;
+      if (row < NP) *reinterpret_cast<s16x8*>(ldsK + row * 64 + pos) = kv[it];
+      *reinterpret_cast<s16x8*>(ldsV + row * 64 + pos) = vv[it];
+    }
   }
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave retire in order; keep the compiler from reordering
 
@@ -131,13 +148,46 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block
   const int tr_q = l15 >> 2, tr_p = l15 & 3;
 
+  // The query fragment and the 9 bias groups of a query tile are requested one tile ahead: with one wave per problem
+  // and two waves per SIMD nothing else covers a global-load latency, and unprefetched they cost two of them per
+  // tile (18 per problem: ~17 of the ~20 us a problem took).
+  struct QTile {
+    f16x8 qf;
+    f16x4 bv[NT];
+    Tok<WS> tq;
+    bool q_in;
+  };
+  auto load_qtile = [&](int qt, QTile& T) {
+    const int qi = qt * 16 + l15;
+    T.q_in = (N % 16 == 0) || qi < N;
+    T.tq = map_token<WS>(T.q_in ? qi : 0, wy, wx, g);
+    const _Float16* qsrc = (T.tq.valid ? qkv_b + (size_t)T.tq.token * row_elems : qkv_bias) + hoff + grp * 8;
+    T.qf = *reinterpret_cast<const f16x8*>(qsrc);
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const int key0 = kt * 16 + grp * 4;
+      f16x4 bv = {0, 0, 0, 0};
+      if constexpr (N % 4 == 0) {  // rows of the bias are 8-byte aligned and a 4-key group is all in or all out
+        if ((N % 16 == 0) || (T.q_in && key0 < N))
+          bv = *reinterpret_cast<const f16x4*>(bias_h + (size_t)(T.q_in ? qi : 0) * N + key0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (T.q_in && key0 + r < N) bv[r] = bias_h[(size_t)qi * N + key0 + r];
+      }
+      T.bv[kt] = bv;
+    }
+  };
+  const bool multi_region = g.shift > 0 && (wy == g.nWin / g.nWx - 1 || wx == g.nWx - 1);
+  QTile nxt;
+  load_qtile(0, nxt);
 #pragma unroll 1
   for (int qt = 0; qt < NT; ++qt) {
-    const int qi = qt * 16 + l15;
-    const bool q_in = (N % 16 == 0) || qi < N;
-    const Tok<WS> tq = map_token<WS>(q_in ? qi : 0, wy, wx, g);
-    const _Float16* qsrc = (tq.valid ? qkv_b + (size_t)tq.token * row_elems : qkv_bias) + hoff + grp * 8;
-    const f16x8 qf = *reinterpret_cast<const f16x8*>(qsrc);
+    const QTile cur = nxt;
+    if (qt + 1 < NT) load_qtile(qt + 1, nxt);
+    const bool q_in = cur.q_in;
+    const Tok<WS> tq = cur.tq;
+    const f16x8 qf = cur.qf;
 
     // ---- S^T tiles: D[i = key][j = query] ----
     f32x4 s[NT];
@@ -148,29 +198,30 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
       s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
     // ---- scale, bias, mask (all in the log2 domain), row max ----
+    // The shift mask costs ~3 of the ~12 VALU instructions per score, and this kernel is VALU-bound (two waves per
+    // SIMD, ~6 k instructions per problem): only windows on the last window row / column of a shifted block hold more
+    // than one region, everything else takes the mask-free instantiation (wave-uniform branch).
     float mx = -INFINITY;
+    auto scores = [&](auto mask_tag) {
+      constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      const int key0 = kt * 16 + grp * 4;
-      f16x4 bv = {0, 0, 0, 0};
-      if constexpr (N % 4 == 0) {  // rows of the bias are 8-byte aligned and a 4-key group is all in or all out
-        if ((N % 16 == 0) || (q_in && key0 < N))
-          bv = *reinterpret_cast<const f16x4*>(bias_h + (size_t)(q_in ? qi : 0) * N + key0);
-      } else {
+      for (int kt = 0; kt < NT; ++kt) {
+        const int key0 = kt * 16 + grp * 4;
+        const f16x4 bv = cur.bv[kt];
+        unsigned regk = 0;
+        if (MASK) regk = *reinterpret_cast<const unsigned*>(ldsR + key0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (q_in && key0 + r < N) bv[r] = bias_h[(size_t)qi * N + key0 + r];
+        for (int r = 0; r < 4; ++r) {
+          float v = s[kt][r] * scale_log2e + (float)bv[r] * log2e;
+          if (MASK && (int)((regk >> (8 * r)) & 0xff) != tq.region) v -= 100.0f * log2e;
+          if ((N % 16 != 0) && key0 + r >= N) v = -INFINITY;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
       }
-      const unsigned regk = *reinterpret_cast<const unsigned*>(ldsR + key0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = s[kt][r] * scale_log2e + (float)bv[r] * log2e;
-        if (g.shift > 0 && (int)((regk >> (8 * r)) & 0xff) != tq.region) v -= 100.0f * log2e;
-        if ((N % 16 != 0) && key0 + r >= N) v = -INFINITY;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    }
+    };
+    if (multi_region) scores(std::true_type{});
+    else scores(std::false_type{});
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // ---- exp, row sum, pack P^T as MFMA B fragments ----
