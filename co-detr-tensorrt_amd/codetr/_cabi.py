@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "codetr_preprocess_u8_f16": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "codetr_preprocess_u8_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "codetr_batched_nms_f32": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float, _vp]),
+    "codetr_patch_merge_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float]),
     "codetr_mask_pyramid": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "codetr_linear_splitk_plan": (_i32, [_i64, _i64, _i64, _vp]),
     "codetr_linear_splitk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
@@ -71,7 +72,7 @@ _lib = None
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
-         "msda_backward": 0}
+         "msda_backward": 0, "patch_merge_layernorm": 0}
 
 
 def load():
@@ -318,6 +319,17 @@ _LN_BY_DTYPE = {torch.float16: "codetr_layernorm_f16", torch.bfloat16: "codetr_l
 def layernorm_supported(x, weight) -> bool:
     C = x.shape[-1]
     return x.dtype in _LN_BY_DTYPE and weight is not None and weight.dtype == x.dtype and C % 8 == 0 and C <= 4096
+
+
+def patch_merge_layernorm(x4d, weight_kkc, bias_kkc, eps):
+    """x4d [B,H,W,C] f16 contiguous -> LayerNorm of the 2x2-merged rows [B, H2*W2, 4C] ((ky, kx, c) order)"""
+    CALLS["patch_merge_layernorm"] += 1
+    B, H, W, C = x4d.shape
+    out = torch.empty((B, ((H + 1) // 2) * ((W + 1) // 2), 4 * C), dtype=x4d.dtype, device=x4d.device)
+    rc = load().codetr_patch_merge_layernorm_f16(current_stream_ptr(x4d.device), x4d.data_ptr(), weight_kkc.data_ptr(),
+                                                 bias_kkc.data_ptr(), out.data_ptr(), B, H, W, C, float(eps))
+    check(rc, "codetr_patch_merge_layernorm_f16")
+    return out
 
 
 def layernorm(x2d, weight, bias, eps, out2d):

@@ -10,6 +10,8 @@ that op lands, never as a fallback for a native kernel that exists.
 There is no CPU path: a CPU tensor reaching any of these functions is an error (the CPU
 formulation of the model lives in oracle/ and is test infrastructure).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -22,7 +24,8 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "mask_pyramid(level masks + running valid counts + valid ratios)",
           "query_sine_embed(f16: sigmoid x valid ratios + sine embedding of the decoder reference boxes)",
           "encoder_geometry(f16: reference points, proposals, keep/drop state)", "row_max(f16)",
-          "preprocess_image(u8 -> f16/f32, cv2-exact resize + pad + normalise + mask)", "batched_nms(f32)"}
+          "preprocess_image(u8 -> f16/f32, cv2-exact resize + pad + normalise + mask)", "batched_nms(f32)",
+          "patch_merge_layernorm(f16: Swin 2x2 gather + LayerNorm)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -186,6 +189,24 @@ def layer_norm(x, weight, bias, eps=1e-5):
                 _cabi.layernorm(x2, weight, bias, eps, out)
         return out.view(x.shape)
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)  # fp32 parity runs
+
+
+def patch_merge_layernorm_supported(x, C):
+    return (x.is_cuda and x.dtype == torch.float16 and C % 8 == 0 and 4 * C <= 4096
+            and os.environ.get("CODETR_MERGE_LN", "1") != "0")
+
+
+def patch_merge_layernorm(x, hw, weight_kkc, bias_kkc, eps=1e-5):
+    """Swin PatchMerging's 2x2 gather + LayerNorm(4C) in one pass: x [B, H*W, C] tokens -> [B, H2*W2, 4C] with the 4C
+    axis ordered (ky, kx, c) (weight / bias given in that order)."""
+    _gpu(x, "patch_merge_layernorm")
+    B, L, C = x.shape
+    H, W = hw
+    x4 = x.view(B, H, W, C)
+    if not x4.is_contiguous():
+        x4 = x4.contiguous()
+    with torch.cuda.device(x.device):
+        return _cabi.patch_merge_layernorm(x4, weight_kkc, bias_kkc, eps)
 
 
 def group_norm(x, groups, weight, bias, eps=1e-5):

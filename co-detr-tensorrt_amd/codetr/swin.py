@@ -77,6 +77,11 @@ class PatchMerging(nn.Module):
             # whole C-vectors (>= 384 contiguous bytes) instead of single elements, and LayerNorm / Linear see their
             # parameters permuted the same way (LN is invariant under a joint permutation; the Linear's columns follow).
             nw, nb, rw = self._permuted_params(C)
+            if (self.norm is not None and isinstance(self.norm, nn.LayerNorm)
+                    and hip_ops.patch_merge_layernorm_supported(x, C)):
+                # gather + LayerNorm in one kernel: the merged map is never written un-normalised
+                x = hip_ops.patch_merge_layernorm(x.reshape(B, -1, C), (2 * H2, 2 * W2), nw, nb, self.norm.eps)
+                return hip_ops.linear(x, rw, self.reduction.bias), (H2, W2)
             x = x.view(B, H2, 2, W2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H2 * W2, 4 * C)
             if self.norm is not None:
                 x = hip_ops.layer_norm(x, nw, nb, self.norm.eps)

@@ -49,10 +49,18 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // G lanes per row, NCH chunks of 8 elements per lane (G * NCH * 8 >= C)
-template <class T, int G, int NCH>
+// MERGE: the input row is gathered on the fly from the 2 x 2 neighbourhood of a token map [B, H, W, Cs] -- Swin's
+// PatchMerging (reference codetr/transformer_mmcv.py:213-316: nn.Unfold(2, stride 2) + LayerNorm(4 Cs)) with the 4 Cs axis
+// ordered (ky, kx, c) -- so the merged map is never written un-normalised: row r = (b, y2, x2), chunk ch -> sub-pixel
+// k = ch / (Cs/8) = ky*2 + kx, source token (2 y2 + ky, 2 x2 + kx), zeros beyond an odd H / W (F.pad).
+struct MergeGeom {
+  int H, W, Cs, H2, W2;
+};
+
+template <class T, int G, int NCH, bool MERGE = false>
 __global__ __launch_bounds__(kThreads) void layernorm_kernel(const short* __restrict__ x, const short* __restrict__ gamma,
                                                              const short* __restrict__ beta, short* __restrict__ y,
-                                                             int64_t rows, int C, float eps) {
+                                                             int64_t rows, int C, float eps, MergeGeom mg = MergeGeom{}) {
   constexpr int ROWS_PER_BLOCK = kThreads / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
@@ -70,13 +78,28 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const short* __rest
   }
   for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + rloc; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
     const short* xr = x + row * C;
+    int mb = 0, my = 0, mx = 0;
+    if (MERGE) {
+      mb = (int)(row / ((int64_t)mg.H2 * mg.W2));
+      const int rr = (int)(row - (int64_t)mb * mg.H2 * mg.W2);
+      my = rr / mg.W2;
+      mx = rr - my * mg.W2;
+    }
     s16x8 v[NCH];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = sub + c * G;
       if (ch < nchunks) {
-        v[c] = *reinterpret_cast<const s16x8*>(xr + ch * 8);
+        if (MERGE) {
+          const int cpc = mg.Cs >> 3, k = ch / cpc, within = ch - k * cpc;
+          const int sy = 2 * my + (k >> 1), sx = 2 * mx + (k & 1);
+          v[c] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (sy < mg.H && sx < mg.W)
+            v[c] = *reinterpret_cast<const s16x8*>(x + (((int64_t)mb * mg.H + sy) * mg.W + sx) * mg.Cs + within * 8);
+        } else {
+          v[c] = *reinterpret_cast<const s16x8*>(xr + ch * 8);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += T::up(v[c][e]);
       }
@@ -110,16 +133,35 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const short* __rest
   }
 }
 
-template <class T, int G, int NCH>
-int launch_cfg(hipStream_t st, const void* x, const void* g, const void* b, void* y, int64_t rows, int C, float eps) {
+template <class T, int G, int NCH, bool MERGE = false>
+int launch_cfg(hipStream_t st, const void* x, const void* g, const void* b, void* y, int64_t rows, int C, float eps,
+               MergeGeom mg = MergeGeom{}) {
   constexpr int RPB = kThreads / G;
   int64_t blocks = (rows + RPB - 1) / RPB;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
-  hipLaunchKernelGGL((layernorm_kernel<T, G, NCH>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
+  hipLaunchKernelGGL((layernorm_kernel<T, G, NCH, MERGE>), dim3((unsigned)blocks), dim3(kThreads), 0, st,
                      static_cast<const short*>(x), static_cast<const short*>(g), static_cast<const short*>(b),
-                     static_cast<short*>(y), rows, C, eps);
+                     static_cast<short*>(y), rows, C, eps, mg);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+int launch_merge(hipStream_t st, const void* x, const void* g, const void* b, void* y, int64_t B, int64_t H, int64_t W,
+                 int64_t Cs, float eps) {
+  if (!x || !g || !b || !y || B <= 0 || H <= 0 || W <= 0 || Cs <= 0) return CODETR_E_BADARG;
+  const int64_t C = 4 * Cs;
+  if (Cs % 8 != 0 || C > 4096) return CODETR_E_UNSUPPORTED;
+  if (H > 0x7fffffffLL || W > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  MergeGeom mg{(int)H, (int)W, (int)Cs, (int)((H + 1) / 2), (int)((W + 1) / 2)};
+  const int64_t rows = B * mg.H2 * mg.W2;
+  const int nch = (int)(C / 8);
+  if (nch <= 32) return launch_cfg<LnHalf, 32, 1, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 64) return launch_cfg<LnHalf, 64, 1, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 128) return launch_cfg<LnHalf, 64, 2, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 192) return launch_cfg<LnHalf, 64, 3, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 256) return launch_cfg<LnHalf, 64, 4, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 384) return launch_cfg<LnHalf, 64, 6, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  return launch_cfg<LnHalf, 64, 8, true>(st, x, g, b, y, rows, (int)C, eps, mg);
 }
 
 template <class T>
@@ -148,6 +190,11 @@ int codetr_layernorm_f16(void* stream, const void* x_dev, const void* gamma_dev,
 int codetr_layernorm_bf16(void* stream, const void* x_dev, const void* gamma_dev, const void* beta_dev, void* y_dev,
                           int64_t rows, int64_t C, float eps) {
   return launch<LnBf16>(static_cast<hipStream_t>(stream), x_dev, gamma_dev, beta_dev, y_dev, rows, C, eps);
+}
+
+int codetr_patch_merge_layernorm_f16(void* stream, const void* x_dev, const void* gamma_dev, const void* beta_dev,
+                                     void* y_dev, int64_t B, int64_t H, int64_t W, int64_t C, float eps) {
+  return launch_merge(static_cast<hipStream_t>(stream), x_dev, gamma_dev, beta_dev, y_dev, B, H, W, C, eps);
 }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 20
+#define CODETR_HIP_ABI_VERSION 21
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -308,6 +308,13 @@ int codetr_layernorm_f16(void *stream, const void *x_dev, const void *gamma_dev,
                          int64_t rows, int64_t C, float eps);
 int codetr_layernorm_bf16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev, void *y_dev,
                           int64_t rows, int64_t C, float eps);
+
+/* Swin PatchMerging's gather + LayerNorm in one pass (codetr/transformer_mmcv.py:213-316: nn.Unfold(2, stride 2) on
+ * the token map, then LayerNorm(4C)): x_dev [B, H, W, C] f16 token map, y_dev [B, ceil(H/2)*ceil(W/2), 4C] f16 with
+ * the 4C axis ordered (ky, kx, c) -- gamma / beta (and the reduction Linear's columns) must be in that order, i.e.
+ * permuted from nn.Unfold's (c, ky, kx); zeros beyond an odd H / W.  C % 8 == 0, 4C <= 4096. */
+int codetr_patch_merge_layernorm_f16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev,
+                                     void *y_dev, int64_t B, int64_t H, int64_t W, int64_t C, float eps);
 
 /* ------------------------------------------------------------------------------------------
  * Fused (shifted-)window multi-head self-attention of one Swin block.

@@ -50,3 +50,24 @@ def test_layernorm_3d_and_noncontiguous():
     torch.testing.assert_close(hip_ops.layer_norm(x, w, b).float(), ref, rtol=2e-3, atol=2e-3)
     xt = x.transpose(0, 1)
     torch.testing.assert_close(hip_ops.layer_norm(xt, w, b).float(), ref.transpose(0, 1), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 8, 12, 192), (2, 7, 9, 192), (1, 20, 30, 384), (2, 10, 14, 768), (1, 5, 6, 64)])
+def test_patch_merge_layernorm_equals_gather_then_layernorm(B, H, W, C):
+    """codetr_patch_merge_layernorm_f16 == (2x2 gather in (ky, kx, c) order, zero-padded) -> codetr_layernorm_f16,
+    bit for bit (same statistics arithmetic on the same values)."""
+    import torch.nn.functional as F
+    from codetr import _cabi, hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(H * 31 + W)
+    x = torch.randn(B, H * W, C, device=DEV, generator=g).half()
+    gam = (1 + 0.1 * torch.randn(4 * C, device=DEV, generator=g)).half()
+    bet = (0.1 * torch.randn(4 * C, device=DEV, generator=g)).half()
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    x4 = F.pad(x.view(B, H, W, C), (0, 0, 0, W % 2, 0, H % 2))
+    merged = x4.view(B, H2, 2, W2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H2 * W2, 4 * C)
+    ref = hip_ops.layer_norm(merged, gam, bet, 1e-5)
+    before = _cabi.CALLS["patch_merge_layernorm"]
+    y = hip_ops.patch_merge_layernorm(x, (H, W), gam, bet, 1e-5)      # odd sizes: the kernel pads with zeros itself
+    assert _cabi.CALLS["patch_merge_layernorm"] == before + 1
+    assert y.shape == ref.shape and torch.equal(y, ref)
