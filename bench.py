@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8,
                     help="images per GPU per step (default 8 = BASELINE config 4: batch 64 sharded over 8 GPUs)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="sub-batches replayed concurrently on separate HIP streams (graph mode; 1 = single stream)")
     ap.add_argument("--res", default="1920x1280", help="WxH")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="do not replay the forward from a captured hipGraph")
@@ -270,36 +272,56 @@ def main():
 
     gathered = torch.empty(world * a.batch, 300, 6, device=device, dtype=torch.float32) if world > 1 else None
 
-    def forward():
-        with torch.no_grad():
-            boxes, scores, labels = model(images, masks)
-        return pack_detections(boxes, scores, labels)  # [B,300,6] fp32
+    # The per-GPU batch is cut into `streams` sub-batches, each captured into its own hipGraph on its own HIP stream and
+    # replayed concurrently: kernels of different phases (MFMA-bound GEMMs, the L2-bound MSDA gather, HBM-bound norms,
+    # store-bound epilogues) of the two sub-batches overlap on the chip (measured -2.7 % ms/image at 2 x 4 images).
+    nstreams = max(1, min(a.streams, a.batch)) if not a.no_graph else 1
+    bounds = [(i * a.batch) // nstreams for i in range(nstreams + 1)]
+    subs = [(images[bounds[i]:bounds[i + 1]].contiguous(), masks[bounds[i]:bounds[i + 1]].contiguous())
+            for i in range(nstreams)]
+    static_out = torch.empty(a.batch, 300, 6, device=device, dtype=torch.float32)
 
-    static_out = None
-    graph = None
+    def forward(i):
+        with torch.no_grad():
+            boxes, scores, labels = model(*subs[i])
+        static_out[bounds[i]:bounds[i + 1]].copy_(pack_detections(boxes, scores, labels))  # [b,300,6] fp32
+
+    graphs = None
     # eager warm-up first (builds the shape-keyed caches, lets the allocator settle)
     for _ in range(max(2, min(a.warmup, 3))):
-        static_out = forward()
+        for i in range(nstreams):
+            forward(i)
     torch.cuda.synchronize(device)
+    side = [torch.cuda.Stream(device) for _ in range(nstreams)]
     if not a.no_graph:
         try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = forward()
-            graph.replay()
+            graphs = []
+            for i in range(nstreams):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side[i]):
+                    with torch.cuda.graph(gr, stream=side[i]):
+                        forward(i)
+                graphs.append(gr)
             torch.cuda.synchronize(device)
         except Exception as e:  # noqa: BLE001 -- report and run eagerly; the number is still valid, just launch-bound
             if rank == 0:
                 print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
+            graphs = None
             torch.cuda.synchronize(device)
+    graph = graphs  # (name kept for the report below)
 
     def step():
-        nonlocal static_out
-        if graph is not None:
-            graph.replay()
+        main = torch.cuda.current_stream(device)
+        if graphs is not None:
+            for i in range(nstreams):
+                side[i].wait_stream(main)       # the previous step's consumers are done with static_out
+                with torch.cuda.stream(side[i]):
+                    graphs[i].replay()
+            for i in range(nstreams):
+                main.wait_stream(side[i])
         else:
-            static_out = forward()
+            for i in range(nstreams):
+                forward(i)
         if world > 1:
             gather_detections(static_out, world * a.batch, out=gathered)  # the only collective: 7.2 KB per image
 
@@ -349,7 +371,7 @@ def main():
                 "workload": "CoDETR.forward, Co-DINO 5-scale Swin-L, %s, batch %d per GPU, 900 queries, 300 detections"
                             % (a.res, a.batch),
                 "global_batch": a.batch * world, "parallelism": "image-sharded replicas x%d" % world,
-                "hipgraph": graph is not None,
+                "hipgraph": graph is not None, "streams": nstreams,
                 "native_kernels": sorted(__import__("codetr.hip_ops", fromlist=["NATIVE"]).NATIVE),
             },
             "reference_note": "reference publishes 79.5 ms/image (TensorRT fp16, RTX 4090, batch 1, README.md:33); "
