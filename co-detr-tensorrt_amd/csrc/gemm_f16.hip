@@ -832,15 +832,17 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
   }
 }
 
-// the 256-tile kernel is used when it fills the chip at least twice over and N wastes little of a 256-wide tile
+// the 256-tile kernel: K >= 384 (Swin stages 1-3), see the rule at the end
 bool big_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
   static const int off = [] {
     const char* e = getenv("CODETR_GEMM_BIG");
     return e ? atoi(e) == 0 : 0;
   }();
-  if (off || hm_hd != 0 || K < 512 || K % 64 != 0 || N % 8 != 0) return false;
+  if (off || hm_hd != 0 || K < 384 || K % 64 != 0 || N % 8 != 0) return false;
   const int64_t tn = (N + 255) / 256, tm = (M + 255) / 256;
-  return tm * tn >= 512 && N * 8 >= tn * 256 * 7;  // >= 87.5 % of the tile columns are real
+  // enough tiles to fill the chip twice, and little of the 256-wide tile wasted: >= 87.5 % of the tile columns real,
+  // or >= 75 % when one column tile covers N (X is then read exactly once: Swin stage-0 fc2, N = 192, 806 -> 678 us)
+  return tm * tn >= 512 && (N * 8 >= tn * 256 * 7 || (tn == 1 && N * 4 >= 256 * 3));
 }
 
 template <class T, int ACT>
