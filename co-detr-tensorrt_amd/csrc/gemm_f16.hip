@@ -840,9 +840,11 @@ bool big_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
   }();
   if (off || hm_hd != 0 || K < 384 || K % 64 != 0 || N % 8 != 0) return false;
   const int64_t tn = (N + 255) / 256, tm = (M + 255) / 256;
-  // enough tiles to fill the chip twice, and little of the 256-wide tile wasted: >= 87.5 % of the tile columns real,
+  static const int64_t kBigMinTiles = [] { const char* e = getenv("CODETR_BIG_MIN_TILES"); return e ? atoll(e) : 200; }();
+  // at least ~0.8 tiles per CU (CODETR_BIG_MIN_TILES; 200 measured better than 512 for the single-image shapes: Swin
+  // stage-2 fc1 78 -> 67 us, stage-3 qkv 58 -> 46 us), and little of the 256-wide tile wasted: >= 87.5 % of the tile columns real,
   // or >= 75 % when one column tile covers N (X is then read exactly once: Swin stage-0 fc2, N = 192, 806 -> 678 us)
-  return tm * tn >= 512 && (N * 8 >= tn * 256 * 7 || (tn == 1 && N * 4 >= 256 * 3));
+  return tm * tn >= kBigMinTiles && (N * 8 >= tn * 256 * 7 || (tn == 1 && N * 4 >= 256 * 3));
 }
 
 template <class T, int ACT>
