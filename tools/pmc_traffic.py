@@ -32,7 +32,8 @@ def main():
     fetch = fold(sys.argv[1], "FETCH_SIZE")
     write = fold(sys.argv[2], "WRITE_SIZE")
     forwards = int(sys.argv[3])
-    groups = {"linear_kernel": "linear_kernel", "msda_tiled_kernel": "msda", "ffn_fused_kernel": "ffn_fused",
+    # "linear_": linear_kernel + linear_xs_kernel + linear_256_kernel + splitk_reduce: every launch behind hip_ops.linear
+    groups = {"linear_": "linear_kernel", "msda_tiled_kernel": "msda", "ffn_fused_kernel": "ffn_fused",
               "window_attention_kernel": "window_attention", "layernorm_kernel": "layernorm"}
     out = {"unit": "bytes", "forwards_profiled": forwards,
            "note": "FETCH_SIZE / WRITE_SIZE (KiB) x 1024; read_corrected = 2 x read_raw (gfx950 128-B requests tallied as 64 B)",
