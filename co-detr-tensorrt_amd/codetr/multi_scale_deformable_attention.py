@@ -98,9 +98,11 @@ class MultiScaleDeformableAttention(nn.Module):
 
     # ------------------------------------------------------------------ batch-first core
     def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
-                   level_start_index, query_plus_pos=None):
+                   level_start_index, query_plus_pos=None, value_projected=None):
         """query [B,Nq,C]; value [B,S,C]; returns output_proj(msda(...)) + identity, [B,Nq,C].
-        query_plus_pos: `query + query_pos` if the caller already holds it."""
+        query_plus_pos: `query + query_pos` if the caller already holds it.  value_projected [B,S,C]: this module's
+        value_proj(value) with the padding mask applied, if the caller already computed it (the decoder projects the
+        memory for all its layers in one GEMM)."""
         if query_plus_pos is not None:
             query = query_plus_pos
         elif query_pos is not None:
@@ -125,7 +127,10 @@ class MultiScaleDeformableAttention(nn.Module):
                                      L, P, head_major=True)
             return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
         # value projection with the padding mask folded into the GEMM epilogue (reference :173-176)
-        v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask)
+        if value_projected is not None:
+            v = value_projected
+        else:
+            v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask)
         v = v.view(B, S, H, -1)
         if query.is_cuda and hip_ops.msda_fused_supported(v.dtype, v.shape[-1], L, P):
             # one GEMM for (offsets | logits); softmax and location arithmetic happen inside the MSDA kernel

@@ -121,6 +121,7 @@ class DinoTransformerDecoder(nn.Module):
         """query [B,Nq,C], value [B,S,C], reference_points [B,Nq,4] unactivated."""
         out = query
         vr = torch.cat((valid_ratios, valid_ratios), -1) if reference_points.shape[-1] == 4 else valid_ratios
+        v_all = self._project_values(value, key_padding_mask)
         for lid, layer in enumerate(self.layers):
             if hip_ops.query_sine_embed_supported(reference_points, valid_ratios, self.embed_dims // 2):
                 ref_in, sine = hip_ops.query_sine_embed(reference_points, valid_ratios, self.embed_dims // 2)
@@ -129,13 +130,50 @@ class DinoTransformerDecoder(nn.Module):
                 sine = self.gen_sineembed_for_position(ref_in[:, :, 0, :], self.embed_dims // 2)
             qpos = run_mlp(self.ref_point_head, sine)
             out = layer.forward_bf(out, None, value, query_pos=qpos, key_padding_mask=key_padding_mask,
-                                   reference_points=ref_in, **kw)
+                                   reference_points=ref_in, value_projected=None if v_all is None else v_all[lid], **kw)
             if reg_branches is not None:
                 if reference_points.shape[-1] != 4:
                     raise AssertionError("box refinement needs 4-d reference points")
                 reference_points = run_mlp(reg_branches[lid], out, residual=reference_points)  # no detach / sigmoid
         out = hip_ops.layer_norm(out, self.norm.weight, self.norm.bias, self.norm.eps)
         return out, reference_points
+
+    def _cross_attentions(self):
+        from .multi_scale_deformable_attention import MultiScaleDeformableAttention
+        atts = []
+        for layer in self.layers:
+            ai = 0
+            for op in layer.operation_order:
+                if op in ("self_attn", "cross_attn"):
+                    if op == "cross_attn":
+                        atts.append(layer.attentions[ai])
+                    ai += 1
+        ok = len(atts) == len(self.layers) and all(isinstance(a, MultiScaleDeformableAttention) for a in atts)
+        return atts if ok else None
+
+    def _project_values(self, memory, key_padding_mask):
+        """value_proj(memory) of EVERY layer's cross-attention as one GEMM (N = layers * 256): the memory [B,S,256] is
+        read once instead of once per layer; the output is laid out [layer][B*S][256], so each layer's value map is a
+        contiguous [B,S,M,D] tensor.  None when the fused form does not apply (then every layer projects itself)."""
+        atts = self._cross_attentions()
+        if atts is None or not memory.is_cuda or memory.dtype != torch.float16 or torch.is_grad_enabled():
+            return None
+        C = atts[0].value_proj.out_features
+        if (any(a.value_proj.out_features != C or a.value_proj.in_features != memory.shape[-1] or a.value_proj.bias is None
+                for a in atts) or C % 64 != 0 or memory.shape[-1] not in (192, 256) or len(atts) * C > 1536
+                or memory.shape[0] * memory.shape[1] < 128 * 256):
+            return None
+        ps = [p for a in atts for p in (a.value_proj.weight, a.value_proj.bias)]
+        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
+        hit = getattr(self, "_vproj_cache", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = self._vproj_cache = (key, torch.cat([a.value_proj.weight for a in atts], 0).contiguous(),
+                                           torch.cat([a.value_proj.bias for a in atts], 0).contiguous())
+        B, S, K = memory.shape
+        mask = None if key_padding_mask is None else key_padding_mask.reshape(1, B * S)
+        y = hip_ops.linear(memory.reshape(1, B * S, K), hit[1], hit[2], row_mask=mask, head_major=C)  # [1, layers, B*S, C]
+        return [y[0, i].view(B, S, C) for i in range(len(atts))]
 
     def forward(self, query, *args, reference_points=None, valid_ratios=None, reg_branches=None, **kwargs):
         """reference layout: query (Nq, bs, C), value kwarg (S, bs, C); returns ((bs,Nq,C), (bs,Nq,4))."""

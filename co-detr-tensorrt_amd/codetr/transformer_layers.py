@@ -206,9 +206,10 @@ class BaseTransformerLayer(nn.Module):
                     val = query if op == "self_attn" else value
                     mask = query_key_padding_mask if op == "self_attn" else key_padding_mask
                     qpp = query_plus_pos if (ai == 0 and oi == 0) else None  # valid for the layer's input only
+                    vp = kw.get("value_projected") if op == "cross_attn" else None
                     query = att.forward_bf(query, val, query if res is None else res, query_pos, mask,
                                            kw["reference_points"], kw["spatial_shapes"], kw["level_start_index"],
-                                           query_plus_pos=qpp)
+                                           query_plus_pos=qpp, value_projected=vp)
                 else:
                     if op == "self_attn":
                         query = att.forward_bf(query, query, query, res, query_pos, query_pos)

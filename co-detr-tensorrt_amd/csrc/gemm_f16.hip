@@ -884,14 +884,15 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
                                                         const unsigned short* __restrict__ bias,
                                                         const unsigned short* __restrict__ R,
                                                         unsigned short* __restrict__ Y,
-                                                        const unsigned char* __restrict__ row_mask, int M, int N) {
+                                                        const unsigned char* __restrict__ row_mask, int M, int N, int hm_rows,
+                                                        int hm_hd) {
   constexpr int K = KS * 32, CH = K / 8;          // 16-byte chunks per row
   constexpr int CN = 32;                          // output columns per W chunk
   constexpr int kChunkBytes = CN * K * 2;         // 12 / 16 / 24 KiB
   constexpr int kPieces = kChunkBytes / 4096;     // LDS-DMA instructions per thread per chunk (3 / 4 / 6)
   constexpr int kXsPitch = 2 * CN * 2 + 16;       // staged output row: two chunks side by side, 128 B + 16
   constexpr int kStage = 4 * 32 * kXsPitch;       // 18 KiB: 4 waves x 32 rows
-  constexpr int kMaxBias = 1024;
+  constexpr int kMaxBias = 1568;
   constexpr int SWZ = (CH % 16 == 0) ? 15 : 7;    // XOR mask that keeps a swizzled chunk inside its row
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kChunkBytes + kStage + kMaxBias * 2];
   unsigned char* stage_base = lds + 2 * kChunkBytes;
@@ -1029,16 +1030,23 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
           for (int e = 0; e < 8; ++e)
             v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[it][e]));
         }
-        *reinterpret_cast<s16x8*>(Y + (size_t)m * N + n) = v;
+        size_t off = (size_t)m * N + n;
+        if (hm_hd > 0) {  // column-block-major destination y[b][n / hm_hd][position][n % hm_hd] (hm_hd % 64 == 0 here)
+          const int bb = m / hm_rows, pos = m - bb * hm_rows;
+          const int head = n / hm_hd, ch = n - head * hm_hd;
+          off = (((size_t)bb * (N / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
+        }
+        *reinterpret_cast<s16x8*>(Y + off) = v;
       }
     }
     __builtin_amdgcn_wave_barrier();  // the staging region is rewritten by the next pair
   }
 }
 
-// The short-K kernel serves f16 / bf16, K in {192, 256}, N % 8 == 0 (16-byte row chunks), 128 <= N <= 992 (bias in
+// The short-K kernel serves f16 / bf16, K in {192, 256}, N % 8 == 0 (16-byte row chunks), 128 <= N <= 1536 (bias in
 // LDS; narrower outputs measured equal or slower), at least one workgroup per CU (below that the tiled kernel's
-// N-parallelism wins), no head-major output.  K = 384 (Swin stage 1) fits the registers but measured 20-30 % slower
+// N-parallelism wins); column-block-major output only for blocks of a multiple of 64 columns (a stored chunk pair
+// must not straddle blocks: the six decoder value projections as one N = 1536 GEMM, not the 32-wide MSDA heads).  K = 384 (Swin stage 1) fits the registers but measured 20-30 % slower
 // than the tiled kernel (2 workgroups per CU, 48 MFMAs per barrier) and stays there.
 bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
   static const int off = [] {
@@ -1046,12 +1054,12 @@ bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
     return e ? atoi(e) == 0 : 0;
   }();
   if (off) return false;
-  return (K == 192 || K == 256) && N % 8 == 0 && N >= 128 && N <= 992 && M >= 128 * 256 && hm_hd == 0;
+  return (K == 192 || K == 256) && N % 8 == 0 && N >= 128 && N <= 1536 && M >= 128 * 256 && hm_hd % 64 == 0;
 }
 
 template <class T, int KS, int ACT>
 int launch_xs_res(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
-                  const void* mask, int M, int N) {
+                  const void* mask, int M, int N, int hm_rows, int hm_hd) {
   const dim3 grid((unsigned)((M + 127) / 128)), block(256);
   auto x = static_cast<const unsigned short*>(X);
   auto w = static_cast<const unsigned short*>(W);
@@ -1059,28 +1067,28 @@ int launch_xs_res(hipStream_t st, const void* X, const void* W, const void* bias
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (R) hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N);
-  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N);
+  if (R) hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, hm_rows, hm_hd);
+  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, hm_rows, hm_hd);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
 
 template <class T, int KS>
 int launch_xs_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
-                  const void* mask, int M, int N, int act) {
+                  const void* mask, int M, int N, int act, int hm_rows, int hm_hd) {
   switch (act) {
-    case 0: return launch_xs_res<T, KS, 0>(st, X, W, bias, R, Y, mask, M, N);
-    case 1: return launch_xs_res<T, KS, 1>(st, X, W, bias, R, Y, mask, M, N);
-    default: return launch_xs_res<T, KS, 2>(st, X, W, bias, R, Y, mask, M, N);
+    case 0: return launch_xs_res<T, KS, 0>(st, X, W, bias, R, Y, mask, M, N, hm_rows, hm_hd);
+    case 1: return launch_xs_res<T, KS, 1>(st, X, W, bias, R, Y, mask, M, N, hm_rows, hm_hd);
+    default: return launch_xs_res<T, KS, 2>(st, X, W, bias, R, Y, mask, M, N, hm_rows, hm_hd);
   }
 }
 
 template <class T>
 int launch_xs(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
-              int M, int N, int K, int act) {
+              int M, int N, int K, int act, int hm_rows, int hm_hd) {
   switch (K) {
-    case 192: return launch_xs_act<T, 6>(st, X, W, bias, R, Y, mask, M, N, act);
-    default: return launch_xs_act<T, 8>(st, X, W, bias, R, Y, mask, M, N, act);
+    case 192: return launch_xs_act<T, 6>(st, X, W, bias, R, Y, mask, M, N, act, hm_rows, hm_hd);
+    default: return launch_xs_act<T, 8>(st, X, W, bias, R, Y, mask, M, N, act, hm_rows, hm_hd);
   }
 }
 
@@ -1106,7 +1114,7 @@ int launch(hipStream_t st, const void* X, const void* W, const void* bias, const
   }
   if (xs_applicable(M, N, K, hm_hd) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
       (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0))
-    return launch_xs<T>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, act);
+    return launch_xs<T>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, act, (int)hm_rows, hm_hd);
   switch (act) {
     case 0: return launch_act<T, 0>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, (int)hm_rows, hm_hd);
     case 1: return launch_act<T, 1>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, (int)hm_rows, hm_hd);

@@ -280,3 +280,35 @@ def test_token_major_path_equals_nchw_path():
                 & ((b0[bi].float() - b1[bi, k].float()).abs().max(-1)[0] <= 1.0)
             matched += int(ok.any())
     assert matched >= 36, matched
+
+
+def test_decoder_projects_all_layer_values_in_one_gemm():
+    """DinoTransformerDecoder._project_values: value_proj(memory) of the six cross-attentions as one N = 1536 GEMM
+    (memory read once) == the six per-layer projections, bit for bit, padding mask included."""
+    from codetr import _cabi, hip_ops
+    from codetr.transformer import DinoTransformerDecoder
+
+    torch.manual_seed(0)
+    cfg = dict(type="DetrTransformerDecoderLayer",
+               attn_cfgs=[dict(type="MultiheadAttention", embed_dims=256, num_heads=8, dropout=0.0),
+                          dict(type="MultiScaleDeformableAttention", embed_dims=256, num_levels=5, dropout=0.0)],
+               feedforward_channels=2048, ffn_dropout=0.0,
+               operation_order=("self_attn", "norm", "cross_attn", "norm", "ffn", "norm"))
+    dec = DinoTransformerDecoder(return_intermediate=True, transformerlayers=cfg, num_layers=6).to(DEV).half().eval()
+    for layer in dec.layers:  # distinct, non-trivial projections
+        torch.nn.init.normal_(layer.attentions[1].value_proj.weight, std=0.05)
+        torch.nn.init.normal_(layer.attentions[1].value_proj.bias, std=0.5)
+    B, S = 2, 20000
+    g = torch.Generator(device=DEV).manual_seed(3)
+    mem = torch.randn(B, S, 256, device=DEV, generator=g).half()
+    mask = torch.rand(B, S, device=DEV, generator=g) < 0.2
+    before = _cabi.CALLS["linear"]
+    with torch.no_grad():
+        vs = dec._project_values(mem, mask)
+    assert vs is not None and len(vs) == 6 and _cabi.CALLS["linear"] == before + 1
+    for lid, layer in enumerate(dec.layers):
+        vp = layer.attentions[1].value_proj
+        ref = hip_ops.linear(mem, vp.weight, vp.bias, row_mask=mask)
+        assert vs[lid].shape == ref.shape and vs[lid].is_contiguous() and torch.equal(vs[lid], ref)
+    with torch.no_grad():
+        assert dec._project_values(mem[:, :100], mask[:, :100]) is None  # short memories: per-layer projections
