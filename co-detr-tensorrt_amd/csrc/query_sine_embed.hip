@@ -50,9 +50,9 @@ __global__ __launch_bounds__(256) void query_sine_embed_kernel(const _Float16* _
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int f = (ch0 >> 1) + p;
-    const float a = e * __builtin_amdgcn_exp2f(-log2_temperature * (2.0f * (float)f / (float)F));
-    o[2 * p] = (_Float16)sinf(a);
-    o[2 * p + 1] = (_Float16)cosf(a);
+    const float rev = e * __builtin_amdgcn_exp2f(-log2_temperature * (2.0f * (float)f / (float)F)) * 0.15915494309189535f;
+    o[2 * p] = (_Float16)__builtin_amdgcn_sinf(rev);  // v_sin_f32 on revolutions (angle <= 2 pi here)
+    o[2 * p + 1] = (_Float16)__builtin_amdgcn_cosf(rev);
   }
   *reinterpret_cast<f16x8*>(embed + row * (int64_t)(ref_dim * F) + c * 8) = o;
 }

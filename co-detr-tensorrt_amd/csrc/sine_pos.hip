@@ -45,9 +45,12 @@ __global__ __launch_bounds__(kThreads) void sine_pos_kernel(const float* __restr
     for (int p = 0; p < 4; ++p) {
       const int f = (ch0 >> 1) + p;  // frequency index: channels 2f, 2f+1
       const float inv = __builtin_amdgcn_exp2f(-log2_temperature * (2.0f * (float)f / (float)num_feats));
-      const float a = e * inv;
-      o[2 * p] = (_Float16)sinf(a);
-      o[2 * p + 1] = (_Float16)cosf(a);
+      // v_sin_f32 / v_cos_f32 take revolutions and reduce the argument themselves (valid to +-256 revolutions; the
+      // angle here is <= scale + a little, ~1 revolution); ~1e-6 absolute, far inside the f16 rounding of the result,
+      // and ~10x fewer instructions than libm's sinf / cosf with their own range reduction
+      const float rev = e * inv * 0.15915494309189535f;
+      o[2 * p] = (_Float16)__builtin_amdgcn_sinf(rev);
+      o[2 * p + 1] = (_Float16)__builtin_amdgcn_cosf(rev);
     }
     if (level_embed) {
       const f16x8 le = *reinterpret_cast<const f16x8*>(level_embed + c * 8);
