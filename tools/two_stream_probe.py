@@ -60,3 +60,22 @@ for nstreams, per in ((2, 4), (4, 2), (2, 8)):
 
     t = timed(step)
     print(f"{nstreams} streams x {per} images: {t * 1e3:.2f} ms/step = {t * 1e3 / (nstreams * per):.3f} ms/image")
+
+# free-running streams with an initial skew of half a forward (no per-step join)
+streams = [torch.cuda.Stream() for _ in range(2)]
+graphs = [make_graph(4, st)[0] for st in streams]
+for skew_ms in (0, 25, 50):
+    def run(steps):
+        for j, (st, gr) in enumerate(zip(streams, graphs)):
+            with torch.cuda.stream(st):
+                if j == 1 and skew_ms:
+                    torch.cuda._sleep(int(skew_ms * 2.0e6))   # ~2 GHz cycles
+                for _ in range(steps):
+                    gr.replay()
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(10)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 10
+    print(f"free-running 2 x 4 images, initial skew {skew_ms} ms: {t * 1e3:.2f} ms/step = {t * 1e3 / 8:.3f} ms/image (skew included)")
