@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -36,6 +36,10 @@ SIGNATURES = {
                                              _i32, _i32, _i32, _i64, _i32, _vp]),
     "codetr_msda_fused_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _i64,
                                               _i32, _i32, _i32, _i64, _i32, _vp]),
+    "codetr_msda_encoder_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32,
+                                               _i32, _i32, _vp]),
+    "codetr_msda_encoder_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32,
+                                                _i32, _i32, _vp]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp]),
@@ -72,7 +76,7 @@ _lib = None
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
-         "msda_backward": 0, "patch_merge_layernorm": 0}
+         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0}
 
 
 def load():
@@ -380,6 +384,31 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
         ref.data_ptr(), ref.shape[-1], 1 if head_major else 0, B, S, M, D, num_levels, Nq, num_points, out.data_ptr())
     check(rc, "codetr_msda_fused_forward")
     return out
+
+
+_MSDA_ENCODER_BY_DTYPE = {torch.float16: "codetr_msda_encoder_forward_f16",
+                          torch.bfloat16: "codetr_msda_encoder_forward_bf16"}
+E_UNSUPPORTED = -4
+
+
+def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points, halo, out) -> bool:
+    """Encoder self-attention form (queries = pixels of the pyramid): value [B,S,M,32]; level_shapes = host
+    list of (h, w); proj / ref as msda_fused (ref [B,S,L,2]).  Returns False when the library reports the shape
+    as unsupported (the caller then uses msda_fused), raises on any other error."""
+    lib = load()
+    B, S, M, D = value.shape
+    L = len(level_shapes)
+    shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
+    ncols, es = proj.shape[2], proj.element_size()
+    rc = getattr(lib, _MSDA_ENCODER_BY_DTYPE[value.dtype])(
+        current_stream_ptr(value.device), value.data_ptr(), ctypes.cast(shapes, ctypes.c_void_p),
+        proj.data_ptr() + off_col * es, ncols, proj.data_ptr() + logit_col * es, ncols, ref.data_ptr(), B, S, M, D, L,
+        num_points, int(halo), out.data_ptr())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "codetr_msda_encoder_forward")
+    CALLS["msda_encoder"] += 1
+    return True
 
 
 def groupnorm_tokens_supported(x, groups) -> bool:

@@ -415,6 +415,32 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
     return out
 
 
+MSDA_ENCODER = os.environ.get("CODETR_MSDA_ENC", "1") != "0"      # A/B switch: 0 = general fused kernel in the encoder
+MSDA_HALO = int(os.environ.get("CODETR_MSDA_HALO", "4"))          # staged offset range, pixels of the sampled level
+
+
+def msda_encoder(value, level_shapes, proj, off_col, logit_col, reference_points, num_points):
+    """Encoder self-attention form of msda_fused (queries = the pixels of the pyramid, 2-d reference points): the
+    gather runs out of LDS-staged neighbourhoods.  level_shapes: host sequence of (h, w).  Returns None when the
+    library does not take the shape (caller falls back to msda_fused) -- results are identical either way."""
+    _gpu(value, "msda_encoder")
+    B, S, M, D = value.shape
+    if not (MSDA_ENCODER and D == 32 and value.dtype in (torch.float16, torch.bfloat16)
+            and proj.shape[1] == S and reference_points.shape[-1] == 2 and len(level_shapes) <= 8):
+        return None
+    out = torch.empty((B, S, M * D), dtype=value.dtype, device=value.device)
+    ok = [True]
+
+    def run():
+        ok[0] = _cabi.msda_encoder(value.contiguous(), level_shapes, proj.contiguous(), off_col, logit_col,
+                                   reference_points.to(value.dtype).contiguous(), num_points, MSDA_HALO, out)
+
+    with torch.cuda.device(value.device):
+        _timed("msda_fused", {"B": B, "S": S, "Nq": S, "M": M, "D": D, "L": len(level_shapes), "P": num_points},
+               run, value.device)
+    return out if ok[0] else None
+
+
 def msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step):
     """The reference's native op, hand-written HIP behind the C ABI (always native)."""
     return torch.ops.codetr.multi_scale_deformable_attention(

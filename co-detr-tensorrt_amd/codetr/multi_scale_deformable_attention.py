@@ -136,8 +136,14 @@ class MultiScaleDeformableAttention(nn.Module):
             # one GEMM for (offsets | logits); softmax and location arithmetic happen inside the MSDA kernel
             Wc, bc = self._fused_projection()
             proj = hip_ops.linear(query, Wc, bc)
-            out = hip_ops.msda_fused(v, spatial_shapes, level_start_index, proj, 0, H * L * P * 2, reference_points,
-                                     L, P)
+            out = None
+            host_shapes = getattr(spatial_shapes, "_codetr_host", None)
+            if host_shapes is not None and Nq == S and reference_points.shape[-1] == 2:
+                # encoder self-attention: queries are the pixels of the pyramid -> LDS-staged gather
+                out = hip_ops.msda_encoder(v, host_shapes, proj, 0, H * L * P * 2, reference_points, P)
+            if out is None:
+                out = hip_ops.msda_fused(v, spatial_shapes, level_start_index, proj, 0, H * L * P * 2,
+                                         reference_points, L, P)
             return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
         offsets = hip_ops.linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias)
         offsets = offsets.view(B, Nq, H, L, P, 2)

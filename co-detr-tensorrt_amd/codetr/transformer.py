@@ -290,6 +290,7 @@ def _shape_tensors(shapes, device):
     if hit is None:
         ss = torch.as_tensor(shapes, dtype=torch.long, device=device)
         counts = ss.prod(1)
+        ss._codetr_host = tuple((int(h), int(w)) for h, w in shapes)   # host copy for launch geometry (no sync)
         hit = (ss, torch.cat((ss.new_zeros((1,)), counts.cumsum(0)[:-1])))
         _SHAPE_TENSORS[key] = hit
     return hit

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 21
+#define CODETR_HIP_ABI_VERSION 22
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -114,6 +114,32 @@ int codetr_msda_fused_forward_bf16(void *stream, const void *value_dev, const in
                                    const void *logits_dev, int64_t logits_row_stride, const void *ref_dev, int ref_dim,
                                    int value_head_major, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,
                                    void *out_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder self-attention form of the fused op (same arithmetic, bit-identical results; LDS-staged gather).
+ *
+ * For DetrTransformerEncoder (codetr/transformer.py:81-92), where the queries ARE the pixels of the flattened
+ * multi-level map (Nq == S, query q = pixel q) and reference_points are 2-d (get_reference_points,
+ * codetr/transformer.py:280-305): a workgroup serves every query of one 64x32-image-pixel region for one head
+ * and first stages the region's neighbourhood on every level in LDS, so each value row crosses L2 -> CU once
+ * per region instead of once per sample.  Samples that leave the staged neighbourhood (offsets beyond `halo`
+ * pixels of the sampled level) are read from global memory: `halo` changes speed, never results.
+ *
+ *   value_dev          [B, S, M, D]   D == 32, 16-bit storage
+ *   level_shapes_host  [L][2] (h, w) HOST copy of spatial_shapes (the launch geometry depends on it); sum h*w == S
+ *   offsets / logits / ref as for codetr_msda_fused_forward_* with ref_dim == 2
+ *   halo               staged offset range in pixels of the sampled level (4 = the reference's initialisation,
+ *                      multi_scale_deformable_attention.py:90-115); CODETR_E_UNSUPPORTED if the neighbourhoods
+ *                      of one region exceed 160 KB of LDS (callers fall back to codetr_msda_fused_forward_*)
+ * ------------------------------------------------------------------------------------------ */
+int codetr_msda_encoder_forward_f16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
+                                    const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
+                                    int64_t logits_row_stride, const void *ref_dev, int64_t B, int64_t S, int M, int D,
+                                    int L, int P, int halo, void *out_dev);
+int codetr_msda_encoder_forward_bf16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
+                                     const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
+                                     int64_t logits_row_stride, const void *ref_dev, int64_t B, int64_t S, int M,
+                                     int D, int L, int P, int halo, void *out_dev);
 
 /* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
  * Pure host function; lets tests assert that the model shape takes the tiled path. */

@@ -1,0 +1,68 @@
+"""Encoder MSDA at BASELINE's pyramid: LDS-staged kernel (codetr_msda_encoder_forward_f16) against the general fused
+kernel on the same inputs.  Offsets follow the reference's initialisation (multi_scale_deformable_attention.py:90-115:
+head m points along angle 2 pi m / M, point p at distance p + 1 pixels) plus Gaussian noise of `--noise` pixels.
+    python tools/bench_msda_encoder.py [--batch 1] [--noise 0.5] [--halo 4]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "co-detr-tensorrt_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--noise", type=float, default=0.5)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    from codetr import hip_ops
+
+    dev = "cuda:0"
+    shapes = [(320, 480), (160, 240), (80, 120), (40, 60), (20, 30)]
+    B, M, D, L, P = a.batch, 8, 32, 5, 4
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator(device=dev).manual_seed(0)
+    value = torch.randn(B, S, M, D, device=dev, generator=g).half()
+    th = torch.arange(M, device=dev) * (2 * math.pi / M)
+    grid = torch.stack((th.cos(), th.sin()), -1)
+    grid = grid / grid.abs().max(-1, keepdim=True)[0]
+    off = grid[:, None, None, :] * (torch.arange(P, device=dev) + 1)[None, None, :, None]      # [M,1,P,2]
+    off = off.expand(M, L, P, 2)[None, None] + a.noise * torch.randn(B, S, M, L, P, 2, device=dev, generator=g)
+    logits = torch.randn(B, S, M * L * P, device=dev, generator=g)
+    proj = torch.cat((off.reshape(B, S, -1), logits), -1).half().contiguous()
+    refs = []
+    for h, w in shapes:
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev) + 0.5, torch.arange(w, device=dev) + 0.5, indexing="ij")
+        refs.append(torch.stack((xs.reshape(-1) / w, ys.reshape(-1) / h), -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(B, S, L, 2).half().contiguous()
+    ss = torch.tensor(shapes, dtype=torch.int64, device=dev)
+    ls = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.iters * 1e3
+
+    enc = lambda: hip_ops.msda_encoder(value, shapes, proj, 0, M * L * P * 2, ref, P)  # noqa: E731
+    gen = lambda: hip_ops.msda_fused(value, ss, ls, proj, 0, M * L * P * 2, ref, L, P)  # noqa: E731
+    o1, o2 = enc(), gen()
+    assert o1 is not None
+    same = torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+    t_enc, t_gen = timed(enc), timed(gen)
+    alg = 2 * (B * S * M * D + 3 * B * S * M * L * P + B * S * M * D)
+    print(f"batch {B} noise {a.noise} halo {hip_ops.MSDA_HALO}: encoder kernel {t_enc:8.1f} us "
+          f"({alg / t_enc / 1e6:6.2f} TB/s algorithmic)   general fused {t_gen:8.1f} us   identical: {same}")
+
+
+if __name__ == "__main__":
+    main()
