@@ -162,16 +162,21 @@ def kernel_rooflines(model, images, masks, device):
         }
     enc = [(a, b, m) for a, b, m in kprof.get("msda_fused", []) if m["Nq"] == m["S"]]
     if enc:
+        from codetr import _cabi as _cabi_mod
+
+        enc_native = _cabi_mod.CALLS.get("msda_encoder", 0) > 0   # the LDS-staged encoder kernel served the launches
         m = enc[0][2]
         e = 2
         # value + offsets (2 per point) + logits (1 per point) + output, each touched once
         nbytes = e * m["B"] * (m["S"] * m["M"] * m["D"] + 3 * m["Nq"] * m["M"] * m["L"] * m["P"] + m["Nq"] * m["M"] * m["D"])
         t = sum(a.elapsed_time(b) for a, b, _ in enc) * 1e-3 / len(enc)
         out["roofline_msda"] = {
-            "kernel": "msda_tiled_kernel<F16,4,fused> (the %d encoder launches of one forward, Nq = S = %d)" % (len(enc), m["S"]),
+            "kernel": "%s (the %d encoder launches of one forward, Nq = S = %d)" % (
+                "msda_encoder_kernel<F16,5,P4>" if enc_native else "msda_tiled_kernel<F16,4,fused>",
+                len(enc), m["S"]),
             "bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": pmc.get("msda", {}).get("hbm_bytes_largest_launch"),
+            "traffic": (pmc.get("msda_encoder", {}) if enc_native else pmc.get("msda", {})).get("hbm_bytes_largest_launch"),
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(t * 1e6, 1),
         }
     return out

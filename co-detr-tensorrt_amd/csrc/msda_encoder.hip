@@ -32,6 +32,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "codetr_hip.h"
 
 namespace {
@@ -279,24 +281,46 @@ __device__ __forceinline__ void process_queries(const Raw<TR, KMAX>& raw, const 
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 
+  const bool wave_clean = __builtin_amdgcn_ballot_w64(bad != 0) == 0;  // every sample of the 16 pairs is in LDS
   if (ablate & 2) {
-  } else if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) {
-    // ---- every sample of these 16 pairs is served from LDS ----
-    if (P4) {
-      // L*P = 4 L: two points per step, the rows of step s + 1 requested before the FMAs of step s
+  } else if (P4) {
+    // L*P = 4 L: two points per step, the rows of step s + 1 requested before the FMAs of step s.  CHECK: a point
+    // that some pair of the wave has outside its staged neighbourhood is re-read from global memory by those lanes.
+    auto run = [&](auto check_c) {
+      constexpr bool CHECK = decltype(check_c)::value;
       constexpr int NS = 2 * KMAX;  // steps
       V rows[2][2][4];
       float ww[2][2][4];
       auto fetch = [&](int s_, int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+          const int pt = 2 * s_ + u, o = pt & 3, k = pt >> 2;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const int o = (2 * s_ + u) & 3;
-            const unsigned a = quad_bcast_u(ad[s_ >> 1][c], o) + lane_byte;
-            ww[buf][u][c] = quad_bcast_f(wt[s_ >> 1][c], o);
+            const unsigned a = quad_bcast_u(ad[k][c], o) + lane_byte;
+            ww[buf][u][c] = quad_bcast_f(wt[k][c], o);
             rows[buf][u][c] = *reinterpret_cast<const V*>(patch + a);
           }
+          if (CHECK) {
+            const bool mine = (bad >> pt) & 1u;
+            if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+              const unsigned hwb = quad_bcast_u(hw[k], o);
+              if (mine) {
+                const int* mt = s_meta + k * kMetaInts;
+                const int H = mt[0], W = mt[1];
+                const int h0 = (int)(short)(hwb >> 16), w0 = (int)(short)(hwb & 0xffffu);
+                const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
+                const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
+                const unsigned st = (unsigned)mt[2];
+                const unsigned char* vb = vimg + lane_byte;
+                rows[buf][u][0] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h0c * W + w0c)) * pix_bytes));
+                rows[buf][u][1] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h0c * W + w1c)) * pix_bytes));
+                rows[buf][u][2] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h1c * W + w0c)) * pix_bytes));
+                rows[buf][u][3] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h1c * W + w1c)) * pix_bytes));
+              }
+            }
+          }
+        }
       };
       fetch(0, 0);
 #pragma unroll
@@ -312,35 +336,39 @@ __device__ __forceinline__ void process_queries(const Raw<TR, KMAX>& raw, const 
                 acc[j] = __builtin_fmaf(ww[s_ & 1][u][c], TR::to_f32(rows[s_ & 1][u][c][j]), acc[j]);
         }
       }
-    } else {
+    };
+    if (wave_clean)
+      run(std::false_type{});
+    else
+      run(std::true_type{});
+  } else if (wave_clean) {
 #pragma unroll
-      for (int p0 = 0; p0 < 4 * KMAX; p0 += 4) {
-        if (p0 < LP) {
-          V rows[4][4];
-          float ww[4][4];
+    for (int p0 = 0; p0 < 4 * KMAX; p0 += 4) {
+      if (p0 < LP) {
+        V rows[4][4];
+        float ww[4][4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (p0 + u < LP) {
+        for (int u = 0; u < 4; ++u)
+          if (p0 + u < LP) {
 #pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const unsigned a = quad_bcast_u(ad[p0 >> 2][c], u) + lane_byte;
-                ww[u][c] = quad_bcast_f(wt[p0 >> 2][c], u);
-                rows[u][c] = *reinterpret_cast<const V*>(patch + a);
-              }
+            for (int c = 0; c < 4; ++c) {
+              const unsigned a = quad_bcast_u(ad[p0 >> 2][c], u) + lane_byte;
+              ww[u][c] = quad_bcast_f(wt[p0 >> 2][c], u);
+              rows[u][c] = *reinterpret_cast<const V*>(patch + a);
             }
+          }
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (p0 + u < LP) {
+        for (int u = 0; u < 4; ++u)
+          if (p0 + u < LP) {
 #pragma unroll
-              for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(ww[u][c], TR::to_f32(rows[u][c][j]), acc[j]);
-            }
-        }
+              for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(ww[u][c], TR::to_f32(rows[u][c][j]), acc[j]);
+          }
       }
     }
   } else {
-    // ---- checked loop: samples outside the staged neighbourhood come from global memory ----
+    // ---- checked loop (any L, P): samples outside the staged neighbourhood come from global memory ----
 #pragma unroll
     for (int p0 = 0; p0 < 4 * KMAX; p0 += 4) {
       if (p0 < LP) {
@@ -358,7 +386,7 @@ __device__ __forceinline__ void process_queries(const Raw<TR, KMAX>& raw, const 
             rows[c] = *reinterpret_cast<const V*>(patch + a);
           }
           if ((bad >> pt) & 1u) {
-            const int* mt = s_meta + (P4 ? (pt >> 2) : pt / P) * kMetaInts;
+            const int* mt = s_meta + (pt / P) * kMetaInts;
             const int H = mt[0], W = mt[1];
             const int h0 = (int)(short)(hwb >> 16), w0 = (int)(short)(hwb & 0xffffu);
             const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);

@@ -1,6 +1,6 @@
 """Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --no-graph` into per-kernel HBM-side traffic.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <forwards> > profiles/...json
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <forwards | 0 = count them> > profiles/...json
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 tallies a
 128-byte request as 64 bytes for wide coalesced reads, so the corrected read traffic is 2 x FETCH_SIZE; WRITE_SIZE is
@@ -32,8 +32,10 @@ def main():
     fetch = fold(sys.argv[1], "FETCH_SIZE")
     write = fold(sys.argv[2], "WRITE_SIZE")
     forwards = int(sys.argv[3])
+    if forwards <= 0:  # derive: encoder_geometry_kernel runs once per forward
+        forwards = int(sum(v[0] for n, v in fetch.items() if "encoder_geometry_kernel" in n)) or 1
     # "linear_": linear_kernel + linear_xs_kernel + linear_256_kernel + splitk_reduce: every launch behind hip_ops.linear
-    groups = {"linear_": "linear_kernel", "msda_tiled_kernel": "msda", "ffn_fused_kernel": "ffn_fused",
+    groups = {"linear_": "linear_kernel", "msda_tiled_kernel": "msda", "msda_encoder_kernel": "msda_encoder", "ffn_fused_kernel": "ffn_fused",
               "window_attention_kernel": "window_attention", "layernorm_kernel": "layernorm"}
     out = {"unit": "bytes", "forwards_profiled": forwards,
            "note": "FETCH_SIZE / WRITE_SIZE (KiB) x 1024; read_corrected = 2 x read_raw (gfx950 128-B requests tallied as 64 B)",
