@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -40,6 +40,7 @@ SIGNATURES = {
                                                _i32, _i32, _vp]),
     "codetr_msda_encoder_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32,
                                                 _i32, _i32, _vp]),
+    "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp]),
@@ -76,7 +77,7 @@ _lib = None
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
-         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0}
+         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0}
 
 
 def load():
@@ -409,6 +410,16 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points,
     check(rc, "codetr_msda_encoder_forward")
     CALLS["msda_encoder"] += 1
     return True
+
+
+def patch_im2col(x, k, kpad, out):
+    """x [B,C,H,W] 16-bit -> out [B*ceil(H/k)*ceil(W/k), kpad] patch rows in (c, ky, kx) order, zero padded."""
+    lib = load()
+    CALLS["patch_im2col"] += 1
+    B, C, H, W = x.shape
+    rc = lib.codetr_patch_im2col_b16(current_stream_ptr(x.device), x.data_ptr(), B, C, H, W, k, kpad, out.data_ptr())
+    check(rc, "codetr_patch_im2col_b16")
+    return out
 
 
 def groupnorm_tokens_supported(x, groups) -> bool:

@@ -25,7 +25,9 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "query_sine_embed(f16: sigmoid x valid ratios + sine embedding of the decoder reference boxes)",
           "encoder_geometry(f16: reference points, proposals, keep/drop state)", "row_max(f16)",
           "preprocess_image(u8 -> f16/f32, cv2-exact resize + pad + normalise + mask)", "batched_nms(f32)",
-          "patch_merge_layernorm(f16: Swin 2x2 gather + LayerNorm)"}
+          "patch_merge_layernorm(f16: Swin 2x2 gather + LayerNorm)",
+          "msda_encoder(f16/bf16: LDS-staged gather for the encoder's self-attention)",
+          "patch_embed(f16/bf16: 4x4 patch gather + GEMM)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -413,6 +415,33 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
                                             off_col, logit_col, reference_points.to(value.dtype).contiguous(),
                                             num_levels, num_points, out, head_major=head_major), value.device)
     return out
+
+
+PATCH_GEMM = os.environ.get("CODETR_PATCH_GEMM", "1") != "0"     # A/B switch: 0 = stem convolution through ATen / MIOpen
+
+
+def patch_embed_supported(x, weight, stride):
+    kh, kw = weight.shape[-2:]
+    return (PATCH_GEMM and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype
+            and kh == kw == 4 and tuple(stride) == (4, 4) and x.shape[1] * 16 <= 64 and not torch.is_grad_enabled())
+
+
+def patch_embed(x, weight, bias):
+    """PatchEmbed's Conv2d(C, E, 4, stride 4) with bottom / right zero padding as patch gather + GEMM: x [B,C,H,W] ->
+    ([B, Hp*Wp, E] token-major, (Hp, Wp)).  The weight padded to 64 columns is cached on the parameter."""
+    _gpu(x, "patch_embed")
+    B, C, H, W = x.shape
+    E = weight.shape[0]
+    Hp, Wp = -(-H // 4), -(-W // 4)
+    cache = getattr(weight, "_codetr_w64", None)
+    if cache is None or cache[0] != weight._version or cache[1].device != weight.device:
+        w64 = torch.zeros((E, 64), dtype=weight.dtype, device=weight.device)
+        w64[:, :C * 16] = weight.detach().reshape(E, C * 16)
+        cache = weight._codetr_w64 = (weight._version, w64)
+    cols = torch.empty((B * Hp * Wp, 64), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _cabi.patch_im2col(x.contiguous(), 4, 64, cols)
+    return linear(cols, cache[1], bias).view(B, Hp * Wp, E), (Hp, Wp)
 
 
 MSDA_ENCODER = os.environ.get("CODETR_MSDA_ENC", "1") != "0"      # A/B switch: 0 = general fused kernel in the encoder

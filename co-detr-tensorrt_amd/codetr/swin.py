@@ -39,6 +39,12 @@ class PatchEmbed(nn.Module):
         H, W = x.shape[-2:]
         kh, kw = self.kernel_size
         sh, sw = self.stride
+        if hip_ops.patch_embed_supported(x, self.projection.weight, self.stride):
+            # non-overlapping patches: gather + GEMM, token-major output, zero padding inside the gather
+            x, hw = hip_ops.patch_embed(x, self.projection.weight, self.projection.bias)
+            if self.norm is not None:
+                x = hip_ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+            return x, hw
         ph = max((-(-H // sh) - 1) * sh + kh - H, 0)
         pw = max((-(-W // sw) - 1) * sw + kw - W, 0)
         if ph or pw:

@@ -1056,7 +1056,8 @@ bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
     return e ? atoi(e) == 0 : 0;
   }();
   if (off) return false;
-  return (K == 192 || K == 256) && N % 8 == 0 && N >= 128 && N <= 1536 && M >= 128 * 256 && hm_hd % 64 == 0;
+  // (K = 64: the patch-embedding GEMM of the Swin stem, act 0 / no residual only)
+  return (K == 192 || K == 256 || K == 64) && N % 8 == 0 && N >= 128 && N <= 1536 && M >= 128 * 256 && hm_hd % 64 == 0;
 }
 
 template <class T, int KS, int ACT>
@@ -1089,6 +1090,7 @@ template <class T>
 int launch_xs(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
               int M, int N, int K, int act, int hm_rows, int hm_hd) {
   switch (K) {
+    case 64: return launch_xs_res<T, 2, 0>(st, X, W, bias, nullptr, Y, mask, M, N, hm_rows, hm_hd);
     case 192: return launch_xs_act<T, 6>(st, X, W, bias, R, Y, mask, M, N, act, hm_rows, hm_hd);
     default: return launch_xs_act<T, 8>(st, X, W, bias, R, Y, mask, M, N, act, hm_rows, hm_hd);
   }
@@ -1114,7 +1116,7 @@ int launch(hipStream_t st, const void* X, const void* W, const void* bias, const
       default: return launch_big<T, 2>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
     }
   }
-  if (xs_applicable(M, N, K, hm_hd) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+  if (xs_applicable(M, N, K, hm_hd) && (K != 64 || (act == 0 && !R)) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
       (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0))
     return launch_xs<T>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, act, (int)hm_rows, hm_hd);
   switch (act) {

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 22
+#define CODETR_HIP_ABI_VERSION 23
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -140,6 +140,20 @@ int codetr_msda_encoder_forward_bf16(void *stream, const void *value_dev, const 
                                      const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
                                      int64_t logits_row_stride, const void *ref_dev, int64_t B, int64_t S, int M,
                                      int D, int L, int P, int halo, void *out_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch gather of the Swin stem (mmdet PatchEmbed: Conv2d(C, E, k, stride k) with "corner" zero padding, reference
+ * codetr/swin.py:13, 567; equivalent source codetr/transformer_mmcv.py:100-210).  The convolution over
+ * non-overlapping patches is a GEMM: this call writes its left operand,
+ *   out[(b, ty, tx)][(c, ky, kx)] = x[b, c, k ty + ky, k tx + kx]   (0 beyond the image and for columns >= C k k),
+ * in the column order of conv.weight.view(E, C k k), so that codetr_linear_* with the weight padded to kpad columns
+ * produces the token-major [B, ceil(H/k) ceil(W/k), E] map directly (no NCHW round trip, no flatten / transpose).
+ *   x_dev   [B, C, H, W]  16-bit elements (fp16 or bf16: pure data movement), 8-byte aligned
+ *   out_dev [B * ceil(H/k) * ceil(W/k), kpad]  same element type, 16-byte aligned
+ * Implemented for k == 4, kpad == 64 (C <= 4): CODETR_E_UNSUPPORTED otherwise.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_patch_im2col_b16(void *stream, const void *x_dev, int64_t B, int C, int64_t H, int64_t W, int k, int kpad,
+                            void *out_dev);
 
 /* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
  * Pure host function; lets tests assert that the model shape takes the tiled path. */
