@@ -114,7 +114,9 @@ def test_swin_block_fused_matches_oracle():
     with torch.no_grad():
         outs = s(img.to(DEV).half())
     assert _cabi.CALLS["window_attention"] - before["window_attention"] == 4  # every block took the fused kernel
-    assert _cabi.CALLS["linear"] - before["linear"] == 4 * 4 + 1             # qkv, proj, fc1, fc2 per block + 1 merge
+    # qkv, proj, fc1, fc2 per block + 1 merge + the stem (patch gather + GEMM)
+    assert _cabi.CALLS["linear"] - before["linear"] == 4 * 4 + 1 + 1
+    assert _cabi.CALLS["patch_im2col"] - before["patch_im2col"] == 1
     assert _cabi.CALLS["layernorm"] > before["layernorm"]
     ref = M.swin_forward({"backbone." + k: v for k, v in sd.items()}, img, num_heads=(2, 4), window_size=12,
                          out_indices=(0, 1))
