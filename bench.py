@@ -139,7 +139,7 @@ def kernel_rooflines(model, images, masks, device):
     achieved = flops / secs / 1e12
     big = max(prof, key=lambda p: p[0].elapsed_time(p[1]))
     out["roofline"] = {
-        "kernel": "linear_kernel<f16> (all %d launches of one forward)" % len(prof),
+        "kernel": "linear_kernel / linear_256_kernel / linear_xs_kernel <f16> (all %d launches of one forward)" % len(prof),
         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
         "traffic": pmc.get("linear_kernel", {}).get("hbm_bytes_per_launch"),
@@ -383,11 +383,15 @@ def main():
                               "not the same hardware, so vs_baseline stays null",
         }
         if world == 1 and not a.no_roofline:
-            # rooflines and the single-image latency are taken at batch 1 (the shape the committed PMC passes ran)
+            # rooflines: one eager forward over the images of ONE replayed graph (batch / streams: the launches of the
+            # timed region, same shapes and kernels; the committed PMC passes ran this shape).  The stand-alone MSDA
+            # operator and the latency are single-image quantities.
             op = msda_roofline(1, H, W, dtype, device)
             out["latency_batch1"] = batch1_latency(model, images[:1].contiguous(), masks[:1].contiguous(), device)
             if dtype == torch.float16:
-                out.update(kernel_rooflines(model, images[:1].contiguous(), masks[:1].contiguous(), device))
+                nb = max(1, a.batch // max(1, nstreams))
+                out.update(kernel_rooflines(model, images[:nb].contiguous(), masks[:nb].contiguous(), device))
+                out["roofline_images_per_launch"] = nb
                 out["roofline_msda_op"] = op
             else:
                 out["roofline"] = op

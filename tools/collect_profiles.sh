@@ -13,7 +13,7 @@ python tools/fold_trace.py "$(find /tmp/tr8 -name '*.db' | head -1)" $out/${tag}
 b1="--batch 1 --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-roofline"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr1 -- python bench.py $b1 > /tmp/tr1.log 2>&1
 python tools/fold_trace.py "$(find /tmp/tr1 -name '*.db' | head -1)" $out/${tag}_batch1 1 "rocprofv3 --kernel-trace --stats -- python bench.py $b1"
-p1="--batch 1 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-roofline"
+p1="--batch 4 --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-roofline"   # = one replayed graph of the default run
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python bench.py $p1 > /tmp/pf.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python bench.py $p1 > /tmp/pw.log 2>&1
 python tools/pmc_traffic.py "$(find /tmp/pf -name '*counter_collection.csv' | head -1)" "$(find /tmp/pw -name '*counter_collection.csv' | head -1)" 0 > $out/pmc_traffic.json
