@@ -40,9 +40,25 @@ constexpr int kThreads = 64 * kWaves;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// element types: fp16 / bf16 storage, fp32 scores and accumulation either way
+struct F16E {
+  using e = _Float16;
+  using v8 = f16x8;
+  using v4 = f16x4;
+  __device__ static f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+struct BF16E {
+  using e = __bf16;
+  using v8 = bf16x8;
+  using v4 = bf16x4;
+  __device__ static f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
 
 struct Geometry {
   int B, H, W, Hp, Wp, shift, nH, nWx, nWin;  // nWin = (Hp/ws)*(Wp/ws)
@@ -73,13 +89,16 @@ __device__ __forceinline__ Tok<WS> map_token(int i, int wy, int wx, const Geomet
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
-template <int WS>
+template <class ET, int WS>
 __global__ __launch_bounds__(kThreads) void window_attention_kernel(
-    const _Float16* __restrict__ qkv,       // [B, H*W, 3C]
-    const _Float16* __restrict__ qkv_bias,  // [3C] (zeros if the layer has no bias)
-    const _Float16* __restrict__ rel_bias,  // [nH, N, N]
-    _Float16* __restrict__ out,             // [B, H*W, C]
+    const typename ET::e* __restrict__ qkv,       // [B, H*W, 3C]
+    const typename ET::e* __restrict__ qkv_bias,  // [3C] (zeros if the layer has no bias)
+    const typename ET::e* __restrict__ rel_bias,  // [nH, N, N]
+    typename ET::e* __restrict__ out,             // [B, H*W, C]
     Geometry g, int n_problems) {
+  using E = typename ET::e;
+  using V8 = typename ET::v8;
+  using V4 = typename ET::v4;
   constexpr int N = WS * WS;
   constexpr int NT = (N + 15) / 16;   // 16-token tiles
   constexpr int NP = NT * 16;         // padded token count of K
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   const int wy = win / g.nWx, wx = win - wy * g.nWx;
   const int C = g.nH * HD;
   const size_t row_elems = (size_t)3 * C;
-  const _Float16* qkv_b = qkv + (size_t)b * g.H * g.W * row_elems;
+  const E* qkv_b = qkv + (size_t)b * g.H * g.W * row_elems;
   const int hoff = head * HD;
 
   unsigned char* ldsK = lds_all + wave * kWaveLdsAligned;
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     regv[it] = 0;
     if (c < VR * 4 && row < N) {
       const Tok<WS> t = map_token<WS>(row, wy, wx, g);
-      const _Float16* src = t.valid ? qkv_b + (size_t)t.token * row_elems : qkv_bias;
+      const E* src = t.valid ? qkv_b + (size_t)t.token * row_elems : qkv_bias;
       kv[it] = *reinterpret_cast<const s16x8*>(src + C + hoff + chunk * 8);
       vv[it] = *reinterpret_cast<const s16x8*>(src + 2 * C + hoff + chunk * 8);
       regv[it] = (unsigned char)t.region;
@@ -142,7 +161,7 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   const int l15 = lane & 15, grp = lane >> 4;
   const float scale_log2e = 0.17677669529663687f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e)
   const float log2e = 1.4426950408889634f;
-  const _Float16* bias_h = rel_bias + (size_t)head * N * N;
+  const E* bias_h = rel_bias + (size_t)head * N * N;
 
   // per-lane addresses that do not depend on the query tile
   // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block
@@ -152,8 +171,8 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   // and two waves per SIMD nothing else covers a global-load latency, and unprefetched they cost two of them per
   // tile (18 per problem: ~17 of the ~20 us a problem took).
   struct QTile {
-    f16x8 qf;
-    f16x4 bv[NT];
+    V8 qf;
+    V4 bv[NT];
     Tok<WS> tq;
     bool q_in;
   };
@@ -161,15 +180,15 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     const int qi = qt * 16 + l15;
     T.q_in = (N % 16 == 0) || qi < N;
     T.tq = map_token<WS>(T.q_in ? qi : 0, wy, wx, g);
-    const _Float16* qsrc = (T.tq.valid ? qkv_b + (size_t)T.tq.token * row_elems : qkv_bias) + hoff + grp * 8;
-    T.qf = *reinterpret_cast<const f16x8*>(qsrc);
+    const E* qsrc = (T.tq.valid ? qkv_b + (size_t)T.tq.token * row_elems : qkv_bias) + hoff + grp * 8;
+    T.qf = *reinterpret_cast<const V8*>(qsrc);
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const int key0 = kt * 16 + grp * 4;
-      f16x4 bv = {0, 0, 0, 0};
+      V4 bv = {(E)0.f, (E)0.f, (E)0.f, (E)0.f};
       if constexpr (N % 4 == 0) {  // rows of the bias are 8-byte aligned and a 4-key group is all in or all out
         if ((N % 16 == 0) || (T.q_in && key0 < N))
-          bv = *reinterpret_cast<const f16x4*>(bias_h + (size_t)(T.q_in ? qi : 0) * N + key0);
+          bv = *reinterpret_cast<const V4*>(bias_h + (size_t)(T.q_in ? qi : 0) * N + key0);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -187,15 +206,15 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     if (qt + 1 < NT) load_qtile(qt + 1, nxt);
     const bool q_in = cur.q_in;
     const Tok<WS> tq = cur.tq;
-    const f16x8 qf = cur.qf;
+    const V8 qf = cur.qf;
 
     // ---- S^T tiles: D[i = key][j = query] ----
     f32x4 s[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const int row = kt * 16 + l15;
-      const f16x8 kf = *reinterpret_cast<const f16x8*>(ldsK + row * 64 + swz(row, grp) * 16);
-      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const V8 kf = *reinterpret_cast<const V8*>(ldsK + row * 64 + swz(row, grp) * 16);
+      s[kt] = ET::mfma(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f});
     }
     // ---- scale, bias, mask (all in the log2 domain), row max ----
     // (Pre-multiplying the bias table by log2 e on the host -- one fma per score instead of mul + fma -- measured -2 %
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         const int key0 = kt * 16 + grp * 4;
-        const f16x4 bv = cur.bv[kt];
+        const V4 bv = cur.bv[kt];
         unsigned regk = 0;
         if (MASK) regk = *reinterpret_cast<const unsigned*>(ldsR + key0);
 #pragma unroll
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // ---- exp, row sum, pack P^T as MFMA B fragments ----
     float sum = 0.f;
-    f16x8 pf[KS];
+    V8 pf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
             p = __builtin_amdgcn_exp2f(s[kt][r] - mx);  // v_exp_f32; argument <= 0
             sum += p;
           }
-          pf[ks][h * 4 + r] = (_Float16)p;
+          pf[ks][h * 4 + r] = (E)p;
         }
       }
     }
@@ -261,43 +280,44 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(ldsV + row1 * 64 + swz(row1, chunk) * 16 + (tr_p & 1) * 8));
         s16x8 vf8 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        f16x8 vf;
+        V8 vf;
         __builtin_memcpy(&vf, &vf8, 16);
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ks], o[dt], 0, 0, 0);
+        o[dt] = ET::mfma(vf, pf[ks], o[dt]);
       }
     }
     // ---- normalise and store: lane holds channels 16*dt + 4*grp + r of query l15 ----
     if (q_in && tq.valid) {
       const float inv = 1.0f / sum;
-      _Float16* dst = out + ((size_t)b * g.H * g.W + tq.token) * C + hoff + grp * 4;
+      E* dst = out + ((size_t)b * g.H * g.W + tq.token) * C + hoff + grp * 4;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        f16x4 ov;
+        V4 ov;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (_Float16)(o[dt][r] * inv);
-        *reinterpret_cast<f16x4*>(dst + dt * 16) = ov;
+        for (int r = 0; r < 4; ++r) ov[r] = (E)(o[dt][r] * inv);
+        *reinterpret_cast<V4*>(dst + dt * 16) = ov;
       }
     }
   }
 }
 
-template <int WS>
+template <class ET, int WS>
 int launch_ws(hipStream_t st, const void* qkv, const void* qkv_bias, const void* rel_bias, void* out, Geometry g) {
   const int64_t n = (int64_t)g.B * g.nWin * g.nH;
   if (n > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
-  hipLaunchKernelGGL((window_attention_kernel<WS>), dim3(blocks), dim3(kThreads), 0, st,
-                     static_cast<const _Float16*>(qkv), static_cast<const _Float16*>(qkv_bias),
-                     static_cast<const _Float16*>(rel_bias), static_cast<_Float16*>(out), g, (int)n);
+  hipLaunchKernelGGL((window_attention_kernel<ET, WS>), dim3(blocks), dim3(kThreads), 0, st,
+                     static_cast<const typename ET::e*>(qkv), static_cast<const typename ET::e*>(qkv_bias),
+                     static_cast<const typename ET::e*>(rel_bias), static_cast<typename ET::e*>(out), g, (int)n);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int codetr_window_attention_f16(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
+template <class ET>
+int window_attention_entry(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
                                 void* out_dev, int64_t B, int64_t H, int64_t W, int num_heads, int head_dim,
                                 int window_size, int shift) {
   if (!qkv_dev || !qkv_bias_dev || !rel_bias_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || num_heads <= 0)
@@ -316,12 +336,31 @@ int codetr_window_attention_f16(void* stream, const void* qkv_dev, const void* q
   g.nWin = (g.Hp / window_size) * g.nWx;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (window_size) {
-    case 12: return launch_ws<12>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
-    case 8: return launch_ws<8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
-    case 7: return launch_ws<7>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
-    case 4: return launch_ws<4>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+    case 12: return launch_ws<ET, 12>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+    case 8: return launch_ws<ET, 8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+    case 7: return launch_ws<ET, 7>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+    case 4: return launch_ws<ET, 4>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
   }
   return CODETR_E_UNSUPPORTED;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int codetr_window_attention_f16(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
+                                void* out_dev, int64_t B, int64_t H, int64_t W, int num_heads, int head_dim,
+                                int window_size, int shift) {
+  return window_attention_entry<F16E>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, B, H, W, num_heads, head_dim,
+                                      window_size, shift);
+}
+
+int codetr_window_attention_bf16(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
+                                 void* out_dev, int64_t B, int64_t H, int64_t W, int num_heads, int head_dim,
+                                 int window_size, int shift) {
+  return window_attention_entry<BF16E>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, B, H, W, num_heads,
+                                       head_dim, window_size, shift);
 }
 
 }  // extern "C"

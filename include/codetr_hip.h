@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 23
+#define CODETR_HIP_ABI_VERSION 24
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -373,11 +373,15 @@ int codetr_patch_merge_layernorm_f16(void *stream, const void *x_dev, const void
  *   out_dev      [B, H*W, C]    f16  attention output in the same spatial token order
  *   shift        0 (W-MSA) or window_size/2 (SW-MSA); head_dim must be 32; window_size in {4,7,8,12}
  *
- * fp32 scores / softmax / accumulation; probabilities rounded to f16 for the P.V product.
+ * fp32 scores / softmax / accumulation; probabilities rounded to f16 (bf16 in the _bf16 form, all tensors bf16) for
+ * the P.V product.
  * ------------------------------------------------------------------------------------------ */
 int codetr_window_attention_f16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
                                 const void *rel_bias_dev, void *out_dev, int64_t B, int64_t H, int64_t W,
                                 int num_heads, int head_dim, int window_size, int shift);
+int codetr_window_attention_bf16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
+                                 const void *rel_bias_dev, void *out_dev, int64_t B, int64_t H, int64_t W,
+                                 int num_heads, int head_dim, int window_size, int shift);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm on token-major activations, written into a slice of the flattened multi-level map.

@@ -51,15 +51,15 @@ def reference_window_attention(qkv, qkv_bias, table, rel_index, H, W, nH, ws, sh
     return o[:, :H, :W].reshape(B, H * W, C)
 
 
-def _case(B, H, W, nH, ws, shift, seed=0, bias_scale=1.0):
+def _case(B, H, W, nH, ws, shift, seed=0, bias_scale=1.0, dtype=torch.float16):
     from codetr import hip_ops
     from codetr.swin import WindowMSA
 
     C = nH * 32
     g = torch.Generator(device=DEV).manual_seed(seed)
-    qkv = torch.randn(B, H * W, 3 * C, device=DEV, generator=g).half()
-    qkv_bias = (0.5 * torch.randn(3 * C, device=DEV, generator=g)).half()
-    m = WindowMSA(C, nH, (ws, ws)).to(DEV).half()
+    qkv = torch.randn(B, H * W, 3 * C, device=DEV, generator=g).to(dtype)
+    qkv_bias = (0.5 * torch.randn(3 * C, device=DEV, generator=g)).to(dtype)
+    m = WindowMSA(C, nH, (ws, ws)).to(DEV).to(dtype)
     with torch.no_grad():
         m.relative_position_bias_table.copy_(bias_scale * torch.randn(m.relative_position_bias_table.shape, device=DEV,
                                                                       generator=g))
@@ -67,7 +67,11 @@ def _case(B, H, W, nH, ws, shift, seed=0, bias_scale=1.0):
     torch.cuda.synchronize()
     ref = reference_window_attention(qkv, qkv_bias, m.relative_position_bias_table, m.relative_position_index, H, W,
                                      nH, ws, shift)
-    torch.testing.assert_close(out.float(), ref, rtol=5e-3, atol=3e-3)
+    assert out.dtype == dtype
+    if dtype == torch.float16:
+        torch.testing.assert_close(out.float(), ref, rtol=5e-3, atol=3e-3)
+    else:   # bf16: probabilities and the output carry 8 significant bits -> 2^-8 of the value scale
+        torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.parametrize("shift", [0, 6])
@@ -85,6 +89,13 @@ def test_window12(B, H, W, nH, shift):
 @pytest.mark.parametrize("ws,shift,H,W", [(7, 0, 14, 14), (7, 3, 16, 20), (8, 4, 17, 9), (4, 2, 11, 15), (4, 0, 8, 8)])
 def test_other_window_sizes(ws, shift, H, W):
     _case(2, H, W, 2, ws, shift, seed=ws)
+
+
+@pytest.mark.parametrize("ws,shift,B,H,W,nH", [(12, 0, 2, 24, 36, 2), (12, 6, 1, 20, 31, 6), (7, 3, 2, 16, 20, 2),
+                                               (12, 6, 1, 40, 60, 4)])
+def test_bf16(ws, shift, B, H, W, nH):
+    """the bf16 instantiation (codetr_window_attention_bf16) against the same fp32 restatement"""
+    _case(B, H, W, nH, ws, shift, seed=ws + H, dtype=torch.bfloat16)
 
 
 def test_large_logits_and_mask_dominance():
