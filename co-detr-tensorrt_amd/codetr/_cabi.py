@@ -66,6 +66,8 @@ SIGNATURES = {
                                       _vp, _vp]),
     "codetr_ffn_relu_ln2_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float,
                                        _vp, _vp, ctypes.c_float, _vp, _vp]),
+    "codetr_ffn_relu_ln2_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float,
+                                       _vp, _vp, ctypes.c_float, _vp, _vp]),
     "codetr_ffn_pack_w2_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
     "codetr_window_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
@@ -459,7 +461,7 @@ def sine_pos_tokens(ycum, xcum, level_embed, out_slice, out_batch_stride, num_fe
 
 
 def ffn_fused_supported(x, w1, w2, act) -> bool:
-    return (x.dtype == torch.float16 and act == "relu" and x.shape[-1] == 256 and w1.shape[1] == 256
+    return (x.dtype in (torch.float16, torch.bfloat16) and act == "relu" and x.shape[-1] == 256 and w1.shape[1] == 256
             and w2.shape[0] == 256 and w1.shape[0] % 64 == 0 and w1.dtype == x.dtype and w2.dtype == x.dtype)
 
 
@@ -475,20 +477,16 @@ def ffn_fused(x2d, w1, b1, w2, b2, out2d, ln=None, pos2d=None, out_plus_pos2d=No
     """w2 must be the PACKED weight (ffn_pack_w2).  ln = (gamma, beta, eps): LayerNorm folded into the epilogue;
     pos2d / out_plus_pos2d: second output `out + pos`; ln_in = (gamma, beta, eps): LayerNorm of the input rows."""
     CALLS["ffn_fused"] += 1
-    if ln is None and pos2d is None and ln_in is None:
-        rc = load().codetr_ffn_relu_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), w1.data_ptr(), b1.data_ptr(),
-                                        w2.data_ptr(), b2.data_ptr(), out2d.data_ptr(), x2d.shape[0], x2d.shape[1],
-                                        w1.shape[0])
-        check(rc, "codetr_ffn_relu_f16")
-        return out2d
     g, b, eps = ln if ln is not None else (None, None, 0.0)
     gi, bi, epsi = ln_in if ln_in is not None else (None, None, 0.0)
-    rc = load().codetr_ffn_relu_ln2_f16(
+    lib = load()
+    fn = lib.codetr_ffn_relu_ln2_bf16 if x2d.dtype == torch.bfloat16 else lib.codetr_ffn_relu_ln2_f16
+    rc = fn(
         current_stream_ptr(x2d.device), x2d.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
         out2d.data_ptr(), x2d.shape[0], x2d.shape[1], w1.shape[0],
         gi.data_ptr() if gi is not None else None, bi.data_ptr() if bi is not None else None, float(epsi),
         g.data_ptr() if g is not None else None, b.data_ptr() if b is not None else None, float(eps),
         pos2d.data_ptr() if pos2d is not None else None,
         out_plus_pos2d.data_ptr() if out_plus_pos2d is not None else None)
-    check(rc, "codetr_ffn_relu_ln2_f16")
+    check(rc, "codetr_ffn_relu_ln2")
     return out2d

@@ -44,6 +44,36 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// element types: fp16 / bf16 storage, fp32 accumulation on the matrix cores either way
+struct F16E {
+  using e = _Float16;
+  using v8 = f16x8;
+  using v4 = f16x4;
+  __device__ static f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  // v_pk_max_f16: one op per two values
+  __device__ static v8 relu(v8 x) {
+    const v8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_elementwise_max(x, z);
+  }
+};
+struct BF16E {
+  using e = __bf16;
+  using v8 = bf16x8;
+  using v4 = bf16x4;
+  __device__ static f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  // sign-magnitude 16-bit floats order like int16 on the non-negative side: v_pk_max_i16(x, 0) is ReLU (-0 -> +0)
+  __device__ static v8 relu(v8 x) {
+    s16x8 i;
+    __builtin_memcpy(&i, &x, 16);
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    i = __builtin_elementwise_max(i, z);
+    __builtin_memcpy(&x, &i, 16);
+    return x;
+  }
+};
 
 __device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
   const unsigned q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
@@ -106,7 +136,7 @@ struct PieceSwitch<-1> {
 };
 
 // MT = 16-row tiles per wave (rows per workgroup = 64 * MT)
-template <int MT>
+template <class ET, int MT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
@@ -114,6 +144,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2, int row0,
     const unsigned short* __restrict__ lnin_g, const unsigned short* __restrict__ lnin_b, float lnin_eps) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2 + 256 * 8];  // 146 KiB, one object
+  using E = typename ET::e;
+  using V8 = typename ET::v8;
+  using V4 = typename ET::v4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
   constexpr int BM = 64 * MT, WR = 16 * MT;  // rows per workgroup / per wave
@@ -123,14 +156,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   stage_chunk(W1, W2, Hd, 0, lds, tid);
 
   // X fragments of this wave's 32 rows (B operand: lane (j = l15, g) holds X[m][32*ks + 8g .. +7]), kept for good
-  f16x8 xf[MT][8];
+  V8 xf[MT][8];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int m = m0 + mt * 16 + l15;
     m = m < M ? m : M - 1;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
-      xf[mt][ks] = *reinterpret_cast<const f16x8*>(X + (size_t)m * C + ks * 32 + grp * 8);
+      xf[mt][ks] = *reinterpret_cast<const V8*>(X + (size_t)m * C + ks * 32 + grp * 8);
   }
   // Optional LayerNorm of the INPUT rows (the post-norm layer's first norm, whose output nothing else reads): the
   // 256 values of row (mt, l15) sit in the four lanes l15 + 16 g of this wave (8 k-steps x 8 values each), so the
@@ -166,11 +199,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const f16x8 gw = *reinterpret_cast<const f16x8*>(lnin_g + ks * 32 + grp * 8);
-        const f16x8 gb = *reinterpret_cast<const f16x8*>(lnin_b + ks * 32 + grp * 8);
+        const V8 gw = *reinterpret_cast<const V8*>(lnin_g + ks * 32 + grp * 8);
+        const V8 gb = *reinterpret_cast<const V8*>(lnin_b + ks * 32 + grp * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          xf[mt][ks][e] = (_Float16)fmaf(((float)xf[mt][ks][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
+          xf[mt][ks][e] = (E)fmaf(((float)xf[mt][ks][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
       }
     }
   }
@@ -178,7 +211,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   f32x4 yacc[16][MT];
 #pragma unroll
   for (int nt = 0; nt < 16; ++nt) {
-    const f16x4 bb = *reinterpret_cast<const f16x4*>(b2 + nt * 16 + grp * 4);
+    const V4 bb = *reinterpret_cast<const V4*>(b2 + nt * 16 + grp * 4);
     const f32x4 b4 = {(float)bb[0], (float)bb[1], (float)bb[2], (float)bb[3]};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) yacc[nt][mt] = b4;
@@ -207,22 +240,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
     for (int ht = 0; ht < 4; ++ht) {
       // bias of this lane's 4 consecutive hidden units of tile ht
-      const f16x4 bv = *reinterpret_cast<const f16x4*>(sB1 + c * BH + ht * 16 + grp * 4);
+      const V4 bv = *reinterpret_cast<const V4*>(sB1 + c * BH + ht * 16 + grp * 4);
       const f32x4 b4 = {(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = b4;
     }
     // one wave per SIMD: nobody else hides LDS latency, so the A fragments of k-step ks+1 are read while the
     // MFMAs of k-step ks issue (explicit register double buffering)
-    auto read_w1 = [&](int ks, f16x8 (&a)[4]) {
+    auto read_w1 = [&](int ks, V8 (&a)[4]) {
 #pragma unroll
       for (int ht = 0; ht < 4; ++ht) {
         const int row = ht * 16 + l15;
         const int chunk = (ks * 4 + grp) ^ (row & 15);
-        a[ht] = *reinterpret_cast<const f16x8*>(sW1 + row * (C * 2) + chunk * 16);
+        a[ht] = *reinterpret_cast<const V8*>(sW1 + row * (C * 2) + chunk * 16);
       }
     };
-    f16x8 aw[2][4];
+    V8 aw[2][4];
     read_w1(0, aw[0]);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
@@ -234,7 +267,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         hacc[i / MT][i % MT] =
-            __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT], 0, 0, 0);
+            ET::mfma(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT]);
       if (ks + 1 < 8) {
         read_w1(ks + 1, aw[(ks + 1) & 1]);
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -244,10 +277,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
       for (int i = 2; i < 4 * MT; ++i)
         hacc[i / MT][i % MT] =
-            __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT], 0, 0, 0);
+            ET::mfma(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT]);
     }
     // ---- ReLU + pack: B operand of the second product, k-slot 8g+j = rows 4g..4g+3 of tiles 2s and 2s+1 ----
-    f16x8 pf[2][MT];
+    V8 pf[2][MT];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -255,20 +288,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pf[s][mt][h * 4 + r] = (_Float16)hacc[2 * s + h][mt][r];
+          for (int r = 0; r < 4; ++r) pf[s][mt][h * 4 + r] = (E)hacc[2 * s + h][mt][r];
     // ReLU on the packed halves (v_pk_max_f16: one op per two values).  max(NaN, 0) = 0 drops a NaN of the hidden
     // unit, but a NaN there can only come from a NaN / inf in this row of X, which the residual add puts back.
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        pf[s][mt] = __builtin_elementwise_max(pf[s][mt], z);
+        pf[s][mt] = ET::relu(pf[s][mt]);
       }
     // ---- Y^T += W2c . relu(H)^T : D[i = n][j = m], k = hidden unit (permuted identically on both operands) ----
     // W2 fragments (pre-packed: the 8 k-slots of lane group g are 16 contiguous bytes) are read two n-tiles
     // ahead of their MFMAs, same double buffering
-    auto read_w2 = [&](int ntp, f16x8 (&a)[4]) {  // n-tiles 2*ntp, 2*ntp+1; index [t*2 + s]
+    auto read_w2 = [&](int ntp, V8 (&a)[4]) {  // n-tiles 2*ntp, 2*ntp+1; index [t*2 + s]
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int n = (2 * ntp + t) * 16 + l15;
@@ -276,10 +308,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int sw = (n >> 1) & 7;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-          a[t * 2 + s] = *reinterpret_cast<const f16x8*>(rowp + ((4 * s + grp) ^ sw) * 16);
+          a[t * 2 + s] = *reinterpret_cast<const V8*>(rowp + ((4 * s + grp) ^ sw) * 16);
       }
     };
-    f16x8 a2[2][4];
+    V8 a2[2][4];
     read_w2(0, a2[0]);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
@@ -288,7 +320,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / 2;
-        yacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt], 0, 0, 0);
+        yacc[nt][mt] = ET::mfma(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt]);
       }
       if (ntp + 1 < 8) {
         read_w2(ntp + 1, a2[(ntp + 1) & 1]);
@@ -299,7 +331,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
       for (int i = 2; i < 4 * MT; ++i) {
         const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / 2;
-        yacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt], 0, 0, 0);
+        yacc[nt][mt] = ET::mfma(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt]);
       }
     }
   }
@@ -312,9 +344,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   for (int nt = 0; nt < 16; ++nt)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const f16x4 o = {(_Float16)yacc[nt][mt][0], (_Float16)yacc[nt][mt][1], (_Float16)yacc[nt][mt][2],
-                       (_Float16)yacc[nt][mt][3]};
-      *reinterpret_cast<f16x4*>(stage + (mt * 16 + l15) * kOutPitch + (nt * 16 + grp * 4) * 2) = o;
+      const V4 o = {(E)yacc[nt][mt][0], (E)yacc[nt][mt][1], (E)yacc[nt][mt][2],
+                       (E)yacc[nt][mt][3]};
+      *reinterpret_cast<V4*>(stage + (mt * 16 + l15) * kOutPitch + (nt * 16 + grp * 4) * 2) = o;
     }
   __builtin_amdgcn_wave_barrier();
   // WR rows x 32 chunks of 16 B: lane -> (row = it*2 + lane/32, chunk = lane%32).  With one wave per SIMD a
@@ -322,44 +354,44 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   // once the epilogue also read pos): all residual / pos rows are requested first -- the accumulators are dead by
   // now, the registers are free -- and consumed afterwards.
   const int chunk = lane & 31;
-  f16x8 xr[WR / 2], pr[WR / 2];
+  V8 xr[WR / 2], pr[WR / 2];
 #pragma unroll
   for (int it = 0; it < WR / 2; ++it) {
     int m = m0 + it * 2 + (lane >> 5);
     m = m < M ? m : M - 1;
-    xr[it] = *reinterpret_cast<const f16x8*>(X + (size_t)m * C + chunk * 8);
+    xr[it] = *reinterpret_cast<const V8*>(X + (size_t)m * C + chunk * 8);
   }
   if (Y2) {
 #pragma unroll
     for (int it = 0; it < WR / 2; ++it) {
       int m = m0 + it * 2 + (lane >> 5);
       m = m < M ? m : M - 1;
-      pr[it] = *reinterpret_cast<const f16x8*>(pos + (size_t)m * C + chunk * 8);
+      pr[it] = *reinterpret_cast<const V8*>(pos + (size_t)m * C + chunk * 8);
     }
   }
-  f16x8 gw, gb, gin_w, gin_b;
+  V8 gw, gb, gin_w, gin_b;
   if (ln_g) {
-    gw = *reinterpret_cast<const f16x8*>(ln_g + chunk * 8);
-    gb = *reinterpret_cast<const f16x8*>(ln_b + chunk * 8);
+    gw = *reinterpret_cast<const V8*>(ln_g + chunk * 8);
+    gb = *reinterpret_cast<const V8*>(ln_b + chunk * 8);
   }
   if (lnin_g) {
-    gin_w = *reinterpret_cast<const f16x8*>(lnin_g + chunk * 8);
-    gin_b = *reinterpret_cast<const f16x8*>(lnin_b + chunk * 8);
+    gin_w = *reinterpret_cast<const V8*>(lnin_g + chunk * 8);
+    gin_b = *reinterpret_cast<const V8*>(lnin_b + chunk * 8);
   }
 #pragma unroll
   for (int it = 0; it < WR / 2; ++it) {
     const int row = it * 2 + (lane >> 5);
     const int m = m0 + row;
-    const f16x8 y = *reinterpret_cast<const f16x8*>(stage + row * kOutPitch + chunk * 16);
-    f16x8 xrow = xr[it];
+    const V8 y = *reinterpret_cast<const V8*>(stage + row * kOutPitch + chunk * 16);
+    V8 xrow = xr[it];
     if (lnin_g) {  // identity = LayerNorm(input row), the same arithmetic on the same statistics as the prologue
       const float mean = sStat[row * 2], rstd = sStat[row * 2 + 1];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xrow[e] = (_Float16)fmaf(((float)xrow[e] - mean) * rstd, (float)gin_w[e], (float)gin_b[e]);
+      for (int e = 0; e < 8; ++e) xrow[e] = (E)fmaf(((float)xrow[e] - mean) * rstd, (float)gin_w[e], (float)gin_b[e]);
     }
-    f16x8 o;
+    V8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)y[e] + (float)xrow[e]);  // identity + ffn(x): fp16 + fp16 -> fp16
+    for (int e = 0; e < 8; ++e) o[e] = (E)((float)y[e] + (float)xrow[e]);  // identity + ffn(x): fp16 + fp16 -> fp16
     if (ln_g) {
       // LayerNorm over the row (its 256 values sit in the 32 lanes of this half-wave): the arithmetic of
       // layernorm_kernel<LnHalf, 32, 1>, statement for statement, so the result is bit-identical to running that
@@ -380,15 +412,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       for (int d = 16; d > 0; d >>= 1) q += __shfl_xor(q, d, 64);
       const float rstd = rsqrtf(q * (1.0f / C) + ln_eps);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaf(((float)o[e] - mean) * rstd, (float)gw[e], (float)gb[e]);
+      for (int e = 0; e < 8; ++e) o[e] = (E)fmaf(((float)o[e] - mean) * rstd, (float)gw[e], (float)gb[e]);
     }
     if (m < M) {
-      *reinterpret_cast<f16x8*>(Y + (size_t)m * C + chunk * 8) = o;
+      *reinterpret_cast<V8*>(Y + (size_t)m * C + chunk * 8) = o;
       if (Y2) {  // the next layer's attention input: this row + its positional encoding (fp16 + fp16 -> fp16)
-        f16x8 o2;
+        V8 o2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o2[e] = (_Float16)((float)o[e] + (float)pr[it][e]);
-        *reinterpret_cast<f16x8*>(Y2 + (size_t)m * C + chunk * 8) = o2;
+        for (int e = 0; e < 8; ++e) o2[e] = (E)((float)o[e] + (float)pr[it][e]);
+        *reinterpret_cast<V8*>(Y2 + (size_t)m * C + chunk * 8) = o2;
       }
     }
   }
@@ -403,6 +435,42 @@ __global__ void pack_w2_kernel(const unsigned short* __restrict__ w2, unsigned s
   const int s = col >> 5, g = (col >> 3) & 3, j = col & 7;
   const int old = 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
   out[i] = w2[(i & ~(int64_t)63) + old];
+}
+
+}  // namespace
+
+namespace {
+
+template <class ET>
+int ffn_entry(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
+                            const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                            int64_t hidden, const void* ln_in_gamma_dev, const void* ln_in_beta_dev, float ln_in_eps,
+                            const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps, const void* pos_dev,
+                            void* y_plus_pos_dev) {
+  const void* w2_dev = w2_packed_dev;
+  if (!x_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !y_dev || M <= 0 || hidden <= 0) return CODETR_E_BADARG;
+  if ((ln_gamma_dev == nullptr) != (ln_beta_dev == nullptr) || (pos_dev == nullptr) != (y_plus_pos_dev == nullptr) ||
+      (ln_in_gamma_dev == nullptr) != (ln_in_beta_dev == nullptr))
+    return CODETR_E_BADARG;
+  if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
+  if (M > 0x7fffffffLL - 256 || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  // MT = 2 (128 rows per workgroup).  MT = 3 fits the register file only without the interleaved DMA issue (236 VGPR
+  // + 240 AGPR, 570 us at M = 204 600 against 545 us for this variant); with it hipcc spills (1147 us).
+  // (Splitting off the last, mostly empty round of 256 workgroups as 64-row workgroups measured -1 %: workgroups are
+  // not dispatched in lockstep rounds, so the tail is already spread.)
+  constexpr int kMT = 2;
+  const unsigned blocks = (unsigned)((M + 64 * kMT - 1) / (64 * kMT));
+  hipLaunchKernelGGL((ffn_fused_kernel<ET, kMT>), dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(x_dev), static_cast<const unsigned short*>(w1_dev),
+                     static_cast<const unsigned short*>(b1_dev), static_cast<const unsigned short*>(w2_dev),
+                     static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
+                     (int)hidden, static_cast<const unsigned short*>(ln_gamma_dev),
+                     static_cast<const unsigned short*>(ln_beta_dev), ln_eps,
+                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev), 0,
+                     static_cast<const unsigned short*>(ln_in_gamma_dev),
+                     static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
 }
 
 }  // namespace
@@ -424,30 +492,17 @@ int codetr_ffn_relu_ln2_f16(void* stream, const void* x_dev, const void* w1_dev,
                             int64_t hidden, const void* ln_in_gamma_dev, const void* ln_in_beta_dev, float ln_in_eps,
                             const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps, const void* pos_dev,
                             void* y_plus_pos_dev) {
-  const void* w2_dev = w2_packed_dev;
-  if (!x_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !y_dev || M <= 0 || hidden <= 0) return CODETR_E_BADARG;
-  if ((ln_gamma_dev == nullptr) != (ln_beta_dev == nullptr) || (pos_dev == nullptr) != (y_plus_pos_dev == nullptr) ||
-      (ln_in_gamma_dev == nullptr) != (ln_in_beta_dev == nullptr))
-    return CODETR_E_BADARG;
-  if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
-  if (M > 0x7fffffffLL - 256 || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  // MT = 2 (128 rows per workgroup).  MT = 3 fits the register file only without the interleaved DMA issue (236 VGPR
-  // + 240 AGPR, 570 us at M = 204 600 against 545 us for this variant); with it hipcc spills (1147 us).
-  // (Splitting off the last, mostly empty round of 256 workgroups as 64-row workgroups measured -1 %: workgroups are
-  // not dispatched in lockstep rounds, so the tail is already spread.)
-  constexpr int kMT = 2;
-  const unsigned blocks = (unsigned)((M + 64 * kMT - 1) / (64 * kMT));
-  hipLaunchKernelGGL(ffn_fused_kernel<kMT>, dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const unsigned short*>(x_dev), static_cast<const unsigned short*>(w1_dev),
-                     static_cast<const unsigned short*>(b1_dev), static_cast<const unsigned short*>(w2_dev),
-                     static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
-                     (int)hidden, static_cast<const unsigned short*>(ln_gamma_dev),
-                     static_cast<const unsigned short*>(ln_beta_dev), ln_eps,
-                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev), 0,
-                     static_cast<const unsigned short*>(ln_in_gamma_dev),
-                     static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps);
-  const hipError_t err = hipGetLastError();
-  return err == hipSuccess ? 0 : (int)err;
+  return ffn_entry<F16E>(stream, x_dev, w1_dev, b1_dev, w2_packed_dev, b2_dev, y_dev, M, C_in, hidden, ln_in_gamma_dev,
+                         ln_in_beta_dev, ln_in_eps, ln_gamma_dev, ln_beta_dev, ln_eps, pos_dev, y_plus_pos_dev);
+}
+
+int codetr_ffn_relu_ln2_bf16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,
+                            const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                            int64_t hidden, const void* ln_in_gamma_dev, const void* ln_in_beta_dev, float ln_in_eps,
+                            const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps, const void* pos_dev,
+                            void* y_plus_pos_dev) {
+  return ffn_entry<BF16E>(stream, x_dev, w1_dev, b1_dev, w2_packed_dev, b2_dev, y_dev, M, C_in, hidden, ln_in_gamma_dev,
+                         ln_in_beta_dev, ln_in_eps, ln_gamma_dev, ln_beta_dev, ln_eps, pos_dev, y_plus_pos_dev);
 }
 
 int codetr_ffn_relu_ln_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,

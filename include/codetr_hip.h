@@ -456,6 +456,13 @@ int codetr_ffn_relu_ln2_f16(void *stream, const void *x_dev, const void *w1_dev,
                             int64_t hidden, const void *ln_in_gamma_dev, const void *ln_in_beta_dev, float ln_in_eps,
                             const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps, const void *pos_dev,
                             void *y_plus_pos_dev);
+/* bf16 storage form of the same kernel (all tensors bf16; the packed W2 comes from codetr_ffn_pack_w2_f16, which only
+ * moves 16-bit elements) */
+int codetr_ffn_relu_ln2_bf16(void *stream, const void *x_dev, const void *w1_dev, const void *b1_dev,
+                            const void *w2_packed_dev, const void *b2_dev, void *y_dev, int64_t M, int64_t C_in,
+                            int64_t hidden, const void *ln_in_gamma_dev, const void *ln_in_beta_dev, float ln_in_eps,
+                            const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps, const void *pos_dev,
+                            void *y_plus_pos_dev);
 /* one-time weight pre-pack for the call above: w2_dev [C_out, hidden] f16 -> w2_packed_dev (same shape) */
 int codetr_ffn_pack_w2_f16(void *stream, const void *w2_dev, void *w2_packed_dev, int64_t C_out, int64_t hidden);
 

@@ -142,3 +142,46 @@ def test_encoder_layers_chain_through_the_fused_epilogue():
     finally:
         hip_ops.FFN_FUSED_MIN_ROWS = saved
     torch.testing.assert_close(out.float(), out0.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,hidden", [(129, 2048), (5000, 512), (30785, 2048)])
+def test_ffn_fused_bf16_vs_fp32(M, hidden):
+    """the bf16 instantiation (codetr_ffn_relu_ln2_bf16): hidden activation rounded to bf16 like the two-GEMM path"""
+    from codetr import _cabi, hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(M + hidden)
+    bf = torch.bfloat16
+    x = torch.randn(M, 256, device=DEV, generator=g).to(bf)
+    w1 = (torch.randn(hidden, 256, device=DEV, generator=g) / 16).to(bf)
+    b1 = (torch.randn(hidden, device=DEV, generator=g) * 0.5).to(bf)
+    w2 = (torch.randn(256, hidden, device=DEV, generator=g) / hidden ** 0.5).to(bf)
+    b2 = (torch.randn(256, device=DEV, generator=g) * 0.5).to(bf)
+    before = _cabi.CALLS["ffn_fused"]
+    y = hip_ops.ffn_fused(x, w1, b1, w2, b2)
+    torch.cuda.synchronize()
+    assert _cabi.CALLS["ffn_fused"] == before + 1 and y.dtype == bf
+    h = torch.relu(x.float() @ w1.float().t() + b1.float()).to(bf).float()
+    ref = (h @ w2.float().t() + b2.float()).to(bf).float() + x.float()
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=3e-2)   # bf16: 8 significant bits
+
+
+def test_ffn_bf16_layernorm_pos_epilogue_matches_three_kernels():
+    """bf16: fused (input LN, FFN, LN, + pos) against layer_norm -> fused FFN -> layer_norm -> add"""
+    from codetr import hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(5)
+    bf = torch.bfloat16
+    M = 128 * 64 + 77
+    mk = lambda *s, sc=1.0: (torch.randn(*s, device=DEV, generator=g) * sc).to(bf)  # noqa: E731
+    x, pos = mk(M, 256), mk(M, 256)
+    w1, b1, w2, b2 = mk(2048, 256, sc=1 / 16), mk(2048), mk(256, 2048, sc=1 / 45), mk(256)
+    gam, bet = (1 + mk(256, sc=0.1).float()).to(bf), mk(256, sc=0.1)
+    y0 = hip_ops.ffn_fused(x, w1, b1, w2, b2)
+    n0 = hip_ops.layer_norm(y0, gam, bet, 1e-5)
+    n1, q1 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), pos=pos)
+    assert torch.equal(n1, n0) and torch.equal(q1, n0 + pos)
+    x1 = hip_ops.layer_norm(x, gam, bet, 1e-5)
+    r0 = hip_ops.ffn_fused(x1, w1, b1, w2, b2, ln=(gam, bet, 1e-5))
+    r1 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), ln_in=(gam, bet, 1e-5))
+    torch.testing.assert_close(r1.float(), r0.float(), rtol=0, atol=6e-2)
+    assert (r1 != r0).float().mean() < 0.05
