@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -50,6 +50,7 @@ SIGNATURES = {
     "codetr_preprocess_u8_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "codetr_batched_nms_f32": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float, _vp]),
     "codetr_patch_merge_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float]),
+    "codetr_patch_merge_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float]),
     "codetr_mask_pyramid": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "codetr_linear_splitk_plan": (_i32, [_i64, _i64, _i64, _vp]),
     "codetr_linear_splitk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
@@ -59,7 +60,11 @@ SIGNATURES = {
     "codetr_groupnorm_tokens_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "codetr_groupnorm_tokens_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i32,
                                            ctypes.c_float]),
+    "codetr_groupnorm_tokens_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i32,
+                                           ctypes.c_float]),
     "codetr_sine_pos_tokens_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, ctypes.c_float,
+                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, _i32]),
+    "codetr_sine_pos_tokens_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_float, _i32]),
     "codetr_ffn_relu_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_ffn_relu_ln_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float,
@@ -334,9 +339,11 @@ def patch_merge_layernorm(x4d, weight_kkc, bias_kkc, eps):
     CALLS["patch_merge_layernorm"] += 1
     B, H, W, C = x4d.shape
     out = torch.empty((B, ((H + 1) // 2) * ((W + 1) // 2), 4 * C), dtype=x4d.dtype, device=x4d.device)
-    rc = load().codetr_patch_merge_layernorm_f16(current_stream_ptr(x4d.device), x4d.data_ptr(), weight_kkc.data_ptr(),
-                                                 bias_kkc.data_ptr(), out.data_ptr(), B, H, W, C, float(eps))
-    check(rc, "codetr_patch_merge_layernorm_f16")
+    lib = load()
+    fn = lib.codetr_patch_merge_layernorm_bf16 if x4d.dtype == torch.bfloat16 else lib.codetr_patch_merge_layernorm_f16
+    rc = fn(current_stream_ptr(x4d.device), x4d.data_ptr(), weight_kkc.data_ptr(), bias_kkc.data_ptr(), out.data_ptr(),
+            B, H, W, C, float(eps))
+    check(rc, "codetr_patch_merge_layernorm")
     return out
 
 
@@ -427,7 +434,7 @@ def patch_im2col(x, k, kpad, out):
 
 
 def groupnorm_tokens_supported(x, groups) -> bool:
-    return x.dtype == torch.float16 and x.shape[-1] == groups * 8 and 256 % groups == 0
+    return x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] == groups * 8 and 256 % groups == 0
 
 
 def groupnorm_tokens(x, gamma, beta, groups, eps, out_slice, out_batch_stride):
@@ -437,10 +444,10 @@ def groupnorm_tokens(x, gamma, beta, groups, eps, out_slice, out_batch_stride):
     CALLS["groupnorm_tokens"] += 1
     B, HW, C = x.shape
     ws = torch.empty(lib.codetr_groupnorm_tokens_workspace_bytes(B, HW, C), dtype=torch.uint8, device=x.device)
-    rc = lib.codetr_groupnorm_tokens_f16(current_stream_ptr(x.device), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                         out_slice.data_ptr(), out_batch_stride, ws.data_ptr(), B, HW, C, groups,
-                                         float(eps))
-    check(rc, "codetr_groupnorm_tokens_f16")
+    fn = lib.codetr_groupnorm_tokens_bf16 if x.dtype == torch.bfloat16 else lib.codetr_groupnorm_tokens_f16
+    rc = fn(current_stream_ptr(x.device), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out_slice.data_ptr(),
+            out_batch_stride, ws.data_ptr(), B, HW, C, groups, float(eps))
+    check(rc, "codetr_groupnorm_tokens")
 
 
 def msda_head_major_supported(dtype, D, L, P) -> bool:
@@ -453,11 +460,13 @@ def sine_pos_tokens(ycum, xcum, level_embed, out_slice, out_batch_stride, num_fe
     """ycum/xcum [B,H,W] fp32 -> encoding written at out_slice.data_ptr() (image 0), see include/codetr_hip.h."""
     CALLS["sine_pos_tokens"] += 1
     B, H, W = ycum.shape
-    rc = load().codetr_sine_pos_tokens_f16(
+    lib = load()
+    fn = lib.codetr_sine_pos_tokens_bf16 if out_slice.dtype == torch.bfloat16 else lib.codetr_sine_pos_tokens_f16
+    rc = fn(
         current_stream_ptr(ycum.device), ycum.data_ptr(), xcum.data_ptr(),
         level_embed.data_ptr() if level_embed is not None else None, out_slice.data_ptr(), out_batch_stride, B, H, W,
         num_feats, float(temperature), float(scale), float(eps), float(offset), 1 if normalize else 0)
-    check(rc, "codetr_sine_pos_tokens_f16")
+    check(rc, "codetr_sine_pos_tokens")
 
 
 def ffn_fused_supported(x, w1, w2, act) -> bool:

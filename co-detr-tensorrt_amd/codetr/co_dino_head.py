@@ -107,7 +107,7 @@ class CoDINOHead(nn.Module):
         Himg, Wimg = img_masks.shape[-2:]
         masks, pos = [], []
         pe = self.positional_encoding
-        native_pos = feat.is_cuda and feat.dtype == torch.float16 and pe.num_feats % 8 == 0
+        native_pos = feat.is_cuda and feat.dtype in (torch.float16, torch.bfloat16) and pe.num_feats % 8 == 0
         pos_flat = feat.new_empty(feat.shape[0], feat.shape[1], 2 * pe.num_feats) if native_pos else None
         B = feat.shape[0]
         mask_flat = valid_counts = None

@@ -194,7 +194,7 @@ def layer_norm(x, weight, bias, eps=1e-5):
 
 
 def patch_merge_layernorm_supported(x, C):
-    return (x.is_cuda and x.dtype == torch.float16 and C % 8 == 0 and 4 * C <= 4096
+    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and C % 8 == 0 and 4 * C <= 4096
             and os.environ.get("CODETR_MERGE_LN", "1") != "0")
 
 
@@ -321,8 +321,10 @@ def sine_pos_tokens_into(mask, dest, row_start, level_embed, num_feats, temperat
     else:
         ycum, xcum = cums
         _gpu(ycum, "sine_pos_tokens_into")
-    if dest.dtype != torch.float16 or not dest.is_contiguous() or dest.shape[2] != 2 * num_feats:
-        raise AssertionError("destination must be a contiguous f16 [B, S, 2*num_feats] tensor")
+    if dest.dtype not in (torch.float16, torch.bfloat16) or not dest.is_contiguous() or dest.shape[2] != 2 * num_feats:
+        raise AssertionError("destination must be a contiguous f16 / bf16 [B, S, 2*num_feats] tensor")
+    if level_embed is not None and level_embed.dtype != dest.dtype:
+        level_embed = level_embed.to(dest.dtype)
     with torch.cuda.device(ycum.device):
         _cabi.sine_pos_tokens(ycum, xcum, level_embed, dest[0, row_start:], dest.shape[1] * dest.shape[2], num_feats,
                               temperature, scale, eps, offset, normalize)

@@ -158,7 +158,8 @@ class DinoTransformerDecoder(nn.Module):
         read once instead of once per layer; the output is laid out [layer][B*S][256], so each layer's value map is a
         contiguous [B,S,M,D] tensor.  None when the fused form does not apply (then every layer projects itself)."""
         atts = self._cross_attentions()
-        if (atts is None or not memory.is_cuda or memory.dtype != torch.float16 or torch.is_grad_enabled()
+        if (atts is None or not memory.is_cuda or memory.dtype not in (torch.float16, torch.bfloat16)
+                or torch.is_grad_enabled()
                 or os.environ.get("CODETR_DEC_VPROJ", "1") == "0"):
             return None
         C = atts[0].value_proj.out_features

@@ -21,19 +21,29 @@ constexpr int kThreads = 256;
 constexpr int kRowsPerSlab = 128;  // rows reduced by one workgroup in pass 1 (600 workgroups at the stride-8 level)
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+// BF = false: fp16 storage, true: bf16 storage (fp32 statistics and arithmetic either way)
+template <bool BF>
 __device__ __forceinline__ float h2f(short b) {
+  if (BF) return __uint_as_float(((unsigned)(unsigned short)b) << 16);
   _Float16 h;
   __builtin_memcpy(&h, &b, 2);
   return (float)h;
 }
+template <bool BF>
 __device__ __forceinline__ short f2h(float v) {
-  _Float16 h = (_Float16)v;
   short b;
+  if (BF) {
+    const __bf16 h = (__bf16)v;  // round-to-nearest-even
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+  }
+  const _Float16 h = (_Float16)v;
   __builtin_memcpy(&b, &h, 2);
   return b;
 }
 
 // grid (nslab, B); partial[b][slab][group][2]
+template <bool BF>
 __global__ __launch_bounds__(kThreads) void gn_partial_kernel(const short* __restrict__ x, float* __restrict__ partial,
                                                               int HW, int C, int nslab) {
   const int groups = C >> 3;                    // lanes per row
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void gn_partial_kernel(const short* __res
       const s16x8 v = *reinterpret_cast<const s16x8*>(xb + (size_t)r * C + gidx * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float f = h2f(v[e]);
+        const float f = h2f<BF>(v[e]);
         s += f;
         q = fmaf(f, f, q);
       }
@@ -97,6 +107,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   }
 }
 
+template <bool BF>
 __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const short* __restrict__ x, const float* __restrict__ stats,
                                                             const short* __restrict__ gamma, const short* __restrict__ beta,
                                                             short* __restrict__ out, int64_t out_batch_stride, int HW,
@@ -113,9 +124,40 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const short* __restr
     const s16x8 gb = *reinterpret_cast<const s16x8*>(beta + g * 8);
     s16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2h(fmaf((h2f(v[e]) - mean) * rstd, h2f(gw[e]), h2f(gb[e])));
+    for (int e = 0; e < 8; ++e) o[e] = f2h<BF>(fmaf((h2f<BF>(v[e]) - mean) * rstd, h2f<BF>(gw[e]), h2f<BF>(gb[e])));
     *reinterpret_cast<s16x8*>(out + (size_t)b * out_batch_stride + (size_t)r * C + g * 8) = o;
   }
+}
+
+}  // namespace
+
+namespace {
+
+template <bool BF>
+int gn_entry(void* stream, const void* x_dev, const void* gamma_dev, const void* beta_dev,
+                                void* out_dev, int64_t out_batch_stride, void* workspace_dev, int64_t B, int64_t HW,
+                                int64_t C, int groups, float eps) {
+  if (!x_dev || !gamma_dev || !beta_dev || !out_dev || !workspace_dev || B <= 0 || HW <= 0 || C <= 0)
+    return CODETR_E_BADARG;
+  if (groups <= 0 || C != (int64_t)groups * 8 || groups > kThreads || kThreads % groups != 0) return CODETR_E_UNSUPPORTED;
+  if (HW > 0x7fffffffLL || B > 65535) return CODETR_E_TOO_LARGE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nslab = (int)((HW + kRowsPerSlab - 1) / kRowsPerSlab);
+  float* partial = static_cast<float*>(workspace_dev);
+  float* stats = partial + (size_t)B * nslab * groups * 2;
+  hipLaunchKernelGGL(gn_partial_kernel<BF>, dim3(nslab, (unsigned)B), dim3(kThreads), 0, st,
+                     static_cast<const short*>(x_dev), partial, (int)HW, (int)C, nslab);
+  const int nstat = (int)(B * groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nstat), dim3(64), 0, st, partial, stats, (int)B, groups,
+                     nslab, (double)HW * 8.0, eps);
+  const int64_t chunks = B * HW * groups;
+  int64_t blocks = (chunks + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gn_apply_kernel<BF>, dim3((unsigned)blocks), dim3(kThreads), 0, st, static_cast<const short*>(x_dev),
+                     stats, static_cast<const short*>(gamma_dev), static_cast<const short*>(beta_dev),
+                     static_cast<short*>(out_dev), out_batch_stride, (int)HW, (int)C, chunks);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
 }
 
 }  // namespace
@@ -131,27 +173,15 @@ int64_t codetr_groupnorm_tokens_workspace_bytes(int64_t B, int64_t HW, int64_t C
 int codetr_groupnorm_tokens_f16(void* stream, const void* x_dev, const void* gamma_dev, const void* beta_dev,
                                 void* out_dev, int64_t out_batch_stride, void* workspace_dev, int64_t B, int64_t HW,
                                 int64_t C, int groups, float eps) {
-  if (!x_dev || !gamma_dev || !beta_dev || !out_dev || !workspace_dev || B <= 0 || HW <= 0 || C <= 0)
-    return CODETR_E_BADARG;
-  if (groups <= 0 || C != (int64_t)groups * 8 || groups > kThreads || kThreads % groups != 0) return CODETR_E_UNSUPPORTED;
-  if (HW > 0x7fffffffLL || B > 65535) return CODETR_E_TOO_LARGE;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nslab = (int)((HW + kRowsPerSlab - 1) / kRowsPerSlab);
-  float* partial = static_cast<float*>(workspace_dev);
-  float* stats = partial + (size_t)B * nslab * groups * 2;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, (unsigned)B), dim3(kThreads), 0, st,
-                     static_cast<const short*>(x_dev), partial, (int)HW, (int)C, nslab);
-  const int nstat = (int)(B * groups);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nstat), dim3(64), 0, st, partial, stats, (int)B, groups,
-                     nslab, (double)HW * 8.0, eps);
-  const int64_t chunks = B * HW * groups;
-  int64_t blocks = (chunks + kThreads - 1) / kThreads;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, static_cast<const short*>(x_dev),
-                     stats, static_cast<const short*>(gamma_dev), static_cast<const short*>(beta_dev),
-                     static_cast<short*>(out_dev), out_batch_stride, (int)HW, (int)C, chunks);
-  const hipError_t err = hipGetLastError();
-  return err == hipSuccess ? 0 : (int)err;
+  return gn_entry<false>(stream, x_dev, gamma_dev, beta_dev, out_dev, out_batch_stride, workspace_dev, B, HW, C, groups,
+                       eps);
+}
+
+int codetr_groupnorm_tokens_bf16(void* stream, const void* x_dev, const void* gamma_dev, const void* beta_dev,
+                                void* out_dev, int64_t out_batch_stride, void* workspace_dev, int64_t B, int64_t HW,
+                                int64_t C, int groups, float eps) {
+  return gn_entry<true>(stream, x_dev, gamma_dev, beta_dev, out_dev, out_batch_stride, workspace_dev, B, HW, C, groups,
+                       eps);
 }
 
 }  // extern "C"

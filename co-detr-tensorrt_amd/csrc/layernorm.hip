@@ -146,6 +146,7 @@ int launch_cfg(hipStream_t st, const void* x, const void* g, const void* b, void
   return err == hipSuccess ? 0 : (int)err;
 }
 
+template <class T>
 int launch_merge(hipStream_t st, const void* x, const void* g, const void* b, void* y, int64_t B, int64_t H, int64_t W,
                  int64_t Cs, float eps) {
   if (!x || !g || !b || !y || B <= 0 || H <= 0 || W <= 0 || Cs <= 0) return CODETR_E_BADARG;
@@ -155,13 +156,13 @@ int launch_merge(hipStream_t st, const void* x, const void* g, const void* b, vo
   MergeGeom mg{(int)H, (int)W, (int)Cs, (int)((H + 1) / 2), (int)((W + 1) / 2)};
   const int64_t rows = B * mg.H2 * mg.W2;
   const int nch = (int)(C / 8);
-  if (nch <= 32) return launch_cfg<LnHalf, 32, 1, true>(st, x, g, b, y, rows, (int)C, eps, mg);
-  if (nch <= 64) return launch_cfg<LnHalf, 64, 1, true>(st, x, g, b, y, rows, (int)C, eps, mg);
-  if (nch <= 128) return launch_cfg<LnHalf, 64, 2, true>(st, x, g, b, y, rows, (int)C, eps, mg);
-  if (nch <= 192) return launch_cfg<LnHalf, 64, 3, true>(st, x, g, b, y, rows, (int)C, eps, mg);
-  if (nch <= 256) return launch_cfg<LnHalf, 64, 4, true>(st, x, g, b, y, rows, (int)C, eps, mg);
-  if (nch <= 384) return launch_cfg<LnHalf, 64, 6, true>(st, x, g, b, y, rows, (int)C, eps, mg);
-  return launch_cfg<LnHalf, 64, 8, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 32) return launch_cfg<T, 32, 1, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 64) return launch_cfg<T, 64, 1, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 128) return launch_cfg<T, 64, 2, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 192) return launch_cfg<T, 64, 3, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 256) return launch_cfg<T, 64, 4, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  if (nch <= 384) return launch_cfg<T, 64, 6, true>(st, x, g, b, y, rows, (int)C, eps, mg);
+  return launch_cfg<T, 64, 8, true>(st, x, g, b, y, rows, (int)C, eps, mg);
 }
 
 template <class T>
@@ -194,7 +195,12 @@ int codetr_layernorm_bf16(void* stream, const void* x_dev, const void* gamma_dev
 
 int codetr_patch_merge_layernorm_f16(void* stream, const void* x_dev, const void* gamma_dev, const void* beta_dev,
                                      void* y_dev, int64_t B, int64_t H, int64_t W, int64_t C, float eps) {
-  return launch_merge(static_cast<hipStream_t>(stream), x_dev, gamma_dev, beta_dev, y_dev, B, H, W, C, eps);
+  return launch_merge<LnHalf>(static_cast<hipStream_t>(stream), x_dev, gamma_dev, beta_dev, y_dev, B, H, W, C, eps);
+}
+
+int codetr_patch_merge_layernorm_bf16(void* stream, const void* x_dev, const void* gamma_dev, const void* beta_dev,
+                                      void* y_dev, int64_t B, int64_t H, int64_t W, int64_t C, float eps) {
+  return launch_merge<LnBf16>(static_cast<hipStream_t>(stream), x_dev, gamma_dev, beta_dev, y_dev, B, H, W, C, eps);
 }
 
 }  // extern "C"

@@ -17,10 +17,13 @@ namespace {
 
 constexpr int kThreads = 256;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// E = _Float16 or __bf16 (storage of the encoding and of level_embed; fp32 arithmetic either way)
+template <class E, class V8>
 __global__ __launch_bounds__(kThreads) void sine_pos_kernel(const float* __restrict__ ycum, const float* __restrict__ xcum,
-                                                            const _Float16* __restrict__ level_embed,
-                                                            _Float16* __restrict__ out, int64_t out_batch_stride, int H,
+                                                            const E* __restrict__ level_embed,
+                                                            E* __restrict__ out, int64_t out_batch_stride, int H,
                                                             int W, int num_feats, float log2_temperature, float scale,
                                                             float eps, float offset, int normalize, int64_t total_chunks) {
   const int lanes_per_token = (2 * num_feats) >> 3;  // 16-byte chunks per token
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void sine_pos_kernel(const float* __restr
       e = (e + offset) / (last + eps) * scale;
     }
     const int ch0 = (is_x ? c - half : c) * 8;  // first channel of this chunk inside its axis block
-    f16x8 o;
+    V8 o;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int f = (ch0 >> 1) + p;  // frequency index: channels 2f, 2f+1
@@ -49,23 +52,24 @@ __global__ __launch_bounds__(kThreads) void sine_pos_kernel(const float* __restr
       // angle here is <= scale + a little, ~1 revolution); ~1e-6 absolute, far inside the f16 rounding of the result,
       // and ~10x fewer instructions than libm's sinf / cosf with their own range reduction
       const float rev = e * inv * 0.15915494309189535f;
-      o[2 * p] = (_Float16)__builtin_amdgcn_sinf(rev);
-      o[2 * p + 1] = (_Float16)__builtin_amdgcn_cosf(rev);
+      o[2 * p] = (E)__builtin_amdgcn_sinf(rev);
+      o[2 * p + 1] = (E)__builtin_amdgcn_cosf(rev);
     }
     if (level_embed) {
-      const f16x8 le = *reinterpret_cast<const f16x8*>(level_embed + c * 8);
+      const V8 le = *reinterpret_cast<const V8*>(level_embed + c * 8);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = (_Float16)((float)o[k] + (float)le[k]);  // fp16 + fp16 -> fp16, as the reference
+      for (int k = 0; k < 8; ++k) o[k] = (E)((float)o[k] + (float)le[k]);  // fp16 + fp16 -> fp16, as the reference
     }
-    *reinterpret_cast<f16x8*>(out + (size_t)b * out_batch_stride + (size_t)r * (2 * num_feats) + c * 8) = o;
+    *reinterpret_cast<V8*>(out + (size_t)b * out_batch_stride + (size_t)r * (2 * num_feats) + c * 8) = o;
   }
 }
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int codetr_sine_pos_tokens_f16(void* stream, const float* ycum_dev, const float* xcum_dev, const void* level_embed_dev,
+template <class E, class V8>
+int sine_entry(void* stream, const float* ycum_dev, const float* xcum_dev, const void* level_embed_dev,
                                void* out_dev, int64_t out_batch_stride, int64_t B, int64_t H, int64_t W, int num_feats,
                                float temperature, float scale, float eps, float offset, int normalize) {
   if (!ycum_dev || !xcum_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || num_feats <= 0 || temperature <= 0.f)
@@ -75,11 +79,29 @@ int codetr_sine_pos_tokens_f16(void* stream, const float* ycum_dev, const float*
   const int64_t chunks = B * H * W * ((2 * num_feats) / 8);
   int64_t blocks = (chunks + kThreads - 1) / kThreads;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(sine_pos_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream), ycum_dev,
-                     xcum_dev, static_cast<const _Float16*>(level_embed_dev), static_cast<_Float16*>(out_dev),
+  hipLaunchKernelGGL((sine_pos_kernel<E, V8>), dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream), ycum_dev,
+                     xcum_dev, static_cast<const E*>(level_embed_dev), static_cast<E*>(out_dev),
                      out_batch_stride, (int)H, (int)W, num_feats, log2f(temperature), scale, eps, offset, normalize, chunks);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_sine_pos_tokens_f16(void* stream, const float* ycum_dev, const float* xcum_dev, const void* level_embed_dev,
+                               void* out_dev, int64_t out_batch_stride, int64_t B, int64_t H, int64_t W, int num_feats,
+                               float temperature, float scale, float eps, float offset, int normalize) {
+  return sine_entry<_Float16, f16x8>(stream, ycum_dev, xcum_dev, level_embed_dev, out_dev, out_batch_stride, B, H, W, num_feats,
+                             temperature, scale, eps, offset, normalize);
+}
+
+int codetr_sine_pos_tokens_bf16(void* stream, const float* ycum_dev, const float* xcum_dev, const void* level_embed_dev,
+                               void* out_dev, int64_t out_batch_stride, int64_t B, int64_t H, int64_t W, int num_feats,
+                               float temperature, float scale, float eps, float offset, int normalize) {
+  return sine_entry<__bf16, bf16x8>(stream, ycum_dev, xcum_dev, level_embed_dev, out_dev, out_batch_stride, B, H, W, num_feats,
+                             temperature, scale, eps, offset, normalize);
 }
 
 }  // extern "C"

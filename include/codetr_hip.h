@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 24
+#define CODETR_HIP_ABI_VERSION 25
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -355,6 +355,8 @@ int codetr_layernorm_bf16(void *stream, const void *x_dev, const void *gamma_dev
  * permuted from nn.Unfold's (c, ky, kx); zeros beyond an odd H / W.  C % 8 == 0, 4C <= 4096. */
 int codetr_patch_merge_layernorm_f16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev,
                                      void *y_dev, int64_t B, int64_t H, int64_t W, int64_t C, float eps);
+int codetr_patch_merge_layernorm_bf16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev,
+                                     void *y_dev, int64_t B, int64_t H, int64_t W, int64_t C, float eps);  /* bf16 storage, same contract */
 
 /* ------------------------------------------------------------------------------------------
  * Fused (shifted-)window multi-head self-attention of one Swin block.
@@ -401,6 +403,9 @@ int64_t codetr_groupnorm_tokens_workspace_bytes(int64_t B, int64_t HW, int64_t C
 int codetr_groupnorm_tokens_f16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev,
                                 void *out_dev, int64_t out_batch_stride, void *workspace_dev, int64_t B, int64_t HW,
                                 int64_t C, int groups, float eps);
+int codetr_groupnorm_tokens_bf16(void *stream, const void *x_dev, const void *gamma_dev, const void *beta_dev,
+                                void *out_dev, int64_t out_batch_stride, void *workspace_dev, int64_t B, int64_t HW,
+                                int64_t C, int groups, float eps);  /* bf16 storage, same contract */
 
 /* ------------------------------------------------------------------------------------------
  * Sine positional encoding of one pyramid level, written into a slice of lvl_pos_embed [B, S, 2*num_feats].
@@ -417,6 +422,9 @@ int codetr_groupnorm_tokens_f16(void *stream, const void *x_dev, const void *gam
 int codetr_sine_pos_tokens_f16(void *stream, const float *ycum_dev, const float *xcum_dev, const void *level_embed_dev,
                                void *out_dev, int64_t out_batch_stride, int64_t B, int64_t H, int64_t W, int num_feats,
                                float temperature, float scale, float eps, float offset, int normalize);
+int codetr_sine_pos_tokens_bf16(void *stream, const float *ycum_dev, const float *xcum_dev, const void *level_embed_dev,
+                               void *out_dev, int64_t out_batch_stride, int64_t B, int64_t H, int64_t W, int num_feats,
+                               float temperature, float scale, float eps, float offset, int normalize);  /* bf16 storage, same contract */
 
 /* ------------------------------------------------------------------------------------------
  * Fused transformer FFN:  y = x + relu(x . w1^T + b1) . w2^T + b2      (hidden activation never leaves the CU)

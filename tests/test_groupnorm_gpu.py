@@ -25,3 +25,20 @@ def test_groupnorm_tokens_into_slice(B, H, W):
     got = dest[:, 5:5 + H * W].float()
     assert ((got - ref).abs() <= 2.0 ** -10 * ref.abs() + 2e-3).all(), float((got - ref).abs().max())
     assert (dest[:, :5] == 7).all() and (dest[:, 5 + H * W:] == 7).all()  # neighbours untouched
+
+
+def test_groupnorm_tokens_bf16():
+    """bf16 storage instantiation against F.group_norm in fp32"""
+    import torch.nn.functional as F
+    from codetr import _cabi
+
+    g = torch.Generator(device=DEV).manual_seed(4)
+    B, HW, C = 2, 777, 256
+    x = (torch.randn(B, HW, C, device=DEV, generator=g) * 2 + 0.5).bfloat16()
+    gam = (1 + 0.1 * torch.randn(C, device=DEV, generator=g)).bfloat16()
+    bet = (0.1 * torch.randn(C, device=DEV, generator=g)).bfloat16()
+    out = torch.empty(B, HW + 50, C, dtype=torch.bfloat16, device=DEV)
+    _cabi.groupnorm_tokens(x, gam, bet, 32, 1e-5, out[0, 50:], out.shape[1] * C)
+    torch.cuda.synchronize()
+    ref = F.group_norm(x.float().transpose(1, 2), 32, gam.float(), bet.float(), 1e-5).transpose(1, 2)
+    torch.testing.assert_close(out[:, 50:].float(), ref, rtol=1e-2, atol=2e-2)

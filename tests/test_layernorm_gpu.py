@@ -71,3 +71,20 @@ def test_patch_merge_layernorm_equals_gather_then_layernorm(B, H, W, C):
     y = hip_ops.patch_merge_layernorm(x, (H, W), gam, bet, 1e-5)      # odd sizes: the kernel pads with zeros itself
     assert _cabi.CALLS["patch_merge_layernorm"] == before + 1
     assert y.shape == ref.shape and torch.equal(y, ref)
+
+
+def test_patch_merge_layernorm_bf16():
+    """bf16 instantiation of the merge + LayerNorm kernel against gather + F.layer_norm in fp32"""
+    import torch.nn.functional as F
+    from codetr import _cabi
+
+    g = torch.Generator(device=DEV).manual_seed(8)
+    B, H, W, C = 2, 14, 10, 96
+    x = torch.randn(B, H, W, C, device=DEV, generator=g).bfloat16()
+    gam = (1 + 0.1 * torch.randn(4 * C, device=DEV, generator=g)).bfloat16()
+    bet = (0.1 * torch.randn(4 * C, device=DEV, generator=g)).bfloat16()
+    out = _cabi.patch_merge_layernorm(x, gam, bet, 1e-5)
+    torch.cuda.synchronize()
+    m = x.float().view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, (H // 2) * (W // 2), 4 * C)
+    ref = F.layer_norm(m, (4 * C,), gam.float(), bet.float(), 1e-5)
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=2e-2)

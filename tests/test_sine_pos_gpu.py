@@ -43,3 +43,21 @@ def test_sine_pos_tokens_vs_module_fp32(H, W, normalize):
     hip_ops.sine_pos_tokens_into(mask, dest, 0, lvl, 128, 20, pe.scale, pe.eps, pe.offset, normalize)
     tol = 2e-3 if normalize else 2e-2  # un-normalised: angles up to H, sin/cos of large arguments in fp32 vs fp32
     torch.testing.assert_close(dest.float(), ref, rtol=0, atol=tol)
+
+
+def test_sine_pos_tokens_bf16_matches_f16_kernel():
+    """bf16 storage instantiation: same fp32 arithmetic as the f16 kernel, rounded to bf16 instead"""
+    from codetr import hip_ops
+
+    B, H, W, nf = 2, 9, 13, 128
+    mask = torch.zeros(B, H, W, dtype=torch.bool, device=DEV)
+    mask[1, 7:, :] = True
+    mask[1, :, 10:] = True
+    le = torch.randn(2 * nf, device=DEV)
+    outs = {}
+    for dt in (torch.float16, torch.bfloat16):
+        dest = torch.zeros(B, H * W + 5, 2 * nf, dtype=dt, device=DEV)
+        hip_ops.sine_pos_tokens_into(mask, dest, 5, le.to(dt), nf, 20, 2 * 3.141592653589793, 1e-6, 0.0, True)
+        outs[dt] = dest[:, 5:].float()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(outs[torch.bfloat16], outs[torch.float16], rtol=1e-2, atol=2e-2)
