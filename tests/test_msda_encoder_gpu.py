@@ -131,6 +131,33 @@ def test_full_size_launch_identical():
     _assert_identical(out, want, "1920x1280")
 
 
+def test_full_size_sampled_queries_against_float64_oracle():
+    """BASELINE's pyramid, one image: 768 queries drawn from all levels (incl. the image border and the level
+    boundaries) against the float64 CPU oracle -- parity at the full size, not only identity with the general kernel."""
+    from oracle import msda_oracle
+
+    shapes = [(320, 480), (160, 240), (80, 120), (40, 60), (20, 30)]
+    M, P, L = 8, 4, 5
+    out, _, (value, proj, ref, ss, ls) = _run_both(shapes, B=1, off_scale=2.5, seed=43)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(1)
+    starts = [0]
+    for h, w in shapes:
+        starts.append(starts[-1] + h * w)
+    idx = torch.cat([torch.randint(starts[l], starts[l + 1], (150,), generator=g) for l in range(L)]
+                    + [torch.tensor([0, 479, 480 * 319, starts[1] - 1, starts[1], starts[4], S - 1])]).unique()
+    sub = proj[0, idx.to(DEV)].double().cpu()
+    off = sub[:, :M * L * P * 2].view(1, -1, M, L, P, 2)
+    w = torch.softmax(sub[:, M * L * P * 2:M * L * P * 3].view(1, -1, M, L * P), -1).view(1, -1, M, L, P)
+    norm = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float64)
+    loc = ref[0, idx.to(DEV)].double().cpu()[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    ssn = np.asarray(shapes, dtype=np.int64)
+    expect = msda_oracle.msda_forward_numpy(value.double().cpu().numpy(), ssn,
+                                            msda_oracle.level_start_index_from_shapes(ssn), loc.numpy(), w.numpy())
+    got = out[0, idx.to(DEV)].float().cpu().numpy()
+    np.testing.assert_allclose(got, expect[0], rtol=4e-3, atol=4e-3)
+
+
 def test_unsupported_shapes_fall_back():
     """A halo whose neighbourhoods do not fit LDS -> the library declines, hip_ops returns None (the module then calls
     the general kernel)."""
