@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -40,6 +40,8 @@ SIGNATURES = {
                                                _i32, _i32, _vp]),
     "codetr_msda_encoder_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32,
                                                 _i32, _i32, _vp]),
+    "codetr_mha_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
+    "codetr_mha_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
@@ -85,7 +87,7 @@ _lib = None
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
-         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0}
+         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0}
 
 
 def load():
@@ -421,6 +423,25 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points,
     check(rc, "codetr_msda_encoder_forward")
     CALLS["msda_encoder"] += 1
     return True
+
+
+def mha_attention_supported(q, k, v, num_heads) -> bool:
+    C = q.shape[-1]
+    return (q.dtype in (torch.float16, torch.bfloat16) and k.dtype == q.dtype and v.dtype == q.dtype
+            and C == num_heads * 32 and k.shape[1] <= 1024 and q.stride(-1) == 1 and k.stride(-1) == 1
+            and v.stride(-1) == 1 and all(t.stride(0) == t.shape[1] * t.stride(1) for t in (q, k, v))
+            and all(t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0 for t in (q, k, v)))
+
+
+def mha_attention(q, k, v, num_heads, out):
+    """q [B,Nq,C], k / v [B,Nk,C] (rows may be strided views of a wider projection output), out [B,Nq,C] contiguous."""
+    lib = load()
+    CALLS["mha_attention"] += 1
+    fn = lib.codetr_mha_attention_bf16 if q.dtype == torch.bfloat16 else lib.codetr_mha_attention_f16
+    rc = fn(current_stream_ptr(q.device), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.shape[0],
+            q.shape[1], k.shape[1], num_heads, 32, q.stride(1), k.stride(1), v.stride(1), out.stride(1))
+    check(rc, "codetr_mha_attention")
+    return out
 
 
 def patch_im2col(x, k, kpad, out):

@@ -27,7 +27,8 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "preprocess_image(u8 -> f16/f32, cv2-exact resize + pad + normalise + mask)", "batched_nms(f32)",
           "patch_merge_layernorm(f16: Swin 2x2 gather + LayerNorm)",
           "msda_encoder(f16/bf16: LDS-staged gather for the encoder's self-attention)",
-          "patch_embed(f16/bf16: 4x4 patch gather + GEMM)"}
+          "patch_embed(f16/bf16: 4x4 patch gather + GEMM)",
+          "mha_attention(f16/bf16: dense softmax attention, head_dim 32, <= 1024 keys)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -380,12 +381,22 @@ def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_s
     return out
 
 
+MHA_NATIVE = os.environ.get("CODETR_MHA", "1") != "0"     # A/B switch: 0 = the SDPA library call
+
+
 def mha_self_attention(q, k, v, num_heads):
-    """q,k,v [B, N, C] already projected -> [B, N, C] (dense softmax attention, 900x900 in the decoder)."""
+    """q,k,v [B, N, C] already projected (q / k may be column slices of one fused projection) -> [B, N, C]: dense
+    softmax attention, 900 x 900 per head in the decoder (reference transformer_mmcv.py:394-428).  Native kernel for
+    head_dim 32 and up to 1024 keys; the SDPA library call otherwise (fp32 parity runs, other head sizes)."""
     _gpu(q, "mha_self_attention")
     B, N, C = q.shape
+    if MHA_NATIVE and _cabi.mha_attention_supported(q, k, v, num_heads):
+        out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
+        with torch.cuda.device(q.device):
+            _cabi.mha_attention(q, k, v, num_heads, out)
+        return out
     hd = C // num_heads
-    sp = lambda t: t.view(B, -1, num_heads, hd).transpose(1, 2)  # noqa: E731
+    sp = lambda t: t.reshape(B, -1, num_heads, hd).transpose(1, 2)  # noqa: E731
     o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v))
     return o.transpose(1, 2).reshape(B, N, C)
 

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 25
+#define CODETR_HIP_ABI_VERSION 26
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -384,6 +384,23 @@ int codetr_window_attention_f16(void *stream, const void *qkv_dev, const void *q
 int codetr_window_attention_bf16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
                                  const void *rel_bias_dev, void *out_dev, int64_t B, int64_t H, int64_t W,
                                  int num_heads, int head_dim, int window_size, int shift);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense multi-head softmax attention, head_dim 32: the core of nn.MultiheadAttention(256, 8) in the decoder's
+ * self-attention (reference codetr/transformer_mmcv.py:394-428, called from DetrTransformerDecoderLayer,
+ * codetr/transformer.py:233-277) between its in- and out-projections, which are codetr_linear_* calls:
+ *   out[b, i, h*32 + c] = sum_j softmax_j(q[b,i,h,:] . k[b,j,h,:] / sqrt(32)) * v[b, j, h*32 + c]
+ *   q_dev   [B, Nq, >= H*32]  rows q_row_stride elements apart (q and k may be column ranges of one fused projection)
+ *   k_dev, v_dev [B, Nk, ...] likewise;  out_dev [B, Nq, ...] rows out_row_stride apart
+ * No attention / key-padding mask (the inference path has none).  fp32 scores, online softmax over 128-key chunks,
+ * fp32 accumulation.  Nk <= 1024 (K and V of one head live in LDS), head_dim == 32: CODETR_E_UNSUPPORTED otherwise.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_mha_attention_f16(void *stream, const void *q_dev, const void *k_dev, const void *v_dev, void *out_dev,
+                             int64_t B, int64_t Nq, int64_t Nk, int num_heads, int head_dim, int64_t q_row_stride,
+                             int64_t k_row_stride, int64_t v_row_stride, int64_t out_row_stride);
+int codetr_mha_attention_bf16(void *stream, const void *q_dev, const void *k_dev, const void *v_dev, void *out_dev,
+                              int64_t B, int64_t Nq, int64_t Nk, int num_heads, int head_dim, int64_t q_row_stride,
+                              int64_t k_row_stride, int64_t v_row_stride, int64_t out_row_stride);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm on token-major activations, written into a slice of the flattened multi-level map.
