@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -42,6 +42,8 @@ SIGNATURES = {
                                                 _i32, _i32, _vp]),
     "codetr_mha_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
     "codetr_mha_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
+    "codetr_linear_xadd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
+    "codetr_linear_xadd_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
@@ -442,6 +444,26 @@ def mha_attention(q, k, v, num_heads, out):
             q.shape[1], k.shape[1], num_heads, 32, q.stride(1), k.stride(1), v.stride(1), out.stride(1))
     check(rc, "codetr_mha_attention")
     return out
+
+
+def linear_xadd_supported(M, N, K, dtype) -> bool:
+    """mirror of the library's rule for codetr_linear_xadd_* (the X-stationary kernel's shapes)"""
+    return (dtype in (torch.float16, torch.bfloat16) and K in (192, 256) and N % 8 == 0 and 128 <= N <= 1536
+            and M >= 128 * 256 and os.environ.get("CODETR_GEMM_XS", "1") != "0")
+
+
+def linear_xadd(x2d, xadd2d, w, bias, out2d) -> bool:
+    """out = (x + x_add) @ w.T + bias; False when the library declines the shape (caller adds and calls linear)."""
+    lib = load()
+    fn = lib.codetr_linear_xadd_bf16 if x2d.dtype == torch.bfloat16 else lib.codetr_linear_xadd_f16
+    M, K = x2d.shape
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), xadd2d.data_ptr(), w.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out2d.data_ptr(), M, w.shape[0], K)
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "codetr_linear_xadd")
+    CALLS["linear"] += 1
+    return True
 
 
 def patch_im2col(x, k, kpad, out):

@@ -128,6 +128,53 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
     return y
 
 
+XADD = os.environ.get("CODETR_XADD", "1") != "0"   # A/B switch: 0 = `query + query_pos` as its own kernel / FFN output
+# Below this many rows the 256-tile GEMM on a stored `query + query_pos` wins over the X-stationary kernel with the add
+# folded in (measured: one 1920x1280 image, 204 600 rows, +0.09 ms per forward; four images -0.35 ms)
+XADD_MIN_ROWS = int(os.environ.get("CODETR_XADD_MIN_ROWS", "400000"))
+
+
+def linear_xadd_supported(x, x_add, weight):
+    """True when (x + x_add) @ weight.T runs as ONE kernel (the add folded into the X-stationary GEMM's operand load)"""
+    return (XADD and x.is_cuda and x_add is not None and x_add.shape == x.shape and x_add.dtype == x.dtype
+            and weight.dtype == x.dtype and not torch.is_grad_enabled()
+            and x.numel() // max(x.shape[-1], 1) >= XADD_MIN_ROWS
+            and _cabi.linear_xadd_supported(x.numel() // max(x.shape[-1], 1), weight.shape[0], x.shape[-1], x.dtype))
+
+
+def linear_xadd(x, x_add, weight, bias=None):
+    """(x + x_add) @ weight.T + bias -- `query + query_pos` in front of the (offsets | logits) projection (reference
+    multi_scale_deformable_attention.py:161-162, 177-179); the sum is rounded to the storage type first, exactly as
+    the separate add.  Falls back to add + linear where the fused form does not apply."""
+    _gpu(x, "linear_xadd")
+    if linear_xadd_supported(x, x_add, weight):
+        K, N = x.shape[-1], weight.shape[0]
+        x2, a2 = x.reshape(-1, K), x_add.reshape(-1, K)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        a2 = a2 if a2.is_contiguous() else a2.contiguous()
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        out = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
+        ok = [False]
+
+        def launch():
+            ok[0] = _cabi.linear_xadd(x2, a2, w, bias, out)
+
+        with torch.cuda.device(x.device):
+            if LINEAR_PROFILE is None:
+                launch()
+            else:
+                st = torch.cuda.current_stream(x.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                launch()
+                e1.record(st)
+                if ok[0]:
+                    LINEAR_PROFILE.append((e0, e1, 2.0 * x2.shape[0] * N * K, x2.shape[0], N, K))
+        if ok[0]:
+            return out.view(*x.shape[:-1], N)
+    return linear(x + x_add, weight, bias)
+
+
 # One 128-row block of the fused FFN kernel runs ~100 us (it walks the whole hidden dimension alone), and the chip
 # holds 256 of them: below ~24k rows the grid is under one wave and the two plain GEMMs (which split N over blocks)
 # finish sooner -- measured 98.6 us fused vs 27 us as two GEMMs at the decoder's 900 rows.

@@ -103,10 +103,14 @@ class MultiScaleDeformableAttention(nn.Module):
         query_plus_pos: `query + query_pos` if the caller already holds it.  value_projected [B,S,C]: this module's
         value_proj(value) with the padding mask applied, if the caller already computed it (the decoder projects the
         memory for all its layers in one GEMM)."""
+        pos_in_gemm = None   # query_pos still to be added: folded into the (offsets | logits) GEMM where that applies
         if query_plus_pos is not None:
             query = query_plus_pos
         elif query_pos is not None:
-            query = query + query_pos
+            if self.takes_pos_in_gemm(query, query_pos, value):
+                pos_in_gemm = query_pos
+            else:
+                query = query + query_pos
         B, Nq, _ = query.shape
         S = value.shape[1]
         H, L, P = self.num_heads, self.num_levels, self.num_points
@@ -135,7 +139,7 @@ class MultiScaleDeformableAttention(nn.Module):
         if query.is_cuda and hip_ops.msda_fused_supported(v.dtype, v.shape[-1], L, P):
             # one GEMM for (offsets | logits); softmax and location arithmetic happen inside the MSDA kernel
             Wc, bc = self._fused_projection()
-            proj = hip_ops.linear(query, Wc, bc)
+            proj = hip_ops.linear_xadd(query, pos_in_gemm, Wc, bc) if pos_in_gemm is not None else hip_ops.linear(query, Wc, bc)
             out = None
             host_shapes = getattr(spatial_shapes, "_codetr_host", None)
             if host_shapes is not None and Nq == S and reference_points.shape[-1] == 2:
@@ -162,6 +166,18 @@ class MultiScaleDeformableAttention(nn.Module):
         out = hip_ops.msda(v.contiguous(), spatial_shapes, level_start_index, loc.contiguous(), weights.contiguous(),
                            self.im2col_step)
         return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
+
+    def takes_pos_in_gemm(self, query, query_pos, value):
+        """True when forward_bf adds `query_pos` inside the (offsets | logits) GEMM (so nobody needs to materialise
+        `query + query_pos`): the general fused-projection path + the short-K kernel's shapes."""
+        if query_pos is None or not query.is_cuda or HEAD_MAJOR_VALUE:
+            return False
+        H, L, P = self.num_heads, self.num_levels, self.num_points
+        hd = self.value_proj.out_features // H
+        if not hip_ops.msda_fused_supported(value.dtype, hd, L, P):
+            return False
+        Wc, _ = self._fused_projection()
+        return hip_ops.linear_xadd_supported(query, query_pos, Wc)
 
     # ------------------------------------------------------------------ reference signature
     def forward(

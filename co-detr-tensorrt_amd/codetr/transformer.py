@@ -41,12 +41,17 @@ class DetrTransformerEncoder(nn.Module):
     def forward_bf(self, query, query_pos, query_key_padding_mask, **kw):
         plus_pos = None
         last = len(self.layers) - 1
+        # `out + query_pos` for the next layer: not needed where that layer's attention adds query_pos inside its
+        # (offsets | logits) GEMM
+        att0 = self.layers[0].attentions[0] if getattr(self.layers[0], "attentions", None) else None
+        pos_in_gemm = (att0 is not None and hasattr(att0, "takes_pos_in_gemm") and query_pos is not None
+                       and att0.takes_pos_in_gemm(query, query_pos, query))
         for i, layer in enumerate(self.layers):
             # every layer but the last also hands over `out + query_pos`, the next layer's attention input, from its
             # fused FFN + LayerNorm epilogue (None when that kernel does not apply: the next layer then adds itself)
             query, plus_pos = layer.forward_bf(query, None, None, query_pos=query_pos,
                                                query_key_padding_mask=query_key_padding_mask,
-                                               query_plus_pos=plus_pos, want_plus_pos=True, want_pos_output=i < last,
+                                               query_plus_pos=plus_pos, want_plus_pos=True, want_pos_output=i < last and not pos_in_gemm,
                                                **kw)
         return query
 

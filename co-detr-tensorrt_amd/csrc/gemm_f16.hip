@@ -49,6 +49,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct HalfT {
   using frag = f16x8;
+  using elem = _Float16;
   __device__ static s16x4 pack4(const float (&v)[4]) {  // 2 x v_cvt_pk_f16_f32 (round-to-nearest-even)
     f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     s16x4 o;
@@ -70,6 +71,7 @@ struct HalfT {
 };
 struct BFloatT {
   using frag = bf16x8;
+  using elem = __bf16;
   __device__ static s16x4 pack4(const float (&v)[4]) {
     return s16x4{(short)from_f32(v[0]), (short)from_f32(v[1]), (short)from_f32(v[2]), (short)from_f32(v[3])};
   }
@@ -882,6 +884,7 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
 // W (<= 1.2 MB) comes from L2.
 template <class T, int KS, int ACT, bool HAS_RES>
 __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __restrict__ X,
+                                                        const unsigned short* __restrict__ X2,
                                                         const unsigned short* __restrict__ W,
                                                         const unsigned short* __restrict__ bias,
                                                         const unsigned short* __restrict__ R,
@@ -929,6 +932,16 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       xf[mt][ks] = *reinterpret_cast<const typename T::frag*>(X + (size_t)m * K + ks * 32 + grp * 8);
+    // optional second input, added element-wise on the way in (x + x2 rounded to T, the fp16 / bf16 add the host
+    // would otherwise run as its own kernel: `query + query_pos` in front of the offsets | logits projection)
+    if (X2) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const typename T::frag p = *reinterpret_cast<const typename T::frag*>(X2 + (size_t)m * K + ks * 32 + grp * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[mt][ks][e] = (typename T::elem)((float)xf[mt][ks][e] + (float)p[e]);
+      }
+    }
   }
   if (bias) {
     for (int i = tid; i < N / 8; i += 256)
@@ -1062,16 +1075,17 @@ bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
 
 template <class T, int KS, int ACT>
 int launch_xs_res(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
-                  const void* mask, int M, int N, int hm_rows, int hm_hd) {
+                  const void* mask, int M, int N, int hm_rows, int hm_hd, const void* X2 = nullptr) {
   const dim3 grid((unsigned)((M + 127) / 128)), block(256);
   auto x = static_cast<const unsigned short*>(X);
+  auto x2 = static_cast<const unsigned short*>(X2);
   auto w = static_cast<const unsigned short*>(W);
   auto b = static_cast<const unsigned short*>(bias);
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (R) hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, hm_rows, hm_hd);
-  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, hm_rows, hm_hd);
+  if (R) hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true>), grid, block, 0, st, x, x2, w, b, r, y, mk, M, N, hm_rows, hm_hd);
+  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false>), grid, block, 0, st, x, x2, w, b, r, y, mk, M, N, hm_rows, hm_hd);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -1126,9 +1140,32 @@ int launch(hipStream_t st, const void* X, const void* W, const void* bias, const
   }
 }
 
+// x + x2 folded into the X-stationary kernel's operand load (act 0, no residual / mask): only where that kernel applies
+template <class T>
+int launch_xadd(hipStream_t st, const void* X, const void* X2, const void* W, const void* bias, void* Y, int64_t M,
+                int64_t N, int64_t K) {
+  if (!X || !X2 || !W || !Y || M <= 0 || N <= 0 || K <= 0) return CODETR_E_BADARG;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if (!xs_applicable(M, N, K, 0) || K == 64 || (reinterpret_cast<uintptr_t>(Y) & 15) ||
+      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(W)) & 15))
+    return CODETR_E_UNSUPPORTED;
+  if (K == 192) return launch_xs_res<T, 6, 0>(st, X, W, bias, nullptr, Y, nullptr, (int)M, (int)N, 0, 0, X2);
+  return launch_xs_res<T, 8, 0>(st, X, W, bias, nullptr, Y, nullptr, (int)M, (int)N, 0, 0, X2);
+}
+
 }  // namespace
 
 extern "C" {
+
+int codetr_linear_xadd_f16(void* stream, const void* x_dev, const void* x_add_dev, const void* w_dev,
+                           const void* bias_dev, void* y_dev, int64_t M, int64_t N, int64_t K) {
+  return launch_xadd<HalfT>(static_cast<hipStream_t>(stream), x_dev, x_add_dev, w_dev, bias_dev, y_dev, M, N, K);
+}
+
+int codetr_linear_xadd_bf16(void* stream, const void* x_dev, const void* x_add_dev, const void* w_dev,
+                            const void* bias_dev, void* y_dev, int64_t M, int64_t N, int64_t K) {
+  return launch_xadd<BFloatT>(static_cast<hipStream_t>(stream), x_dev, x_add_dev, w_dev, bias_dev, y_dev, M, N, K);
+}
 
 int codetr_linear_f16(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev, const void* residual_dev,
                       const void* row_mask_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act, int64_t hm_rows,

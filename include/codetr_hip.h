@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 26
+#define CODETR_HIP_ABI_VERSION 27
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -195,6 +195,17 @@ int codetr_linear_f16(void *stream, const void *x_dev, const void *w_dev, const 
 int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                        const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
                        int64_t K, int act, int64_t hm_rows, int hm_head_dim);
+
+/* y = (x + x_add) . w^T + bias with the element-wise add folded into the operand load of the short-K kernel:
+ * `query + query_pos` in front of the (offsets | logits) projection of MultiScaleDeformableAttention
+ * (codetr/multi_scale_deformable_attention.py:161-162, 177-179) without a separate add kernel or a stored sum.
+ * x + x_add is rounded to T first, exactly as the stand-alone fp16 / bf16 add.  x_add_dev [M, K] like x_dev.
+ * Only where the X-stationary kernel applies (K in {192, 256}, 128 <= N <= 1536, N % 8 == 0, M >= 32768):
+ * CODETR_E_UNSUPPORTED otherwise -- callers then add and call codetr_linear_*. */
+int codetr_linear_xadd_f16(void *stream, const void *x_dev, const void *x_add_dev, const void *w_dev,
+                           const void *bias_dev, void *y_dev, int64_t M, int64_t N, int64_t K);
+int codetr_linear_xadd_bf16(void *stream, const void *x_dev, const void *x_add_dev, const void *w_dev,
+                            const void *bias_dev, void *y_dev, int64_t M, int64_t N, int64_t K);
 
 /* Split-K form of the same layer for problems with few output tiles and a long K -- the neck's extra
  * 3x3 / stride-2 level (codetr/codetr.py neck, mmdet ChannelMapper extra_convs) run as a GEMM over unfolded

@@ -252,3 +252,41 @@ def test_linear_256_tile_row_states():
     ref[state == 2] = b
     torch.testing.assert_close(y.float(), ref.float(), rtol=2e-3, atol=4e-3)
     assert torch.equal(y[state == 1], torch.zeros_like(y[state == 1])) and torch.equal(y[state == 2], ref[state == 2])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(40000, 480, 256), (32768 + 77, 576, 192), (33000, 256, 256)])
+def test_linear_xadd_matches_add_then_linear(M, N, K, dtype):
+    """codetr_linear_xadd_*: (x + x_add) rounded to the storage type inside the operand load, then the GEMM: against
+    the fp32 product of the SAME rounded sum (the separate add kernel's output), and against add + codetr_linear_*
+    (which may run a different tile kernel: equal up to the accumulation order)."""
+    from codetr import _cabi, hip_ops
+
+    hip_ops.XADD_MIN_ROWS, saved = 0, hip_ops.XADD_MIN_ROWS     # (the host's row threshold is a tuning choice)
+    try:
+        with torch.no_grad():       # (inference path: the fused form is not offered while autograd records)
+            _xadd_case(M, N, K, dtype, _cabi, hip_ops)
+    finally:
+        hip_ops.XADD_MIN_ROWS = saved
+
+
+def _xadd_case(M, N, K, dtype, _cabi, hip_ops):
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    a = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, device=DEV, generator=g).to(dtype)
+    assert hip_ops.linear_xadd_supported(x, a, w)
+    y = hip_ops.linear_xadd(x, a, w, b)
+    ref = hip_ops.linear(x + a, w, b)
+    exact = (x + a).float() @ w.float().t() + b.float()
+    # one rounding of the result: half an ulp at the largest magnitude (2^-11 / 2^-8 relative), with margin
+    tol = (1e-3 if dtype == torch.float16 else 8e-3) * exact.abs().max().item()
+    assert (y.float() - exact).abs().max().item() < tol
+    assert (y.float() - ref.float()).abs().max().item() < tol
+    # shapes outside the short-K kernel: the wrapper adds and calls linear (still correct)
+    xs, as_ = x[:500], a[:500]
+    assert not hip_ops.linear_xadd_supported(xs, as_, w)
+    assert torch.equal(hip_ops.linear_xadd(xs, as_, w, b), hip_ops.linear(xs + as_, w, b))
+    out = torch.empty(500, N, dtype=dtype, device=DEV)
+    assert _cabi.linear_xadd(xs.contiguous(), as_.contiguous(), w, b, out) is False
