@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "codetr_mha_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
     "codetr_linear_xadd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_linear_xadd_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
+    "codetr_im2col_tokens_b16": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
@@ -464,6 +465,17 @@ def linear_xadd(x2d, xadd2d, w, bias, out2d) -> bool:
     check(rc, "codetr_linear_xadd")
     CALLS["linear"] += 1
     return True
+
+
+def im2col_tokens(x4d, k, stride, pad, out):
+    """x4d [B,H,W,C] 16-bit token-major -> out [B*Ho*Wo, k*k*C] with K ordered (ky, kx, c), zero padding"""
+    lib = load()
+    CALLS["patch_im2col"] += 1
+    B, H, W, C = x4d.shape
+    rc = lib.codetr_im2col_tokens_b16(current_stream_ptr(x4d.device), x4d.data_ptr(), B, H, W, C, k, stride, pad,
+                                      out.data_ptr())
+    check(rc, "codetr_im2col_tokens_b16")
+    return out
 
 
 def patch_im2col(x, k, kpad, out):

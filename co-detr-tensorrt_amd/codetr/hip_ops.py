@@ -504,6 +504,22 @@ def patch_embed(x, weight, bias):
     return linear(cols, cache[1], bias).view(B, Hp * Wp, E), (Hp, Wp)
 
 
+def im2col_tokens(x4d, k, stride, pad):
+    """k x k / stride / zero-pad patches of a token-major map x4d [B,H,W,C] -> [B, Ho*Wo, k*k*C], K ordered
+    (ky, kx, c).  Native 16-byte gather for 16-bit maps with C % 8 == 0; strided slices + cat otherwise."""
+    _gpu(x4d, "im2col_tokens")
+    B, H, W, C = x4d.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if x4d.dtype in (torch.float16, torch.bfloat16) and C % 8 == 0 and PATCH_GEMM:
+        out = torch.empty((B, Ho * Wo, k * k * C), dtype=x4d.dtype, device=x4d.device)
+        with torch.cuda.device(x4d.device):
+            _cabi.im2col_tokens(x4d.contiguous(), k, stride, pad, out)
+        return out
+    xp = F.pad(x4d, (0, 0, pad, pad, pad, pad))
+    return torch.cat([xp[:, ky:ky + stride * (Ho - 1) + 1:stride, kx:kx + stride * (Wo - 1) + 1:stride, :]
+                      for ky in range(k) for kx in range(k)], dim=-1).reshape(B, Ho * Wo, -1)
+
+
 MSDA_ENCODER = os.environ.get("CODETR_MSDA_ENC", "1") != "0"      # A/B switch: 0 = general fused kernel in the encoder
 MSDA_HALO = int(os.environ.get("CODETR_MSDA_HALO", "4"))          # staged offset range, pixels of the sampled level
 

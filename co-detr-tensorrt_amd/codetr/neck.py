@@ -96,9 +96,7 @@ class ChannelMapper(nn.Module):
             # patches gathered in token layout, K ordered (ky, kx, c): nine strided slices of whole C-vectors, one cat
             # (F.unfold's (c, ky, kx) order needs an NCHW round trip and an element-granular transpose: 85 us vs ~20)
             Ho, Wo = (hw[0] + 1) // 2, (hw[1] + 1) // 2
-            xp = F.pad(t.view(B, hw[0], hw[1], -1), (0, 0, 1, 1, 1, 1))
-            cols = torch.cat([xp[:, ky:ky + 2 * Ho - 1:2, kx:kx + 2 * Wo - 1:2, :] for ky in range(3) for kx in range(3)],
-                             dim=-1).view(B, Ho * Wo, -1)
+            cols = hip_ops.im2col_tokens(t.view(B, hw[0], hw[1], -1), 3, 2, 1)
             y = hip_ops.linear(cols, self._extra_weight_kkc(conv.conv.weight), None)
             hip_ops.groupnorm_tokens_into(y, conv.gn.weight, conv.gn.bias, conv.groups, conv.gn.eps, flat, start)
         return flat, shapes

@@ -60,9 +60,52 @@ __global__ __launch_bounds__(256) void patch_im2col_k4_kernel(const unsigned sho
   }
 }
 
+// k x k / stride s / zero padding p patches of a TOKEN-major map [B, H, W, C] -> rows [B * Ho * Wo, k*k*C] with the K
+// axis ordered (ky, kx, c): whole C-vectors move as 16-byte pieces (the neck's extra 3x3 / stride-2 level as a GEMM).
+__global__ __launch_bounds__(256) void im2col_tokens_kernel(const unsigned short* __restrict__ x,
+                                                            unsigned short* __restrict__ out, int H, int W, int C8,
+                                                            int Ho, int Wo, int k, int stride, int pad,
+                                                            long total_pieces) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_pieces; i += (long)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    long r = i / C8;
+    const int tap = (int)(r % (k * k));
+    r /= (k * k);
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long b = r / Ho;
+    const int ky = tap / k, kx = tap - ky * k;
+    const int y = oy * stride + ky - pad, xx = ox * stride + kx - pad;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (y >= 0 && y < H && xx >= 0 && xx < W)
+      v = *reinterpret_cast<const u32x4*>(x + (((b * H + y) * (long)W + xx) * C8 + c8) * 8);
+    *reinterpret_cast<u32x4*>(out + i * 8) = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int codetr_im2col_tokens_b16(void* stream, const void* x_dev, int64_t B, int64_t H, int64_t W, int64_t C, int k,
+                             int stride, int pad, void* out_dev) {
+  if (!x_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0)
+    return CODETR_E_BADARG;
+  if (C % 8 != 0) return CODETR_E_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(out_dev)) & 15) return CODETR_E_BADARG;
+  const int64_t Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return CODETR_E_BADARG;
+  if (H > 0x7fffffffLL || W > 0x7fffffffLL || C > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  const int64_t pieces = B * Ho * Wo * k * k * (C / 8);
+  int64_t blocks = (pieces + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(im2col_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(x_dev), static_cast<unsigned short*>(out_dev), (int)H, (int)W,
+                     (int)(C / 8), (int)Ho, (int)Wo, k, stride, pad, (long)pieces);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
 
 int codetr_patch_im2col_b16(void* stream, const void* x_dev, int64_t B, int C, int64_t H, int64_t W, int k, int kpad,
                             void* out_dev) {

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 27
+#define CODETR_HIP_ABI_VERSION 28
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -154,6 +154,15 @@ int codetr_msda_encoder_forward_bf16(void *stream, const void *value_dev, const 
  * ------------------------------------------------------------------------------------------ */
 int codetr_patch_im2col_b16(void *stream, const void *x_dev, int64_t B, int C, int64_t H, int64_t W, int k, int kpad,
                             void *out_dev);
+
+/* k x k / stride / zero-padding patches of a token-major map, for convolutions run as GEMMs on token-major data
+ * (the neck's extra level: Conv2d(1536, 256, 3, stride 2, padding 1) of mmdet's ChannelMapper, built at
+ * codetr/codetr.py:53-54 from configs lsj:40-47):
+ *   out[(b, oy, ox)][(ky, kx, c)] = x[b, oy*stride + ky - pad, ox*stride + kx - pad, c]   (0 outside the map)
+ *   x_dev [B, H, W, C] 16-bit elements, C % 8 == 0;  out_dev [B*Ho*Wo, k*k*C], Ho = (H + 2 pad - k) / stride + 1.
+ * The GEMM weight is conv.weight permuted to [C_out, (ky, kx, c)]. */
+int codetr_im2col_tokens_b16(void *stream, const void *x_dev, int64_t B, int64_t H, int64_t W, int64_t C, int k,
+                             int stride, int pad, void *out_dev);
 
 /* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
  * Pure host function; lets tests assert that the model shape takes the tiled path. */

@@ -66,3 +66,20 @@ def test_large_m_takes_the_short_k_kernel():
     y = hip_ops.linear(x, w, b)
     ref = x.float() @ w.float().t() + b.float()
     assert (y.float() - ref).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("B,H,W,C,k,s,p", [(2, 40, 60, 64, 3, 2, 1), (1, 5, 7, 8, 3, 2, 1), (3, 9, 9, 16, 3, 1, 1),
+                                           (1, 8, 6, 24, 2, 2, 0)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_im2col_tokens_bit_exact(B, H, W, C, k, s, p, dtype):
+    """token-major k x k patches (the neck's extra 3x3 / stride-2 level) against F.unfold of the NCHW view"""
+    from codetr import hip_ops
+
+    g = torch.Generator(device="cpu").manual_seed(H * W + C)
+    x = torch.randn(B, H, W, C, generator=g).to(DEV).to(dtype)
+    cols = hip_ops.im2col_tokens(x, k, s, p)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    u = F.unfold(x.float().permute(0, 3, 1, 2), k, stride=s, padding=p)          # [B, C*k*k, Ho*Wo], (c, ky, kx)
+    want = u.view(B, C, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(B, Ho * Wo, k * k * C).to(dtype)
+    assert cols.shape == want.shape
+    assert torch.equal(cols.view(torch.int16), want.view(torch.int16))
