@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -45,6 +45,8 @@ SIGNATURES = {
     "codetr_linear_xadd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_linear_xadd_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_im2col_tokens_b16": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "codetr_topk_f16": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "codetr_topk_bf16": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
@@ -90,7 +92,7 @@ _lib = None
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
-         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0}
+         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0}
 
 
 def load():
@@ -476,6 +478,22 @@ def im2col_tokens(x4d, k, stride, pad, out):
                                       out.data_ptr())
     check(rc, "codetr_im2col_tokens_b16")
     return out
+
+
+def topk_supported(x2d, k) -> bool:
+    return (x2d.dtype in (torch.float16, torch.bfloat16) and x2d.dim() == 2 and x2d.is_contiguous()
+            and 0 < k <= 1024 and k <= x2d.shape[1] < (1 << 24))
+
+
+def topk(x2d, k, values, indices):
+    """x2d [rows, n] f16 / bf16 -> values [rows, k] (or None), indices [rows, k] int64; sorted descending, ties by
+    ascending index, NaN first"""
+    lib = load()
+    CALLS["topk"] += 1
+    fn = lib.codetr_topk_bf16 if x2d.dtype == torch.bfloat16 else lib.codetr_topk_f16
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), x2d.shape[0], x2d.shape[1], k,
+            values.data_ptr() if values is not None else None, indices.data_ptr())
+    check(rc, "codetr_topk")
 
 
 def patch_im2col(x, k, kpad, out):

@@ -153,12 +153,12 @@ class CoDINOHead(nn.Module):
             capture.update(final_state=state, final_refs_unact=refs, outputs_classes=cls, outputs_coords=coords)
         B = coords.shape[0]
         if self.use_sigmoid:
-            scores, idx = torch.topk(cls.sigmoid().view(B, -1), self.max_per_img, dim=-1)
+            scores, idx = hip_ops.topk(cls.sigmoid().view(B, -1), self.max_per_img)
             labels = idx % self.num_classes
             q = idx // self.num_classes
         else:
             s, labels_all = F.softmax(cls, dim=-1)[..., :-1].max(-1)
-            scores, q = torch.topk(s, self.max_per_img, dim=-1)
+            scores, q = hip_ops.topk(s, self.max_per_img)
             labels = torch.gather(labels_all, 1, q)
         boxes = bbox_cxcywh_to_xyxy(torch.gather(coords, 1, q.unsqueeze(-1).expand(-1, -1, 4)))
         key = (Wimg, Himg, boxes.dtype, str(boxes.device))

@@ -28,7 +28,9 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "patch_merge_layernorm(f16: Swin 2x2 gather + LayerNorm)",
           "msda_encoder(f16/bf16: LDS-staged gather for the encoder's self-attention)",
           "patch_embed(f16/bf16: 4x4 patch gather + GEMM)",
-          "mha_attention(f16/bf16: dense softmax attention, head_dim 32, <= 1024 keys)"}
+          "mha_attention(f16/bf16: dense softmax attention, head_dim 32, <= 1024 keys)",
+          "topk(f16/bf16 rows, k <= 1024: radix select + bitonic sort; opt-in, CODETR_TOPK=1)",
+          "im2col_tokens(16-bit token-major maps)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -518,6 +520,31 @@ def im2col_tokens(x4d, k, stride, pad):
     xp = F.pad(x4d, (0, 0, pad, pad, pad, pad))
     return torch.cat([xp[:, ky:ky + stride * (Ho - 1) + 1:stride, kx:kx + stride * (Wo - 1) + 1:stride, :]
                       for ky in range(k) for kx in range(k)], dim=-1).reshape(B, Ho * Wo, -1)
+
+
+# Native top-k is opt-in (CODETR_TOPK=1): one workgroup per row walks the row six times, which at the model's sizes
+# (1 x 204 600 / 1 x 72 000 per image) is slower than torch.topk's multi-block rocPRIM chain: +0.65 ms per single-image
+# forward, +0.06 ms per image at 8 images.  Kept (and tested) as the deterministic-tie-order alternative.
+TOPK_NATIVE = os.environ.get("CODETR_TOPK", "0") == "1"
+
+
+def topk(x, k, want_values=True):
+    """torch.topk(x, k, dim=-1) for the head's two selections (reference transformer.py:560-561, co_dino_head.py:183):
+    (values, indices), sorted descending; ties by ascending index and NaN first on the native path (f16 / bf16 rows,
+    k <= 1024), torch.topk otherwise (fp32 parity runs)."""
+    _gpu(x, "topk")
+    x2 = x.reshape(-1, x.shape[-1])
+    if TOPK_NATIVE and not torch.is_grad_enabled():
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        if _cabi.topk_supported(x2, k):
+            idx = torch.empty((x2.shape[0], k), dtype=torch.int64, device=x.device)
+            val = torch.empty((x2.shape[0], k), dtype=x.dtype, device=x.device) if want_values else None
+            with torch.cuda.device(x.device):
+                _cabi.topk(x2, k, val, idx)
+            shape = (*x.shape[:-1], k)
+            return (val.view(shape) if val is not None else None), idx.view(shape)
+    v, i = torch.topk(x, k, dim=-1)
+    return v, i
 
 
 MSDA_ENCODER = os.environ.get("CODETR_MSDA_ENC", "1") != "0"      # A/B switch: 0 = general fused kernel in the encoder

@@ -407,7 +407,7 @@ class CoDinoTransformer(nn.Module):
         cls_head = cls_branches[last]
         enc_cls = hip_ops.linear(out_mem, cls_head.weight, cls_head.bias)
         if forced_topk_indices is None:
-            topk = torch.topk(hip_ops.row_max(enc_cls), self.two_stage_num_proposals, dim=1)[1]
+            topk = hip_ops.topk(hip_ops.row_max(enc_cls), self.two_stage_num_proposals, want_values=False)[1]
         else:
             topk = forced_topk_indices
         gidx = topk.unsqueeze(-1)

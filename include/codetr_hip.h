@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 28
+#define CODETR_HIP_ABI_VERSION 29
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -163,6 +163,18 @@ int codetr_patch_im2col_b16(void *stream, const void *x_dev, int64_t B, int C, i
  * The GEMM weight is conv.weight permuted to [C_out, (ky, kx, c)]. */
 int codetr_im2col_tokens_b16(void *stream, const void *x_dev, int64_t B, int64_t H, int64_t W, int64_t C, int k,
                              int stride, int pad, void *out_dev);
+
+/* Row-wise top-k of 16-bit floats: the two selections of the detection head -- the two-stage proposals
+ * (torch.topk(enc_outputs_class.max(-1)[0], 900, dim=1), reference codetr/transformer.py:560-561) and the final
+ * detections (cls_score.view(B, -1).topk(300), reference codetr/co_dino_head.py:183-186).
+ *   x_dev       [rows, n]  f16 / bf16, contiguous
+ *   values_dev  [rows, k]  same type, or NULL;   indices_dev [rows, k] int64
+ * Sorted: descending value, ties by ascending index, NaN first (torch's NaN rule; torch leaves the tie order open).
+ * k <= 1024, k <= n < 2^24: CODETR_E_UNSUPPORTED otherwise. */
+int codetr_topk_f16(void *stream, const void *x_dev, int64_t rows, int64_t n, int k, void *values_dev,
+                    int64_t *indices_dev);
+int codetr_topk_bf16(void *stream, const void *x_dev, int64_t rows, int64_t n, int k, void *values_dev,
+                     int64_t *indices_dev);
 
 /* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
  * Pure host function; lets tests assert that the model shape takes the tiled path. */
