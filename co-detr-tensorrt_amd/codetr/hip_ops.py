@@ -522,9 +522,9 @@ def im2col_tokens(x4d, k, stride, pad):
                       for ky in range(k) for kx in range(k)], dim=-1).reshape(B, Ho * Wo, -1)
 
 
-# Native top-k is opt-in (CODETR_TOPK=1): one workgroup per row walks the row six times, which at the model's sizes
-# (1 x 204 600 / 1 x 72 000 per image) is slower than torch.topk's multi-block rocPRIM chain: +0.65 ms per single-image
-# forward, +0.06 ms per image at 8 images.  Kept (and tested) as the deterministic-tie-order alternative.
+# Native top-k is opt-in (CODETR_TOPK=1): one workgroup per row (four sweeps of the row from L2 + a bitonic sort); at the
+# model's sizes (1 x 204 600 / 1 x 72 000 per image) it is level with torch.topk's multi-block rocPRIM chain at 8 images
+# and +0.1 ms per single-image forward.  Kept (and tested) as the deterministic-tie-order alternative.
 TOPK_NATIVE = os.environ.get("CODETR_TOPK", "0") == "1"
 
 

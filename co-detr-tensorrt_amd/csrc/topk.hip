@@ -6,8 +6,13 @@
 // Order: descending value, ties by ascending index, NaN first (torch.topk's NaN rule; its tie order is unspecified).
 // Every element gets a unique 40-bit composite  C = key16 << 24 | (2^24 - 1 - index), key16 = the order-preserving
 // integer image of the 16-bit float (NaN -> 0xFFFF): the k largest composites ARE the answer, there is no tie to
-// break.  MSD radix select over the 5 bytes of C (256-bin LDS histograms, wave-aggregated atomics because scores
-// cluster in a few bins), compaction of the k winners, bitonic sort of <= 1024 composites in LDS.
+// break.
+//   * rows of up to 204 800 elements (the model's sizes): every thread owns a contiguous share of the row and sweeps
+//     it four times with 16-byte loads (the row stays in L2): two 256-bin histogram rounds give the 16-bit threshold
+//     value (run-length flushing: scores cluster in a few bins), a block scan over (greater, tied) counts places the
+//     winners -- ties in index order -- without atomics, a bitonic sort of the <= 1024 composites orders them.
+//   * longer rows: MSD radix select over the 5 bytes of C with one sweep of the row per byte (256-bin LDS histograms,
+//     wave-aggregated atomics), compaction of the k winners, the same sort.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,6 +46,59 @@ __device__ __forceinline__ void wave_hist_add(unsigned* hist, unsigned bin, bool
     if (lane == (unsigned)leader) atomicAdd(&hist[b], (unsigned)__builtin_popcountll(same));
     todo &= ~same;
   }
+}
+
+// block-wide exclusive scan of one value per thread (1024 threads = 16 waves): shuffle scan inside each wave, the 16
+// wave totals through `scratch` (>= 16 u32), two barriers
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* scratch, unsigned* total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) scratch[wave] = incl;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; ++w) {
+    const unsigned t = scratch[w];
+    before += w < wave ? t : 0u;
+    all += t;
+  }
+  if (total) *total = all;
+  __syncthreads();
+  return before + incl - v;
+}
+
+// bitonic sort of buf[0 .. 1023], descending, 1024 threads.  Pairs at distance <= 64 stay inside the 128-element
+// segment of the thread's own wave (LDS operations of a wave retire in order), so only the strides >= 128 need a
+// workgroup barrier: 6 barriers instead of 55.
+__device__ __forceinline__ void bitonic_sort_desc(unsigned long long* buf) {
+  const int tid = threadIdx.x;
+  for (int size = 2; size <= kMaxK; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (tid < kMaxK / 2) {
+        const int lo = 2 * tid - (tid & (stride - 1));  // index of the lower element of this thread's pair
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long a = buf[lo], b = buf[hi];
+        if ((a < b) == desc) {
+          buf[lo] = b;
+          buf[hi] = a;
+        }
+      }
+      if (stride > 64 || (stride == 1 && size >= 128)) {
+        __syncthreads();  // the next step crosses wave segments (or this was the last wave-local step before one)
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  }
+  __syncthreads();
 }
 
 template <bool BF>
@@ -100,22 +158,131 @@ __global__ __launch_bounds__(kThreads) void topk_kernel(const unsigned short* __
   __syncthreads();
   for (int i = (int)count_s + tid; i < kMaxK; i += kThreads) buf[i] = 0;  // pad (count_s == k)
   __syncthreads();
-  // ---- bitonic sort, descending, 1024 composites, one element pair per thread and step ----
-  for (int size = 2; size <= kMaxK; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      if (tid < kMaxK / 2) {
-        const int lo = 2 * tid - (tid & (stride - 1));  // index of the lower element of this thread's pair
-        const int hi = lo + stride;
-        const bool desc = (lo & size) == 0;
-        const unsigned long long a = buf[lo], b = buf[hi];
-        if ((a < b) == desc) {
-          buf[lo] = b;
-          buf[hi] = a;
+  bitonic_sort_desc(buf);
+  if (tid < k) {
+    const unsigned long long c = buf[tid];
+    const unsigned idx = 0xffffffu - (unsigned)(c & 0xffffffu);
+    indices[(size_t)blockIdx.x * k + tid] = (int64_t)idx;
+    if (values) values[(size_t)blockIdx.x * k + tid] = row[idx];
+  }
+}
+
+constexpr int kRegVecs = 25;  // 16-byte vectors per thread held in registers: rows up to 1024 * 25 * 8 elements
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned short elem16(const u32x4& v, int e) {
+  const unsigned w = v[e >> 1];
+  return (unsigned short)((e & 1) ? (w >> 16) : (w & 0xffffu));
+}
+
+// Rows of up to kRegVecs * 8 * 1024 elements: thread t owns the contiguous share [t * 8 nvec, (t + 1) * 8 nvec) and
+// sweeps it four times with 16-byte loads, five in flight (the row stays in L2): two histogram rounds, the count
+// round, the placement round.
+template <bool BF>
+__global__ __launch_bounds__(kThreads) void topk_reg_kernel(const unsigned short* __restrict__ x,
+                                                            unsigned short* __restrict__ values,
+                                                            int64_t* __restrict__ indices, int n, int k, int nvec) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sel_s[2];
+  __shared__ unsigned long long buf[kMaxK];
+  unsigned* scratch = reinterpret_cast<unsigned*>(buf);  // the scans finish before buf is filled
+  const int tid = threadIdx.x;
+  const unsigned short* row = x + (size_t)blockIdx.x * n;
+  const int base = tid * nvec * 8;
+
+  constexpr int kBatch = 5;
+  // visit(f): f(key, index) for every element of this thread's share, in index order; keys of positions past the row
+  // are 0 (below every real key, which is >= 0x0400)
+  auto sweep = [&](auto&& f) {
+    for (int j0 = 0; j0 < nvec; j0 += kBatch) {
+      u32x4 v[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        const int i0 = base + (j0 + u) * 8;
+        if (j0 + u < nvec && i0 < n) {
+          if (i0 + 8 <= n) {
+            v[u] = *reinterpret_cast<const u32x4*>(row + i0);
+          } else {
+            for (int e = 0; e < 8; ++e)
+              if (i0 + e < n) v[u][e >> 1] |= (unsigned)row[i0 + e] << (16 * (e & 1));
+          }
         }
       }
-      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        if (j0 + u < nvec) {
+          const int i0 = base + (j0 + u) * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f(i0 + e < n ? key16<BF>(elem16(v[u], e)) : 0u, (unsigned)(i0 + e));
+        }
+      }
     }
+  };
+
+  // ---- threshold value: two 8-bit histogram rounds over the 16-bit keys ----
+  unsigned prefix = 0, need = (unsigned)k;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    unsigned cur = 0, cnt = 0;  // run-length: one LDS atomic per run of equal bins (scores cluster in a few bins)
+    sweep([&](unsigned key, unsigned) {
+      const bool in = key != 0u && (pass == 0 || (key >> 8) == prefix);
+      const unsigned bin = pass == 0 ? key >> 8 : key & 0xffu;
+      if (in) {
+        if (cnt && bin == cur) {
+          ++cnt;
+        } else {
+          if (cnt) atomicAdd(&hist[cur], cnt);
+          cur = bin;
+          cnt = 1;
+        }
+      }
+    });
+    if (cnt) atomicAdd(&hist[cur], cnt);
+    __syncthreads();
+    if (tid == 0) {
+      unsigned acc = 0;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= need) break;
+        acc += hist[b];
+      }
+      sel_s[0] = (prefix << 8) | (unsigned)b;
+      sel_s[1] = need - acc;
+    }
+    __syncthreads();
+    prefix = sel_s[0];
+    need = sel_s[1];
+    __syncthreads();
   }
+  const unsigned T = prefix;          // 16-bit key of the k-th largest element
+  const unsigned ties_wanted = need;  // how many elements equal to T belong to the result (lowest indices first)
+  const unsigned n_greater = (unsigned)k - ties_wanted;
+
+  // ---- placement without atomics: ascending index = (thread, position inside the thread's share) ----
+  unsigned my_gt = 0, my_tie = 0;
+  sweep([&](unsigned key, unsigned) {
+    my_gt += key > T ? 1u : 0u;
+    my_tie += key == T ? 1u : 0u;
+  });
+  unsigned gt_slot = block_exclusive_scan(my_gt, scratch, nullptr);
+  unsigned tie_seen = block_exclusive_scan(my_tie, scratch, nullptr);
+  for (int i = tid; i < kMaxK; i += kThreads) buf[i] = 0;  // pad
+  __syncthreads();
+  sweep([&](unsigned key, unsigned idx) {
+    const unsigned long long c = ((unsigned long long)key << 24) | (unsigned long long)(0xffffffu - idx);
+    if (key > T) {
+      buf[gt_slot++] = c;
+    } else if (key == T) {
+      if (tie_seen < ties_wanted) buf[n_greater + tie_seen] = c;
+      ++tie_seen;
+    }
+  });
+  __syncthreads();
+  bitonic_sort_desc(buf);
   if (tid < k) {
     const unsigned long long c = buf[tid];
     const unsigned idx = 0xffffffu - (unsigned)(c & 0xffffffu);
@@ -129,8 +296,15 @@ int topk_entry(void* stream, const void* x, int64_t rows, int64_t n, int k, void
   if (!x || !indices || rows <= 0 || n <= 0 || k <= 0) return CODETR_E_BADARG;
   if (k > kMaxK || k > n || n >= (1 << 24)) return CODETR_E_UNSUPPORTED;
   if (rows > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  hipLaunchKernelGGL(topk_kernel<BF>, dim3((unsigned)rows), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const unsigned short*>(x), static_cast<unsigned short*>(values), indices, (int)n, k);
+  const int nvec = (int)((n + kThreads * 8 - 1) / (kThreads * 8));  // 16-byte vectors per thread
+  if (nvec <= kRegVecs && (n % 8 == 0) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    hipLaunchKernelGGL(topk_reg_kernel<BF>, dim3((unsigned)rows), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned short*>(x), static_cast<unsigned short*>(values), indices, (int)n, k,
+                       nvec);
+  } else {
+    hipLaunchKernelGGL(topk_kernel<BF>, dim3((unsigned)rows), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned short*>(x), static_cast<unsigned short*>(values), indices, (int)n, k);
+  }
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
