@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -45,6 +45,9 @@ SIGNATURES = {
     "codetr_linear_xadd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_linear_xadd_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_im2col_tokens_b16": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "codetr_topk_chunks": (_i64, [_i64, _i32, _i64, _vp]),
+    "codetr_topk_chunked_f16": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64]),
+    "codetr_topk_chunked_bf16": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64]),
     "codetr_topk_f16": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "codetr_topk_bf16": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
@@ -487,12 +490,22 @@ def topk_supported(x2d, k) -> bool:
 
 def topk(x2d, k, values, indices):
     """x2d [rows, n] f16 / bf16 -> values [rows, k] (or None), indices [rows, k] int64; sorted descending, ties by
-    ascending index, NaN first"""
+    ascending index, NaN first.  Long rows are cut over several workgroups (two passes, same result)."""
     lib = load()
     CALLS["topk"] += 1
-    fn = lib.codetr_topk_bf16 if x2d.dtype == torch.bfloat16 else lib.codetr_topk_f16
-    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), x2d.shape[0], x2d.shape[1], k,
-            values.data_ptr() if values is not None else None, indices.data_ptr())
+    rows, n = x2d.shape
+    bf = x2d.dtype == torch.bfloat16
+    ws_bytes = ctypes.c_int64(0)
+    chunks = lib.codetr_topk_chunks(n, k, rows, ctypes.cast(ctypes.pointer(ws_bytes), ctypes.c_void_p))
+    vp = values.data_ptr() if values is not None else None
+    if chunks > 1 and x2d.data_ptr() % 16 == 0:
+        ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=x2d.device)
+        fn = lib.codetr_topk_chunked_bf16 if bf else lib.codetr_topk_chunked_f16
+        rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), rows, n, k, chunks, vp, indices.data_ptr(),
+                ws.data_ptr(), ws_bytes.value)
+    else:
+        fn = lib.codetr_topk_bf16 if bf else lib.codetr_topk_f16
+        rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), rows, n, k, vp, indices.data_ptr())
     check(rc, "codetr_topk")
 
 

@@ -29,7 +29,7 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "msda_encoder(f16/bf16: LDS-staged gather for the encoder's self-attention)",
           "patch_embed(f16/bf16: 4x4 patch gather + GEMM)",
           "mha_attention(f16/bf16: dense softmax attention, head_dim 32, <= 1024 keys)",
-          "topk(f16/bf16 rows, k <= 1024: radix select + bitonic sort; opt-in, CODETR_TOPK=1)",
+          "topk(f16/bf16 rows, k <= 1024: radix select + bitonic sort)",
           "im2col_tokens(16-bit token-major maps)"}
 
 
@@ -522,10 +522,9 @@ def im2col_tokens(x4d, k, stride, pad):
                       for ky in range(k) for kx in range(k)], dim=-1).reshape(B, Ho * Wo, -1)
 
 
-# Native top-k is opt-in (CODETR_TOPK=1): one workgroup per row (four sweeps of the row from L2 + a bitonic sort); at the
-# model's sizes (1 x 204 600 / 1 x 72 000 per image) it is level with torch.topk's multi-block rocPRIM chain at 8 images
-# and +0.1 ms per single-image forward.  Kept (and tested) as the deterministic-tie-order alternative.
-TOPK_NATIVE = os.environ.get("CODETR_TOPK", "0") == "1"
+# A/B switch: 0 = torch.topk.  (Long rows are cut over up to 32 workgroups, two passes; level with torch.topk's multi-
+# block rocPRIM chain at the model's sizes, 1 x 204 600 and 1 x 72 000 per image, and deterministic in its tie order.)
+TOPK_NATIVE = os.environ.get("CODETR_TOPK", "1") != "0"
 
 
 def topk(x, k, want_values=True):

@@ -182,7 +182,8 @@ __device__ __forceinline__ unsigned short elem16(const u32x4& v, int e) {
 template <bool BF>
 __global__ __launch_bounds__(kThreads) void topk_reg_kernel(const unsigned short* __restrict__ x,
                                                             unsigned short* __restrict__ values,
-                                                            int64_t* __restrict__ indices, int n, int k, int nvec) {
+                                                            int64_t* __restrict__ indices, int n, int k, int nvec,
+                                                            int chunks, const int64_t* __restrict__ index_map) {
   __shared__ unsigned hist[256];
   __shared__ unsigned sel_s[2];
   __shared__ unsigned long long buf[kMaxK];
@@ -286,27 +287,53 @@ __global__ __launch_bounds__(kThreads) void topk_reg_kernel(const unsigned short
   if (tid < k) {
     const unsigned long long c = buf[tid];
     const unsigned idx = 0xffffffu - (unsigned)(c & 0xffffffu);
-    indices[(size_t)blockIdx.x * k + tid] = (int64_t)idx;
+    // chunks > 1: this "row" is chunk (blockIdx.x % chunks) of a longer row -> report the index inside that row;
+    // index_map: the elements are candidates of an earlier selection -> report the index each one came from
+    int64_t o = (int64_t)idx + (int64_t)(blockIdx.x % (unsigned)chunks) * n;
+    if (index_map) o = index_map[(size_t)blockIdx.x * n + idx];
+    indices[(size_t)blockIdx.x * k + tid] = o;
     if (values) values[(size_t)blockIdx.x * k + tid] = row[idx];
   }
 }
 
 template <bool BF>
-int topk_entry(void* stream, const void* x, int64_t rows, int64_t n, int k, void* values, int64_t* indices) {
-  if (!x || !indices || rows <= 0 || n <= 0 || k <= 0) return CODETR_E_BADARG;
+int topk_entry(void* stream, const void* x, int64_t rows, int64_t n, int k, void* values, int64_t* indices,
+               int chunks = 1, const int64_t* index_map = nullptr) {
+  if (!x || !indices || rows <= 0 || n <= 0 || k <= 0 || chunks <= 0) return CODETR_E_BADARG;
   if (k > kMaxK || k > n || n >= (1 << 24)) return CODETR_E_UNSUPPORTED;
   if (rows > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   const int nvec = (int)((n + kThreads * 8 - 1) / (kThreads * 8));  // 16-byte vectors per thread
   if (nvec <= kRegVecs && (n % 8 == 0) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     hipLaunchKernelGGL(topk_reg_kernel<BF>, dim3((unsigned)rows), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                        static_cast<const unsigned short*>(x), static_cast<unsigned short*>(values), indices, (int)n, k,
-                       nvec);
+                       nvec, chunks, index_map);
   } else {
+    if (chunks != 1 || index_map) return CODETR_E_UNSUPPORTED;
     hipLaunchKernelGGL(topk_kernel<BF>, dim3((unsigned)rows), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                        static_cast<const unsigned short*>(x), static_cast<unsigned short*>(values), indices, (int)n, k);
   }
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+// Long rows over several workgroups: pass 1 selects the top k of each of `chunks` equal pieces of every row (rows *
+// chunks workgroups), pass 2 selects the top k of the chunks * k candidates and maps them back.  Candidates of one row
+// are laid out chunk-major and sorted inside a chunk, so position order among equal values is index order: the result
+// is the same stable order as the one-pass kernel's.  Workspace: rows * chunks * k * (2 + 8) bytes, caller-owned.
+template <bool BF>
+int topk_two_pass(void* stream, const void* x, int64_t rows, int64_t n, int k, int chunks, void* values,
+                  int64_t* indices, void* workspace, int64_t workspace_bytes) {
+  if (!workspace || chunks < 2 || n % chunks != 0) return CODETR_E_BADARG;
+  const int k1 = (k + 7) & ~7;  // candidates kept per piece: k rounded up so that the candidate rows stay 16-byte multiples
+  const int64_t cn = n / chunks, cand = (int64_t)chunks * k1;
+  if (cn % 8 != 0 || cn < k1 || k1 > kMaxK || workspace_bytes < rows * cand * 10 ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return CODETR_E_BADARG;
+  int64_t* cand_idx = static_cast<int64_t*>(workspace);
+  unsigned short* cand_val = reinterpret_cast<unsigned short*>(cand_idx + rows * cand);
+  int rc = topk_entry<BF>(stream, x, rows * chunks, cn, k1, cand_val, cand_idx, chunks, nullptr);
+  if (rc) return rc;
+  return topk_entry<BF>(stream, cand_val, rows, cand, k, values, indices, 1, cand_idx);
 }
 
 }  // namespace
@@ -321,6 +348,33 @@ int codetr_topk_f16(void* stream, const void* x_dev, int64_t rows, int64_t n, in
 int codetr_topk_bf16(void* stream, const void* x_dev, int64_t rows, int64_t n, int k, void* values_dev,
                      int64_t* indices_dev) {
   return topk_entry<true>(stream, x_dev, rows, n, k, values_dev, indices_dev);
+}
+
+int64_t codetr_topk_chunks(int64_t n, int k, int64_t rows, int64_t* workspace_bytes) {
+  // how many pieces codetr_topk_chunked_* should cut a row into (1 = call codetr_topk_*): the largest divisor <= 32 of
+  // n whose pieces are 16-byte multiples of at least k elements; only worth it for rows beyond one sweep's comfort
+  if (workspace_bytes) *workspace_bytes = 0;
+  const int k1 = (k + 7) & ~7;
+  if (n < 32768 || k <= 0 || k1 > kMaxK) return 1;
+  for (int c = 32; c >= 2; --c) {
+    if (n % c == 0 && (n / c) % 8 == 0 && n / c >= k1) {
+      if (workspace_bytes) *workspace_bytes = rows * c * k1 * 10;
+      return c;
+    }
+  }
+  return 1;
+}
+
+int codetr_topk_chunked_f16(void* stream, const void* x_dev, int64_t rows, int64_t n, int k, int chunks,
+                            void* values_dev, int64_t* indices_dev, void* workspace_dev, int64_t workspace_bytes) {
+  return topk_two_pass<false>(stream, x_dev, rows, n, k, chunks, values_dev, indices_dev, workspace_dev,
+                              workspace_bytes);
+}
+
+int codetr_topk_chunked_bf16(void* stream, const void* x_dev, int64_t rows, int64_t n, int k, int chunks,
+                             void* values_dev, int64_t* indices_dev, void* workspace_dev, int64_t workspace_bytes) {
+  return topk_two_pass<true>(stream, x_dev, rows, n, k, chunks, values_dev, indices_dev, workspace_dev,
+                             workspace_bytes);
 }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 29
+#define CODETR_HIP_ABI_VERSION 30
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -175,6 +175,17 @@ int codetr_topk_f16(void *stream, const void *x_dev, int64_t rows, int64_t n, in
                     int64_t *indices_dev);
 int codetr_topk_bf16(void *stream, const void *x_dev, int64_t rows, int64_t n, int k, void *values_dev,
                      int64_t *indices_dev);
+
+/* The same selection with a long row cut over several workgroups (the 204 600-element proposal row of one image):
+ *   codetr_topk_chunks         how many equal pieces to cut a row into (1: call codetr_topk_*) and the workspace needed
+ *   codetr_topk_chunked_*      pass 1: top k of every piece (rows * chunks workgroups); pass 2: top k of the
+ *                              chunks * k candidates, mapped back to row indices.  Same result, same stable order.
+ * Caller-owned workspace (16-byte aligned), no allocation, hipGraph-capturable. */
+int64_t codetr_topk_chunks(int64_t n, int k, int64_t rows, int64_t *workspace_bytes);
+int codetr_topk_chunked_f16(void *stream, const void *x_dev, int64_t rows, int64_t n, int k, int chunks,
+                            void *values_dev, int64_t *indices_dev, void *workspace_dev, int64_t workspace_bytes);
+int codetr_topk_chunked_bf16(void *stream, const void *x_dev, int64_t rows, int64_t n, int k, int chunks,
+                             void *values_dev, int64_t *indices_dev, void *workspace_dev, int64_t workspace_bytes);
 
 /* Name of the kernel variant the arguments above would dispatch to ("tiled_d32x8", "scalar", ...).
  * Pure host function; lets tests assert that the model shape takes the tiled path. */
