@@ -43,7 +43,7 @@ def test_full_size_contract_determinism_and_image_independence(swin_l):
         singles = [swin_l(img[i:i + 1], mask[i:i + 1]) for i in range(2)]
     for k in ("linear", "layernorm", "window_attention", "msda_fused", "ffn_fused", "groupnorm_tokens",
               "sine_pos_tokens", "mask_pyramid", "encoder_geometry", "query_sine_embed", "patch_merge_layernorm",
-              "msda_encoder"):
+              "msda_encoder", "patch_im2col", "mha_attention", "topk"):
         assert _cabi.CALLS[k] > before[k], f"{k} kernels did not run"
     # contract
     assert b2.shape == (2, 300, 4) and s2.shape == (2, 300) and l2.shape == (2, 300)
