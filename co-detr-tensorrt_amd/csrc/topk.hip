@@ -244,15 +244,28 @@ __global__ __launch_bounds__(kThreads) void topk_reg_kernel(const unsigned short
     });
     if (cnt) atomicAdd(&hist[cur], cnt);
     __syncthreads();
-    if (tid == 0) {
-      unsigned acc = 0;
-      int b = 255;
-      for (; b > 0; --b) {
-        if (acc + hist[b] >= need) break;
-        acc += hist[b];
+    if (tid < 64) {
+      // threshold bin, searched by one wave: lane l owns bins 4l .. 4l+3, a suffix sum over the lanes finds the lane in
+      // which the count from the top crosses `need`, that lane walks its four bins
+      const unsigned h[4] = {hist[4 * tid], hist[4 * tid + 1], hist[4 * tid + 2], hist[4 * tid + 3]};
+      const unsigned own = h[0] + h[1] + h[2] + h[3];
+      unsigned suf = own;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = __shfl_down(suf, off, 64);
+        if (tid + off < 64) suf += up;
       }
-      sel_s[0] = (prefix << 8) | (unsigned)b;
-      sel_s[1] = need - acc;
+      const unsigned above = suf - own;  // elements in the bins of higher lanes
+      if (above < need && need <= above + own) {
+        unsigned acc = above;
+        int j = 3;
+        for (; j > 0; --j) {
+          if (acc + h[j] >= need) break;
+          acc += h[j];
+        }
+        sel_s[0] = (prefix << 8) | (unsigned)(4 * tid + j);
+        sel_s[1] = need - acc;
+      }
     }
     __syncthreads();
     prefix = sel_s[0];
