@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -42,6 +42,8 @@ SIGNATURES = {
                                                 _i32, _i32, _vp]),
     "codetr_mha_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
     "codetr_mha_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
+    "codetr_linear_ln_f16": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
+    "codetr_linear_ln_bf16": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
     "codetr_linear_xadd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_linear_xadd_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "codetr_im2col_tokens_b16": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
@@ -456,6 +458,20 @@ def linear_xadd_supported(M, N, K, dtype) -> bool:
     """mirror of the library's rule for codetr_linear_xadd_* (the X-stationary kernel's shapes)"""
     return (dtype in (torch.float16, torch.bfloat16) and K in (192, 256) and N % 8 == 0 and 128 <= N <= 1536
             and M >= 128 * 256 and os.environ.get("CODETR_GEMM_XS", "1") != "0")
+
+
+def linear_ln(x2d, gamma, beta, eps, w, bias, act, out2d) -> bool:
+    """out = act(LayerNorm(x) @ w.T + bias); False when the library declines the shape"""
+    lib = load()
+    fn = lib.codetr_linear_ln_bf16 if x2d.dtype == torch.bfloat16 else lib.codetr_linear_ln_f16
+    M, K = x2d.shape
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), w.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out2d.data_ptr(), M, w.shape[0], K, _ACT[act])
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "codetr_linear_ln")
+    CALLS["linear"] += 1
+    return True
 
 
 def linear_xadd(x2d, xadd2d, w, bias, out2d) -> bool:

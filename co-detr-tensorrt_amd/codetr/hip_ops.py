@@ -130,6 +130,47 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
     return y
 
 
+LN_GEMM = os.environ.get("CODETR_LN_GEMM", "1") != "0"   # A/B switch: 0 = LayerNorm as its own kernel in front of the GEMM
+
+
+def linear_ln_supported(x, norm_weight, weight):
+    """True when LayerNorm(x) @ weight.T runs as ONE kernel (the norm applied in the short-K GEMM's operand load)"""
+    return (LN_GEMM and x.is_cuda and norm_weight is not None and norm_weight.dtype == x.dtype and weight.dtype == x.dtype
+            and not torch.is_grad_enabled() and norm_weight.shape[0] == x.shape[-1]
+            and _cabi.linear_xadd_supported(x.numel() // max(x.shape[-1], 1), weight.shape[0], x.shape[-1], x.dtype))
+
+
+def linear_ln(x, norm_weight, norm_bias, eps, weight, bias=None, act=None):
+    """act(LayerNorm(x) @ weight.T + bias): Swin's norm1 -> qkv and norm2 -> fc1 (reference swin.py:345-386), where only
+    the GEMM reads the normalised rows.  Falls back to layer_norm + linear where the fused form does not apply."""
+    _gpu(x, "linear_ln")
+    if linear_ln_supported(x, norm_weight, weight):
+        K, N = x.shape[-1], weight.shape[0]
+        x2 = x.reshape(-1, K)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        out = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
+        ok = [False]
+
+        def launch():
+            ok[0] = _cabi.linear_ln(x2, norm_weight, norm_bias, eps, w, bias, act, out)
+
+        with torch.cuda.device(x.device):
+            if LINEAR_PROFILE is None:
+                launch()
+            else:
+                st = torch.cuda.current_stream(x.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                launch()
+                e1.record(st)
+                if ok[0]:
+                    LINEAR_PROFILE.append((e0, e1, 2.0 * x2.shape[0] * N * K, x2.shape[0], N, K))
+        if ok[0]:
+            return out.view(*x.shape[:-1], N)
+    return linear(layer_norm(x, norm_weight, norm_bias, eps), weight, bias, act=act)
+
+
 XADD = os.environ.get("CODETR_XADD", "1") != "0"   # A/B switch: 0 = `query + query_pos` as its own kernel / FFN output
 # Below this many rows the 256-tile GEMM on a stored `query + query_pos` wins over the X-stationary kernel with the add
 # folded in (measured: one 1920x1280 image, 204 600 rows, +0.09 ms per forward; four images -0.35 ms)

@@ -185,7 +185,11 @@ class ShiftWindowMSA(nn.Module):
         self.w_msa = WindowMSA(embed_dims, num_heads, to_2tuple(window_size), qkv_bias, qk_scale, attn_drop_rate,
                                proj_drop_rate)
 
-    def forward(self, query, hw_shape, identity=None):
+    def takes_norm(self, query, hw_shape):
+        """True when forward runs the fused window-attention path (the only one that accepts `pre_norm`)"""
+        return hip_ops.swin_window_attention_supported(query, self.w_msa.embed_dims, self.w_msa.num_heads, self.window_size)
+
+    def forward(self, query, hw_shape, identity=None, pre_norm=None):
         """query [B, H*W, C] (already normalised) -> attention branch output (+ `identity` if given).
         Padding to a multiple of the window is applied AFTER norm1: pad tokens are exact zeros, come
         out of qkv as the bias and take part in the softmax as ordinary keys (only the shift mask
@@ -199,7 +203,10 @@ class ShiftWindowMSA(nn.Module):
         if hip_ops.swin_window_attention_supported(query, C, m.num_heads, ws):
             # fused path: qkv GEMM on real tokens only, one kernel for everything between qkv and proj,
             # residual folded into the proj GEMM's epilogue
-            qkv = hip_ops.linear(query, m.qkv.weight, m.qkv.bias)
+            if pre_norm is not None:   # LayerNorm of the rows inside the qkv GEMM (SwinBlock.forward)
+                qkv = hip_ops.linear_ln(query, pre_norm[0], pre_norm[1], pre_norm[2], m.qkv.weight, m.qkv.bias)
+            else:
+                qkv = hip_ops.linear(query, m.qkv.weight, m.qkv.bias)
             o = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads, ws, sh)
             return hip_ops.linear(o, m.proj.weight, m.proj.bias, residual=identity)
         x = query.view(B, H, W, C)
@@ -235,9 +242,21 @@ class SwinBlock(nn.Module):
                        act_cfg=act_cfg, add_identity=True)
 
     def forward(self, x, hw_shape):
-        h = hip_ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.attn(h, hw_shape, identity=x)
-        h = hip_ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        n1, n2 = self.norm1, self.norm2
+        if (isinstance(n1, nn.LayerNorm) and self.attn.takes_norm(x, hw_shape)
+                and hip_ops.linear_ln_supported(x, n1.weight, self.attn.w_msa.qkv.weight)):
+            # norm1 folded into the qkv GEMM's operand load (only that GEMM reads the normalised rows)
+            x = self.attn(x, hw_shape, identity=x, pre_norm=(n1.weight, n1.bias, n1.eps))
+        else:
+            h = hip_ops.layer_norm(x, n1.weight, n1.bias, n1.eps)
+            x = self.attn(h, hw_shape, identity=x)
+        fc1, fc2 = self.ffn.layers[0][0], self.ffn.layers[1]
+        if (isinstance(n2, nn.LayerNorm) and self.ffn.add_identity
+                and hip_ops.linear_ln_supported(x, n2.weight, fc1.weight)):
+            # norm2 folded into fc1 (+ GELU); fc2 adds the identity as before
+            h = hip_ops.linear_ln(x, n2.weight, n2.bias, n2.eps, fc1.weight, fc1.bias, act=self.ffn.act)
+            return hip_ops.linear(h, fc2.weight, fc2.bias, residual=x)
+        h = hip_ops.layer_norm(x, n2.weight, n2.bias, n2.eps)
         return self.ffn(h, identity=x)
 
 

@@ -885,6 +885,8 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
 template <class T, int KS, int ACT, bool HAS_RES>
 __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __restrict__ X,
                                                         const unsigned short* __restrict__ X2,
+                                                        const unsigned short* __restrict__ LNG,
+                                                        const unsigned short* __restrict__ LNB, float ln_eps,
                                                         const unsigned short* __restrict__ W,
                                                         const unsigned short* __restrict__ bias,
                                                         const unsigned short* __restrict__ R,
@@ -940,6 +942,38 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
         const typename T::frag p = *reinterpret_cast<const typename T::frag*>(X2 + (size_t)m * K + ks * 32 + grp * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) xf[mt][ks][e] = (typename T::elem)((float)xf[mt][ks][e] + (float)p[e]);
+      }
+    }
+    // optional LayerNorm of the input rows (the whole row is in this wave: K values in the four lanes l15 + 16 g), fp32
+    // two-pass statistics, result rounded to T = the operand a separate LayerNorm kernel would have written; used
+    // where nothing else reads that normalised tensor (Swin's pre-norm blocks: norm1 -> qkv, norm2 -> fc1)
+    if (LNG) {
+      float sm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += (float)xf[mt][ks][e];
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mean = sm * (1.0f / K);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)xf[mt][ks][e] - mean;
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = rsqrtf(q * (1.0f / K) + ln_eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const typename T::frag gw = *reinterpret_cast<const typename T::frag*>(LNG + ks * 32 + grp * 8);
+        const typename T::frag gb = *reinterpret_cast<const typename T::frag*>(LNB + ks * 32 + grp * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          xf[mt][ks][e] = (typename T::elem)fmaf(((float)xf[mt][ks][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
       }
     }
   }
@@ -1075,17 +1109,20 @@ bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
 
 template <class T, int KS, int ACT>
 int launch_xs_res(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
-                  const void* mask, int M, int N, int hm_rows, int hm_hd, const void* X2 = nullptr) {
+                  const void* mask, int M, int N, int hm_rows, int hm_hd, const void* X2 = nullptr,
+                  const void* LNG = nullptr, const void* LNB = nullptr, float ln_eps = 0.f) {
   const dim3 grid((unsigned)((M + 127) / 128)), block(256);
   auto x = static_cast<const unsigned short*>(X);
   auto x2 = static_cast<const unsigned short*>(X2);
+  auto lg = static_cast<const unsigned short*>(LNG);
+  auto lb = static_cast<const unsigned short*>(LNB);
   auto w = static_cast<const unsigned short*>(W);
   auto b = static_cast<const unsigned short*>(bias);
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (R) hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true>), grid, block, 0, st, x, x2, w, b, r, y, mk, M, N, hm_rows, hm_hd);
-  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false>), grid, block, 0, st, x, x2, w, b, r, y, mk, M, N, hm_rows, hm_hd);
+  if (R) hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true>), grid, block, 0, st, x, x2, lg, lb, ln_eps, w, b, r, y, mk, M, N, hm_rows, hm_hd);
+  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false>), grid, block, 0, st, x, x2, lg, lb, ln_eps, w, b, r, y, mk, M, N, hm_rows, hm_hd);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -1153,9 +1190,44 @@ int launch_xadd(hipStream_t st, const void* X, const void* X2, const void* W, co
   return launch_xs_res<T, 8, 0>(st, X, W, bias, nullptr, Y, nullptr, (int)M, (int)N, 0, 0, X2);
 }
 
+// LayerNorm of the input rows folded into the X-stationary kernel (no residual / mask): only where that kernel applies
+template <class T>
+int launch_ln(hipStream_t st, const void* X, const void* G, const void* Bt, float eps, const void* W, const void* bias,
+              void* Y, int64_t M, int64_t N, int64_t K, int act) {
+  if (!X || !G || !Bt || !W || !Y || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return CODETR_E_BADARG;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if (!xs_applicable(M, N, K, 0) || K == 64 || (reinterpret_cast<uintptr_t>(Y) & 15) ||
+      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Bt) |
+        reinterpret_cast<uintptr_t>(W)) & 15))
+    return CODETR_E_UNSUPPORTED;
+#define CODETR_LN_CASE(KS, ACT) \
+  return launch_xs_res<T, KS, ACT>(st, X, W, bias, nullptr, Y, nullptr, (int)M, (int)N, 0, 0, nullptr, G, Bt, eps)
+  if (K == 192) {
+    if (act == 0) CODETR_LN_CASE(6, 0);
+    if (act == 1) CODETR_LN_CASE(6, 1);
+    CODETR_LN_CASE(6, 2);
+  }
+  if (act == 0) CODETR_LN_CASE(8, 0);
+  if (act == 1) CODETR_LN_CASE(8, 1);
+  CODETR_LN_CASE(8, 2);
+#undef CODETR_LN_CASE
+}
+
 }  // namespace
 
 extern "C" {
+
+int codetr_linear_ln_f16(void* stream, const void* x_dev, const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps,
+                         const void* w_dev, const void* bias_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act) {
+  return launch_ln<HalfT>(static_cast<hipStream_t>(stream), x_dev, ln_gamma_dev, ln_beta_dev, ln_eps, w_dev, bias_dev,
+                          y_dev, M, N, K, act);
+}
+
+int codetr_linear_ln_bf16(void* stream, const void* x_dev, const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps,
+                          const void* w_dev, const void* bias_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act) {
+  return launch_ln<BFloatT>(static_cast<hipStream_t>(stream), x_dev, ln_gamma_dev, ln_beta_dev, ln_eps, w_dev, bias_dev,
+                            y_dev, M, N, K, act);
+}
 
 int codetr_linear_xadd_f16(void* stream, const void* x_dev, const void* x_add_dev, const void* w_dev,
                            const void* bias_dev, void* y_dev, int64_t M, int64_t N, int64_t K) {

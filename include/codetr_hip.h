@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 30
+#define CODETR_HIP_ABI_VERSION 31
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -238,6 +238,19 @@ int codetr_linear_xadd_f16(void *stream, const void *x_dev, const void *x_add_de
                            const void *bias_dev, void *y_dev, int64_t M, int64_t N, int64_t K);
 int codetr_linear_xadd_bf16(void *stream, const void *x_dev, const void *x_add_dev, const void *w_dev,
                             const void *bias_dev, void *y_dev, int64_t M, int64_t N, int64_t K);
+
+/* y = act(LayerNorm(x) . w^T + bias) with the LayerNorm applied to the rows as they are loaded by the short-K kernel
+ * (the whole row is that kernel's stationary operand): Swin's pre-norm blocks, norm1 -> qkv and norm2 -> fc1 (reference
+ * codetr/swin.py:345-386), where nothing else reads the normalised tensor.  fp32 two-pass statistics, the normalised
+ * row rounded to T before the product (what the separate kernel writes).  gamma / beta [K].
+ * Only where the X-stationary kernel applies (K in {192, 256}, 128 <= N <= 1536, N % 8 == 0, M >= 32768):
+ * CODETR_E_UNSUPPORTED otherwise -- callers then run codetr_layernorm_* and codetr_linear_*. */
+int codetr_linear_ln_f16(void *stream, const void *x_dev, const void *ln_gamma_dev, const void *ln_beta_dev,
+                         float ln_eps, const void *w_dev, const void *bias_dev, void *y_dev, int64_t M, int64_t N,
+                         int64_t K, int act);
+int codetr_linear_ln_bf16(void *stream, const void *x_dev, const void *ln_gamma_dev, const void *ln_beta_dev,
+                          float ln_eps, const void *w_dev, const void *bias_dev, void *y_dev, int64_t M, int64_t N,
+                          int64_t K, int act);
 
 /* Split-K form of the same layer for problems with few output tiles and a long K -- the neck's extra
  * 3x3 / stride-2 level (codetr/codetr.py neck, mmdet ChannelMapper extra_convs) run as a GEMM over unfolded

@@ -290,3 +290,37 @@ def _xadd_case(M, N, K, dtype, _cabi, hip_ops):
     assert torch.equal(hip_ops.linear_xadd(xs, as_, w, b), hip_ops.linear(xs + as_, w, b))
     out = torch.empty(500, N, dtype=dtype, device=DEV)
     assert _cabi.linear_xadd(xs.contiguous(), as_.contiguous(), w, b, out) is False
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,act", [(40000, 576, 192, None), (32768 + 33, 768, 192, "gelu"), (33000, 256, 256, "relu")])
+def test_linear_ln_matches_layernorm_then_linear(M, N, K, act, dtype):
+    """codetr_linear_ln_*: LayerNorm of the rows inside the short-K GEMM's operand load (Swin norm1 -> qkv, norm2 -> fc1)
+    against the fp32 formula and against codetr_layernorm_* + codetr_linear_* (statistics are summed in a different
+    lane order, so the normalised operand may differ in its last bit on a few elements)."""
+    import torch.nn.functional as F
+    from codetr import _cabi, hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = (torch.randn(M, K, device=DEV, generator=g) * 2 + 0.3).to(dtype)
+    gam = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
+    bet = (0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, device=DEV, generator=g).to(dtype)
+    with torch.no_grad():
+        assert hip_ops.linear_ln_supported(x, gam, w)
+        before = _cabi.CALLS["layernorm"]
+        y = hip_ops.linear_ln(x, gam, bet, 1e-5, w, b, act=act)
+        assert _cabi.CALLS["layernorm"] == before, "the LayerNorm kernel ran: not fused"
+        two = hip_ops.linear(hip_ops.layer_norm(x, gam, bet, 1e-5), w, b, act=act)
+        h = F.layer_norm(x.float(), (K,), gam.float(), bet.float(), 1e-5).to(dtype).float()
+        exact = h @ w.float().t() + b.float()
+        exact = F.gelu(exact) if act == "gelu" else (F.relu(exact) if act == "relu" else exact)
+    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) * max(exact.abs().max().item(), 1.0)
+    assert (y.float() - exact).abs().max().item() < tol
+    assert (y.float() - two.float()).abs().max().item() < tol
+    assert (y != two).float().mean().item() < 0.05      # the vast majority of elements are bit-identical
+    # shapes outside the short-K kernel: LayerNorm + linear
+    with torch.no_grad():
+        assert not hip_ops.linear_ln_supported(x[:500], gam, w)
+        assert torch.equal(hip_ops.linear_ln(x[:500], gam, bet, 1e-5, w, b, act=act), two[:500])
