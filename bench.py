@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+``python bench.py --gpus N`` with N > 1 and no launcher environment starts the N ranks itself: before anything in this
+process touches the GPU it runs ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a CHILD process
+(never an exec), relays rank 0's JSON line and exits with the child's code.
+
 A "step" is one pass of the hot path (``CoDETR.forward``: Swin-L -> ChannelMapper -> CoDINOHead incl.
 12 MSDA HIP launches per image) over one batch of synthetic images already resident in HBM, random-init
 weights of the real architecture (no network: no checkpoint, no COCO).  Images shard across ranks
@@ -12,15 +16,27 @@ weights of the real architecture (no network: no checkpoint, no COCO).  Images s
 8 GPUs); the only collective is one all_gather of the final detections [B,300,6] per step over RCCL.  Timing: W warm-up steps, then exactly K steps between
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks.  Rank 0 prints ONE JSON line.
 
-Extra objects on that line (N=1 only): ``latency_batch1`` -- p50 / p90 of single-image forwards (the quantity the
-reference publishes); the rooflines below are taken on that batch-1 forward as well; ``roofline`` -- the dominant kernel of the forward, the hand-written
-MFMA linear, every launch of one forward timed live with HIP events on its launch stream and priced with
-2*M*N*K flops against the 2.5 PF dense fp16 MFMA peak; ``roofline_ffn`` -- the fused encoder FFN kernel, same
+Weights: seeded default init, except that every MSDA ``sampling_offsets.weight`` (zero in the default init, i.e. every
+query would sample the fixed bias grid -- the best case for the LDS-staged encoder kernel) is drawn so that the sampling
+offsets carry ``--offset-noise-px`` (default 2) pixels of query-dependent spread on top of the bias grid, like trained
+Co-DINO offsets; the measured spread and the fraction of samples that leave the staged neighbourhood are reported in
+``roofline_msda``, next to the same kernel's number at zero spread (``roofline_msda_zero_noise``).
+
+Extra objects on that line: ``host_feed`` -- the same K steps with every step's images copied from pinned host memory
+(PCIe) on the sub-batch streams, i.e. the rate including the input transfer (never ``value``); and at N=1 only:
+``latency_batch1`` -- p50 / p90 of single-image forwards (the quantity the
+reference publishes); ``roofline`` -- the dominant kernel group of the forward, the hand-written
+MFMA linears, every launch of one forward timed live with HIP events on its launch stream and priced with
+2*M*N*K flops against the 2.5 PF dense fp16 MFMA peak (``composite``: the same launches against
+max(flops / 2.5 PF, bytes / 8 TB/s) per launch -- the short-K layers are HBM-bound); ``roofline_ffn`` -- the fused encoder FFN kernel, same
 peak; ``roofline_msda`` -- the fused MSDA gather kernel as the model launches it at the encoder shape, priced with
 the algorithmic bytes of BASELINE.md section 3 against 8 TB/s (``roofline_msda_op``: the same for the stand-alone
 operator ``torch.ops.codetr.multi_scale_deformable_attention`` on synthetic sampling locations); ``traffic`` in each
-= HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json); ``cpu_baseline`` -- the
+= HBM-side bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json); ``cpu_baseline`` -- the
 fp32 CPU oracle (oracle/codetr_fp32.py + the C MSDA restatement) timed on the host cores on a bounded sample.
+
+``--dry-run`` (CPU, gloo): the launcher, sharding, gather, timing and JSON assembly with stand-in detections instead of
+the model -- what tests/test_bench_launch_cpu.py runs with 2 processes; ``value`` is null there.
 """
 import argparse
 import json
@@ -53,13 +69,90 @@ def msda_algorithmic_bytes(B, S, Nq, M=8, D=32, L=5, P=4, e=2):
     return e * (B * S * M * D + 3 * B * Nq * M * L * P + B * Nq * M * D) + 24 * L
 
 
-def build_model(device, dtype, seed=42):
+def build_model(device, dtype, seed=42, offset_noise_px=2.0):
+    """Seeded random-init weights of the real architecture.  offset_noise_px > 0: every MSDA sampling_offsets.weight
+    (zero in the default init, reference multi_scale_deformable_attention.py:90-115) is drawn N(0, s^2) with s chosen
+    so that offsets = W q + b spread by about that many pixels around the bias grid for unit-variance-ish queries
+    (the measured spread is reported by `msda_offset_stats`)."""
     import codetr
 
     torch.manual_seed(seed)
     model = codetr.build_CoDETR(CFG, None, "cpu")
     model.init_weights()  # seeded default init of every sub-module (random weights of the real architecture)
+    set_offset_noise(model, offset_noise_px, seed)
     return model.to(device=device, dtype=dtype).eval()
+
+
+def set_offset_noise(model, px, seed=42):
+    """(re)draw the sampling_offsets weights of every MSDA module for `px` pixels of query-dependent spread (0: the
+    reference's default init, all zeros).  The encoder's query + pos has mean square ~2.6 per channel on these weights
+    (LayerNorm output + sine encoding + level embedding); the decoder's ~2."""
+    from codetr.multi_scale_deformable_attention import MultiScaleDeformableAttention
+
+    g = torch.Generator().manual_seed(seed + 7)
+    for m in model.modules():
+        if isinstance(m, MultiScaleDeformableAttention):
+            w = m.sampling_offsets.weight
+            with torch.no_grad():
+                if px > 0:
+                    std = px / (w.shape[1] * 2.6) ** 0.5
+                    w.copy_((torch.randn(w.shape, generator=g) * std).to(device=w.device, dtype=w.dtype))
+                else:
+                    w.zero_()
+
+
+def msda_offset_stats(model, images, masks, halo=4):
+    """One eager forward with a hook on the encoder's (offsets | logits) projections: the spread of the sampling
+    offsets around their bias grid (pixels of the sampled level, std over queries / heads / points) and the fraction
+    of sample points farther than `halo` pixels from the query's own location on that level -- the ones the LDS-staged
+    encoder kernel has to fetch from global memory instead of its staged neighbourhood."""
+    from codetr import hip_ops
+    from codetr.multi_scale_deformable_attention import MultiScaleDeformableAttention
+
+    enc_atts = [layer.attentions[0] for layer in model.query_head.transformer.encoder.layers]
+    stats = []
+    orig_linear, orig_xadd = hip_ops.linear, hip_ops.linear_xadd
+
+    def record(att, proj):
+        n_off = att.num_heads * att.num_levels * att.num_points * 2
+        off = proj[..., :n_off].float()
+        bias = att.sampling_offsets.bias.float()
+        spread = (off - bias).std().item()
+        miss = (off.abs().view(*off.shape[:-1], -1, 2).amax(-1) > halo).float().mean().item()
+        stats.append((spread, miss))
+
+    def find(weight):
+        for a in enc_atts:
+            if getattr(a, "_fused_w", None) is weight:
+                return a
+        return None
+
+    def linear(x, weight, *args, **kw):
+        y = orig_linear(x, weight, *args, **kw)
+        a = find(weight)
+        if a is not None and y.shape[-1] == weight.shape[0] and y.dim() == 3 and y.shape[1] > 10000:
+            record(a, y)
+        return y
+
+    def linear_xadd(x, x_add, weight, bias=None):
+        y = orig_xadd(x, x_add, weight, bias)
+        a = find(weight)
+        if a is not None:
+            record(a, y)
+        return y
+
+    hip_ops.linear, hip_ops.linear_xadd = linear, linear_xadd
+    try:
+        with torch.no_grad():
+            model(images, masks)
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.linear, hip_ops.linear_xadd = orig_linear, orig_xadd
+    if not stats:
+        return None
+    return {"offset_spread_px_per_encoder_layer": [round(a, 2) for a, _ in stats],
+            "fraction_of_samples_outside_halo_per_layer": [round(b, 4) for _, b in stats],
+            "halo_px": halo}
 
 
 def msda_roofline(B, H, W, dtype, device, iters=30):
@@ -105,13 +198,19 @@ def msda_roofline(B, H, W, dtype, device, iters=30):
 
 def _pmc_traffic():
     """HBM-side bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
-    workload (profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py; reads corrected x2 as
+    workload (profiles/rNN_pmc_traffic.json, newest round first; made by tools/pmc_traffic.py; reads corrected x2 as
     MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected from inside this process."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["kernels"]
-    except (OSError, KeyError, ValueError):
-        return {}
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)["kernels"]
+            d["_file"] = os.path.relpath(path, ROOT)
+            return d
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}
 
 
 def kernel_rooflines(model, images, masks, device):
@@ -138,12 +237,22 @@ def kernel_rooflines(model, images, masks, device):
     secs = sum(p[0].elapsed_time(p[1]) for p in prof) * 1e-3
     achieved = flops / secs / 1e12
     big = max(prof, key=lambda p: p[0].elapsed_time(p[1]))
+    # per-launch composite bound: a launch cannot finish sooner than its flops at the MFMA peak NOR than its
+    # algorithmic bytes (X + W + Y once, 2 B each) at the HBM peak -- the K <= 384 layers sit under the HBM roof
+    bound_s = sum(max(p[2] / (MFMA_PEAK_TFLOPS * 1e12), 2.0 * (p[3] * p[5] + p[4] * p[5] + p[3] * p[4]) / (HBM_PEAK_GBS * 1e9))
+                  for p in prof)
+    hbm_bound_launches = sum(1 for p in prof if 2.0 * (p[3] * p[5] + p[4] * p[5] + p[3] * p[4]) / (HBM_PEAK_GBS * 1e9)
+                             > p[2] / (MFMA_PEAK_TFLOPS * 1e12))
     out["roofline"] = {
         "kernel": "linear_kernel / linear_256_kernel / linear_xs_kernel <f16> (all %d launches of one forward)" % len(prof),
         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
         "traffic": pmc.get("linear_kernel", {}).get("hbm_bytes_per_launch"),
-        "traffic_note": "HBM-side bytes per launch, average over the launches of a forward (committed PMC pass)",
+        "traffic_note": "HBM-side bytes per launch, average over the launches of a forward (committed PMC pass %s)" % pmc.get("_file"),
+        "composite": {"frac": round(bound_s / secs, 4), "bound_ms": round(bound_s * 1e3, 3),
+                      "hbm_bound_launches": hbm_bound_launches,
+                      "note": "sum over launches of max(flops / 2.5 PF, (M*K + N*K + M*N) * 2 B / 8 TB/s) / sum of "
+                              "measured durations"},
         "algorithmic_flops_per_forward": flops, "sum_launch_ms": round(secs * 1e3, 3),
         "avg_launch_us": round(secs / len(prof) * 1e6, 1),
         "longest_launch": {"M": big[3], "N": big[4], "K": big[5], "us": round(big[0].elapsed_time(big[1]) * 1e3, 1),
@@ -213,27 +322,96 @@ def batch1_latency(model, image, mask, device, steps=20):
             "hipgraph": run is not fwd}
 
 
-def cpu_baseline(model, H=608, W=608, full_hw=(1280, 1920)):
-    """fp32 CPU oracle on the host cores, one 608x608 image (bounded sample), scaled by pixel count."""
+def cpu_baseline(model, full_hw=(1280, 1920), budget_s=45.0):
+    """fp32 CPU oracle on the host cores.  A 608x608 image is timed first (a few seconds); if that predicts the
+    full-size image fits the budget, ONE 1920x1280 image -- the workload itself -- is run and reported directly;
+    otherwise the 608x608 time is scaled by the pixel ratio (and says so)."""
     import codetr_fp32 as M
 
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    g = torch.Generator().manual_seed(42)
-    img = torch.randn(1, 3, H, W, generator=g)
-    mask = torch.zeros(1, H, W)
     threads = torch.get_num_threads()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        M.codetr_forward(sd, img, mask, backbone="swin", num_heads=(6, 12, 24, 48), window_size=12)
-    dt = time.perf_counter() - t0
-    scale = (H * W) / float(full_hw[0] * full_hw[1])
-    return {
-        "value": round(scale / dt, 5), "unit": "images/s", "cores": threads, "kind": "port",
-        "sample": f"1 image {W}x{H} through the fp32 CPU oracle (oracle/codetr_fp32.py + C MSDA, {threads} threads, "
-                  f"os.cpu_count()={os.cpu_count()}) took {dt:.1f} s; value = 1/t scaled by the pixel ratio "
-                  f"{scale:.3f} to {full_hw[1]}x{full_hw[0]}-equivalent images/s",
-        "seconds_for_sample": round(dt, 2),
-    }
+
+    def run(H, W):
+        g = torch.Generator().manual_seed(42)
+        img = torch.randn(1, 3, H, W, generator=g)
+        mask = torch.zeros(1, H, W)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            M.codetr_forward(sd, img, mask, backbone="swin", num_heads=(6, 12, 24, 48), window_size=12)
+        return time.perf_counter() - t0
+
+    t608 = run(608, 608)
+    ratio = (608 * 608) / float(full_hw[0] * full_hw[1])
+    who = (f"fp32 CPU oracle (oracle/codetr_fp32.py + C MSDA, {threads} threads, os.cpu_count()={os.cpu_count()})")
+    if t608 / ratio <= budget_s:
+        dt = run(*full_hw)
+        return {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": f"1 image {full_hw[1]}x{full_hw[0]} (the workload's own size) through the {who}: {dt:.1f} s "
+                          f"(a 608x608 image took {t608:.1f} s)",
+                "seconds_for_sample": round(dt + t608, 2)}
+    return {"value": round(ratio / t608, 5), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 image 608x608 through the {who} took {t608:.1f} s; value = 1/t scaled by the pixel ratio "
+                      f"{ratio:.3f} to {full_hw[1]}x{full_hw[0]}-equivalent images/s (a full-size image would exceed the "
+                      f"{budget_s:.0f} s budget)",
+            "seconds_for_sample": round(t608, 2)}
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run (this process
+    has not touched the GPU and never execs), relay the child's stdout (rank 0's JSON line), return its exit code."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
+
+
+def bind_rank(local_rank, local_world):
+    """rank -> device is explicit (cuda:local_rank); the rank's CPU affinity is narrowed to the cores of the GPU's
+    NUMA node when sysfs tells (pinned host buffers and the launch thread then sit next to the GPU's PCIe root),
+    else to an even contiguous share of the cores.  Returns a short description for the report."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return "no affinity API"
+    node = None
+    try:
+        prop = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id)
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node >= 0:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                want = set()
+                for part in f.read().strip().split(","):
+                    lo, _, hi = part.partition("-")
+                    want.update(range(int(lo), int(hi or lo) + 1))
+            share = [c for c in cpus if c in want]
+            if share:
+                os.sched_setaffinity(0, share)
+                return f"cuda:{local_rank} numa node {node}, {len(share)} cpus"
+    except (OSError, AttributeError, ValueError, RuntimeError):
+        pass
+    if local_world > 1 and len(cpus) >= local_world:
+        per = len(cpus) // local_world
+        share = cpus[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, share)
+        return f"cuda:{local_rank} cpus {share[0]}-{share[-1]} (even split; numa node unknown)"
+    return f"cuda:{local_rank} (affinity unchanged)"
 
 
 def main():
@@ -247,29 +425,45 @@ def main():
                     help="sub-batches replayed concurrently on separate HIP streams (graph mode; 1 = single stream)")
     ap.add_argument("--res", default="1920x1280", help="WxH")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--offset-noise-px", type=float, default=2.0,
+                    help="query-dependent spread of the MSDA sampling offsets in pixels (0 = the default init: fixed grid)")
+    ap.add_argument("--feed", default="hbm", choices=["hbm", "host"],
+                    help="hbm: inputs resident in HBM (the metric); host: every step copies its images from pinned host "
+                         "memory inside the timed region (reported, never `value`)")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the forward from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-feed", action="store_true", help="skip the extra host-feed pass")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU / gloo: launcher, sharding, gather, timing and report with stand-in detections, no model")
     a = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not launched and a.gpus > 1:
+        # no launcher around us: start the ranks as a child process BEFORE any GPU call in this one
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit(f"--gpus {a.gpus} needs the torch.distributed.run launcher (WORLD_SIZE is 1)")
         a.gpus = world
+    if a.dry_run:
+        return dry_run(a, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    binding = bind_rank(local_rank, local_world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[a.dtype]
     W, H = (int(x) for x in a.res.split("x"))
-    model = build_model(device, dtype)
+    model = build_model(device, dtype, offset_noise_px=a.offset_noise_px)
     g = torch.Generator(device=device).manual_seed(42 + rank)
     images = torch.randn(a.batch, 3, H, W, device=device, generator=g).to(dtype)  # ~ mean/std-normalised image
     masks = torch.zeros(a.batch, H, W, device=device, dtype=dtype)
@@ -285,6 +479,8 @@ def main():
     subs = [(images[bounds[i]:bounds[i + 1]].contiguous(), masks[bounds[i]:bounds[i + 1]].contiguous())
             for i in range(nstreams)]
     static_out = torch.empty(a.batch, 300, 6, device=device, dtype=torch.float32)
+    # host side of the PCIe feed: the same images in pinned memory, one buffer per sub-batch
+    host_subs = [subs[i][0].cpu().pin_memory() for i in range(nstreams)]
 
     def forward(i):
         with torch.no_grad():
@@ -315,44 +511,58 @@ def main():
             torch.cuda.synchronize(device)
     graph = graphs  # (name kept for the report below)
 
-    def step():
+    def step(feed_host=False):
         main = torch.cuda.current_stream(device)
         if graphs is not None:
             for i in range(nstreams):
                 side[i].wait_stream(main)       # the previous step's consumers are done with static_out
                 with torch.cuda.stream(side[i]):
+                    if feed_host:   # this sub-batch's images over PCIe, on its own stream: overlaps the other's compute
+                        subs[i][0].copy_(host_subs[i], non_blocking=True)
                     graphs[i].replay()
             for i in range(nstreams):
                 main.wait_stream(side[i])
         else:
             for i in range(nstreams):
+                if feed_host:
+                    subs[i][0].copy_(host_subs[i], non_blocking=True)
                 forward(i)
         if world > 1:
             gather_detections(static_out, world * a.batch, out=gathered)  # the only collective: 7.2 KB per image
-
-    for _ in range(a.warmup):
-        step()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    st = torch.cuda.current_stream(device)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    fence()
-    t0 = time.perf_counter()
-    evs[0].record(st)
-    for i in range(a.steps):
-        step()
-        evs[i + 1].record(st)
-    fence()
-    elapsed = time.perf_counter() - t0
-    per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(feed_host):
+        for _ in range(a.warmup):
+            step(feed_host)
+        st = torch.cuda.current_stream(device)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        evs[0].record(st)
+        for i in range(a.steps):
+            step(feed_host)
+            evs[i + 1].record(st)
+        fence()
+        elapsed = time.perf_counter() - t0
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, per_step
+
+    elapsed, per_step_ms = timed(a.feed == "host")
+    host_feed = None
+    if a.feed == "hbm" and not a.no_host_feed:
+        e2, _ = timed(True)
+        host_feed = {"images_per_s": round(a.steps * a.batch * world / e2, 3), "ms_per_step": round(e2 / a.steps * 1e3, 3),
+                     "bytes_per_rank_per_step": int(sum(h.numel() * h.element_size() for h in host_subs)),
+                     "note": "same K steps with every step's images copied from pinned host memory over PCIe on the "
+                             "sub-batch streams inside the timed region; reported beside `value`, never as it"}
 
     if rank == 0:
         total_images = a.steps * a.batch * world
@@ -370,18 +580,23 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[a.dtype],
-            "data": "synthetic (randn images already in HBM, zero padding masks; seeded random-init weights of the "
-                    "real architecture -- no checkpoint/COCO available offline)",
+            "data": "synthetic (randn images %s, zero padding masks; seeded random-init weights of the "
+                    "real architecture with %g px of query-dependent MSDA offset spread -- no checkpoint/COCO available "
+                    "offline)" % ("already in HBM" if a.feed == "hbm" else "fed from pinned host memory every step",
+                                  a.offset_noise_px),
             "config": {
                 "workload": "CoDETR.forward, Co-DINO 5-scale Swin-L, %s, batch %d per GPU, 900 queries, 300 detections"
                             % (a.res, a.batch),
                 "global_batch": a.batch * world, "parallelism": "image-sharded replicas x%d" % world,
-                "hipgraph": graph is not None, "streams": nstreams,
+                "hipgraph": graph is not None, "streams": nstreams, "feed": a.feed, "rank0_binding": binding,
+                "msda_offset_noise_px": a.offset_noise_px,
                 "native_kernels": sorted(__import__("codetr.hip_ops", fromlist=["NATIVE"]).NATIVE),
             },
             "reference_note": "reference publishes 79.5 ms/image (TensorRT fp16, RTX 4090, batch 1, README.md:33); "
                               "not the same hardware, so vs_baseline stays null",
         }
+        if host_feed is not None:
+            out["host_feed"] = host_feed
         if world == 1 and not a.no_roofline:
             # rooflines: one eager forward over the images of ONE replayed graph (batch / streams: the launches of the
             # timed region, same shapes and kernels; the committed PMC passes ran this shape).  The stand-alone MSDA
@@ -390,9 +605,17 @@ def main():
             out["latency_batch1"] = batch1_latency(model, images[:1].contiguous(), masks[:1].contiguous(), device)
             if dtype == torch.float16:
                 nb = max(1, a.batch // max(1, nstreams))
-                out.update(kernel_rooflines(model, images[:nb].contiguous(), masks[:nb].contiguous(), device))
+                xi, xm = images[:nb].contiguous(), masks[:nb].contiguous()
+                out.update(kernel_rooflines(model, xi, xm, device))
                 out["roofline_images_per_launch"] = nb
                 out["roofline_msda_op"] = op
+                if "roofline_msda" in out:
+                    out["roofline_msda"]["offsets"] = msda_offset_stats(model, xi, xm)
+                    if a.offset_noise_px > 0:
+                        # the same kernel with the default init's zero offset weights (round 1's number): best case
+                        set_offset_noise(model, 0.0)
+                        out["roofline_msda_zero_noise"] = kernel_rooflines(model, xi, xm, device).get("roofline_msda")
+                        set_offset_noise(model, a.offset_noise_px)
             else:
                 out["roofline"] = op
         if world == 1 and not a.no_cpu_baseline:
@@ -402,5 +625,36 @@ def main():
         dist.destroy_process_group()
 
 
+def dry_run(a, world, rank):
+    """The control flow of a multi-rank run without GPUs or the model: gloo process group, shard assignment, the
+    detections all_gather, barrier-fenced timing with MAX over ranks, rank 0's JSON line (value null)."""
+    from codetr.sharding import gather_detections, shard_range
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    s, e = shard_range(a.batch * world, rank, world)
+    local = torch.stack([torch.full((300, 6), float(i)) for i in range(s, e)])
+    ok = True
+    t0 = time.perf_counter()
+    for _ in range(a.warmup + a.steps):
+        full = gather_detections(local, a.batch * world)
+        ok = ok and bool((full[:, 0, 0] == torch.arange(a.batch * world, dtype=torch.float32)).all())
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no model, no GPU)", "value": None, "unit": "images/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "dry_run": True, "gather_ok": ok,
+                          "global_batch": a.batch * world, "ms_per_step": round(elapsed / (a.warmup + a.steps) * 1e3, 3),
+                          "scaling": "weak", "higher_is_better": True}))
+    return 0 if ok else 1
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

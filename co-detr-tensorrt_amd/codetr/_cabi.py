@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -53,6 +53,7 @@ SIGNATURES = {
     "codetr_topk_f16": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "codetr_topk_bf16": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
+    "codetr_linear_variant": (_cp, [_i64, _i64, _i64, _i32, _i32, _i32]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp]),
@@ -97,7 +98,9 @@ _lib = None
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
-         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0}
+         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
+         # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
+         "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0}
 
 
 def load():
@@ -181,6 +184,19 @@ def linear_supported(x, weight) -> bool:
     return x.dtype in _LINEAR_BY_DTYPE and weight.dtype == x.dtype and weight.shape[1] % 64 == 0
 
 
+_VARIANTS = {}
+
+
+def linear_variant(M, N, K, act=None, has_residual=False, hm_head_dim=0) -> str:
+    """'tile128' | 'tile256' | 'xs': the kernel codetr_linear_* launches for this (aligned) problem"""
+    key = (M, N, K, act, bool(has_residual), hm_head_dim)
+    v = _VARIANTS.get(key)
+    if v is None:
+        v = _VARIANTS[key] = load().codetr_linear_variant(M, N, K, _ACT[act], 1 if has_residual else 0,
+                                                          hm_head_dim).decode()
+    return v
+
+
 def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None, hm_rows=0, hm_head_dim=0):
     """Enqueue y = act(x @ w.T + b) (+ r) on torch's current stream.  x2d [M,K], weight [N,K] contiguous;
     row_mask [M] bool/uint8: masked rows are written as zeros; hm_rows/hm_head_dim: head-major destination
@@ -189,6 +205,7 @@ def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None, hm_rows=0, 
     CALLS["linear"] += 1
     M, K = x2d.shape
     N = weight.shape[0]
+    CALLS["linear_" + linear_variant(M, N, K, act, residual2d is not None, hm_head_dim)] += 1
     rc = getattr(lib, _LINEAR_BY_DTYPE[x2d.dtype])(
         current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(),
         bias.data_ptr() if bias is not None else None,
@@ -471,6 +488,7 @@ def linear_ln(x2d, gamma, beta, eps, w, bias, act, out2d) -> bool:
         return False
     check(rc, "codetr_linear_ln")
     CALLS["linear"] += 1
+    CALLS["linear_ln"] += 1
     return True
 
 
@@ -485,6 +503,7 @@ def linear_xadd(x2d, xadd2d, w, bias, out2d) -> bool:
         return False
     check(rc, "codetr_linear_xadd")
     CALLS["linear"] += 1
+    CALLS["linear_xadd"] += 1
     return True
 
 

@@ -72,25 +72,44 @@ class CoDETR(nn.Module):
         self.query_head.init_weights()
 
     def forward(self, batch_inputs: Tensor, img_masks: Tensor, forced_topk_indices=None,
-                capture=None) -> Tuple[Tensor, Tensor, Tensor]:
-        if (capture is None and hasattr(self.backbone, "forward_tokens") and hasattr(self, "neck")
+                capture=None, route=None) -> Tuple[Tensor, Tensor, Tensor]:
+        """Reference signature (:66-90) plus three test hooks that do not exist there: `forced_topk_indices` (see
+        CoDinoTransformer.forward), `capture` (a dict that receives intermediates; it never changes which kernels
+        run) and `route` ("nchw" forces the generic NCHW backbone -> neck -> head route that ResNet / fp32 models
+        take; default: token-major wherever the backbone and neck support it)."""
+        if route not in (None, "tokens", "nchw"):
+            raise ValueError(f"route must be None, 'tokens' or 'nchw', got {route!r}")
+        if (route != "nchw" and hasattr(self.backbone, "forward_tokens") and hasattr(self, "neck")
                 and batch_inputs.is_cuda):
             # token-major path: backbone stage outputs stay [B, HW, C], the neck's 1x1 convs are linears over
             # tokens, GroupNorm writes straight into the encoder's [B, S, 256] input -- no NCHW round trip
             tokens = self.backbone.forward_tokens(batch_inputs)
             if self.neck.tokens_supported(tokens):
                 flat, shapes = self.neck.forward_tokens(tokens)
-                return self.query_head.forward_flat(flat, shapes, img_masks, forced_topk_indices=forced_topk_indices)
+                if capture is not None:
+                    # NCHW *views* of the token-major maps (no copies, nothing recomputed): same keys as the NCHW route
+                    capture["route"] = "tokens"
+                    capture["backbone_feats"] = [t.view(-1, *hw, t.shape[-1]).permute(0, 3, 1, 2) for t, hw in tokens]
+                    starts = [0]
+                    for h, w in shapes:
+                        starts.append(starts[-1] + h * w)
+                    capture["neck_feats"] = [flat[:, a:b].view(-1, h, w, flat.shape[-1]).permute(0, 3, 1, 2)
+                                             for (h, w), a, b in zip(shapes, starts[:-1], starts[1:])]
+                return self.query_head.forward_flat(flat, shapes, img_masks, forced_topk_indices=forced_topk_indices,
+                                                    capture=capture)
+            elif route == "tokens":
+                raise RuntimeError("route='tokens': the neck does not take token-major maps for this model / dtype")
             feats = [t.view(-1, *hw, t.shape[-1]).permute(0, 3, 1, 2).contiguous() for t, hw in tokens]
         else:
+            if route == "tokens":
+                raise RuntimeError("route='tokens' needs a token-major backbone, a neck and GPU tensors")
             feats = self.backbone(batch_inputs)
         if capture is not None:
+            capture["route"] = "nchw"
             capture["backbone_feats"] = feats
         feats = self.neck(feats)
         if capture is not None:
             capture["neck_feats"] = feats
-        if forced_topk_indices is None and capture is None:
-            return self.query_head(feats, img_masks)
         return self.query_head(feats, img_masks, forced_topk_indices=forced_topk_indices, capture=capture)
 
 

@@ -411,16 +411,14 @@ class CoDinoTransformer(nn.Module):
         else:
             topk = forced_topk_indices
         gidx = topk.unsqueeze(-1)
-        if capture is None:
-            # the box branch is row-wise: run it on the selected rows only (900 instead of all S tokens)
-            sel = torch.gather(out_mem, 1, gidx.expand(-1, -1, out_mem.shape[-1]))
-            topk_coords = run_mlp(reg_branches[last], sel, residual=torch.gather(proposals, 1, gidx.expand(-1, -1, 4)))
-            enc_coord = None
-        else:
-            enc_coord = run_mlp(reg_branches[last], out_mem) + proposals
-            topk_coords = torch.gather(enc_coord, 1, gidx.repeat(1, 1, 4))
+        # the box branch is row-wise: run it on the selected rows only (900 instead of all S tokens)
+        sel = torch.gather(out_mem, 1, gidx.expand(-1, -1, out_mem.shape[-1]))
+        topk_coords = run_mlp(reg_branches[last], sel, residual=torch.gather(proposals, 1, gidx.expand(-1, -1, 4)))
         query = self.query_embed.weight[None].expand(B, -1, -1)
         if capture is not None:
+            # the reference's all-rows form (:555-557), for inspection only: what feeds the decoder is `topk_coords`
+            enc_coord = run_mlp(reg_branches[last], out_mem) + proposals
+            capture["topk_coords_unact"] = topk_coords
             capture.update(memory=memory, enc_outputs_class=enc_cls, enc_outputs_coord_unact=enc_coord,
                            topk_indices=topk, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                            valid_ratios=valid_ratios)

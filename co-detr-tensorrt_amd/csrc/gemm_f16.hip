@@ -1147,6 +1147,15 @@ int launch_xs(hipStream_t st, const void* X, const void* W, const void* bias, co
   }
 }
 
+// which of the three kernels behind codetr_linear_* serves a problem (the ONE place this is decided; exported as
+// codetr_linear_variant so hosts and tests can tell which kernel ran).  io16: Y (and R) 16-byte aligned.
+enum { kKernel128 = 0, kKernel256 = 1, kKernelXS = 2 };
+int pick_kernel(int64_t M, int64_t N, int64_t K, int act, bool has_res, int hm_hd, bool io16) {
+  if (io16 && big_applicable(M, N, K, hm_hd)) return kKernel256;
+  if (io16 && xs_applicable(M, N, K, hm_hd) && (K != 64 || (act == 0 && !has_res))) return kKernelXS;
+  return kKernel128;
+}
+
 template <class T>
 int launch(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y, const void* mask,
            int64_t M, int64_t N, int64_t K, int act, int64_t hm_rows, int hm_hd) {
@@ -1159,16 +1168,16 @@ int launch(hipStream_t st, const void* X, const void* W, const void* bias, const
     if (hm_hd <= 0 || hm_rows <= 0 || hm_hd % 8 != 0 || N % hm_hd != 0 || N % 8 != 0 || M % hm_rows != 0 || R)
       return CODETR_E_UNSUPPORTED;
   }
-  if (big_applicable(M, N, K, hm_hd) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
-      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0)) {
+  const bool io16 = (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0);
+  const int kind = pick_kernel(M, N, K, act, R != nullptr, hm_hd, io16);
+  if (kind == kKernel256) {
     switch (act) {
       case 0: return launch_big<T, 0>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
       case 1: return launch_big<T, 1>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
       default: return launch_big<T, 2>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K);
     }
   }
-  if (xs_applicable(M, N, K, hm_hd) && (K != 64 || (act == 0 && !R)) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
-      (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0))
+  if (kind == kKernelXS)
     return launch_xs<T>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, act, (int)hm_rows, hm_hd);
   switch (act) {
     case 0: return launch_act<T, 0>(st, X, W, bias, R, Y, mask, (int)M, (int)N, (int)K, (int)hm_rows, hm_hd);
@@ -1251,6 +1260,15 @@ int codetr_linear_bf16(void* stream, const void* x_dev, const void* w_dev, const
                        int64_t K, int act, int64_t hm_rows, int hm_head_dim) {
   return launch<BFloatT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, row_mask_dev,
                          M, N, K, act, hm_rows, hm_head_dim);
+}
+
+const char* codetr_linear_variant(int64_t M, int64_t N, int64_t K, int act, int has_residual, int hm_head_dim) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 64 != 0) return "unsupported";
+  switch (pick_kernel(M, N, K, act, has_residual != 0, hm_head_dim, true)) {
+    case kKernel256: return "tile256";
+    case kKernelXS: return "xs";
+    default: return "tile128";
+  }
 }
 
 int codetr_linear_splitk_plan(int64_t M, int64_t N, int64_t K, int64_t* workspace_bytes) {

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 31
+#define CODETR_HIP_ABI_VERSION 32
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -227,6 +227,12 @@ int codetr_linear_f16(void *stream, const void *x_dev, const void *w_dev, const 
 int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                        const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
                        int64_t K, int act, int64_t hm_rows, int hm_head_dim);
+
+/* Which of the three kernels behind codetr_linear_* serves a (16-byte aligned) problem: "tile128" (128x128 tiles, the
+ * general kernel), "tile256" (256x256 tiles, one workgroup per CU), "xs" (X-stationary short-K kernel) or
+ * "unsupported" (K % 64 != 0).  Pure function of the arguments and of the CODETR_GEMM_* environment switches; it is the
+ * same routine the launcher consults, so tests can assert which kernel a model shape exercises. */
+const char *codetr_linear_variant(int64_t M, int64_t N, int64_t K, int act, int has_residual, int hm_head_dim);
 
 /* y = (x + x_add) . w^T + bias with the element-wise add folded into the operand load of the short-K kernel:
  * `query + query_pos` in front of the (offsets | logits) projection of MultiScaleDeformableAttention

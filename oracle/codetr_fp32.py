@@ -369,9 +369,9 @@ def _valid_ratio(mask, dtype):
 def transformer(sd, feats, masks, pos_embeds, p="query_head.transformer", head="query_head", num_query=900,
                 forced_topk=None, capture=None):
     """feats: list [B,C,H,W]; masks: list [B,H,W] bool; pos_embeds: list [B,C,H,W].
-    Returns (final_state [B,Nq,C], refs_unact [B,Nq,4]).  `forced_topk` [B,Nq] int64 overrides the
-    proposal selection (parity on random weights); `capture` dict receives
-    intermediates."""
+    Returns (final_state [B,Nq,C], refs_unact [B,Nq,4]).  `forced_topk` [B,Nq] int64 (or a callable
+    (enc_cls, enc_coord, k) -> indices) overrides the proposal selection (parity on random weights, SURVEY.md
+    section 4); `capture` dict receives intermediates."""
     dtype = feats[0].dtype
     B = feats[0].shape[0]
     shapes = [tuple(f.shape[-2:]) for f in feats]
@@ -403,7 +403,10 @@ def transformer(sd, feats, masks, pos_embeds, p="query_head.transformer", head="
     n_dec = _count(sd, p + ".decoder.layers.")
     enc_cls = _lin(sd, f"{head}.cls_branches.{n_dec}", om)
     enc_coord = reg_branch(sd, f"{head}.reg_branches.{n_dec}", om) + prop
-    topk = forced_topk if forced_topk is not None else torch.topk(enc_cls.max(-1)[0], num_query, dim=1)[1]
+    if callable(forced_topk):   # e.g. helpers_model.valid_topk: a selection rule evaluated on this pass's own scores
+        topk = forced_topk(enc_cls, enc_coord, num_query)
+    else:
+        topk = forced_topk if forced_topk is not None else torch.topk(enc_cls.max(-1)[0], num_query, dim=1)[1]
     ref_unact = torch.gather(enc_coord, 1, topk[..., None].expand(-1, -1, 4))
     query = sd[p + ".query_embed.weight"][None].expand(B, -1, -1)
     if capture is not None:

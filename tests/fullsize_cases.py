@@ -1,0 +1,104 @@
+"""Full-architecture parity cases at BASELINE.json's sizes (configs 1-3), shared by the fixture generator
+(tests/golden/make_fullsize_rows.py, runs the fp32 CPU oracle in the build container) and the GPU tests
+(tests/test_timed_route_gpu.py).
+
+A case = the real architecture (Swin-L or R50 Co-DINO from the package's config files) + seeded weights + one seeded
+input.  The oracle's intermediates are too big to commit (encoder memory at 1152x768: 75 MB), so a fixture holds a
+few hundred ROWS of every stage, chosen by a seeded permutation, plus the forced proposal selection; the GPU test
+gathers the same rows from the product's capture.  Everything either side needs to rebuild the case is here."""
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+from helpers_model import seeded_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_DIR = os.path.join(ROOT, "co-detr-tensorrt_amd", "configs")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+CASES = {
+    # BASELINE config 2: Co-DINO Swin-L 608x608 (one image, right / bottom 10 % padding: masks, valid ratios, masked_fill)
+    "swinl_608": dict(cfg="co_dino_5scale_swin_l_16xb1_16e_o365tococo.py", backbone="swin", H=608, W=608, B=1,
+                      pad=(0.9, 0.9), weight_seed=11, input_seed=5),
+    # BASELINE config 3: Co-DINO Swin-L 1152x768 (no Swin padding at any stage; unpadded image)
+    "swinl_1152x768": dict(cfg="co_dino_5scale_swin_l_16xb1_16e_o365tococo.py", backbone="swin", H=768, W=1152, B=1,
+                           pad=None, weight_seed=12, input_seed=6),
+    # BASELINE config 1: Co-DINO R50 608x608 (the reference's CPU-runnable case; here also run in fp32 on the GPU)
+    "r50_608": dict(cfg="co_dino_5scale_r50_8xb2_1x_coco.py", backbone="r50", H=608, W=608, B=1, pad=(0.9, 0.9),
+                    weight_seed=13, input_seed=7),
+}
+
+# rows kept per stage (all channels of a row are kept)
+ROWS = {"backbone": 16, "neck": 16, "memory": 128, "enc_outputs_class": 128, "final_state": 64, "outputs_classes": 64}
+
+
+def build_case(name):
+    """-> (model on CPU in fp32 with the case's weights loaded, state dict, img [B,3,H,W], mask [B,H,W])"""
+    import codetr
+
+    c = CASES[name]
+    torch.manual_seed(0)
+    model = codetr.build_CoDETR(os.path.join(CFG_DIR, c["cfg"]), None, "cpu")
+    spec = [(k, tuple(v.shape)) for k, v in model.named_parameters()]
+    full = dict(model.state_dict())
+    full.update(seeded_params(spec, c["weight_seed"], scale=1.0))
+    g = torch.Generator().manual_seed(c["weight_seed"] + 1000)
+    for k in sorted(full):   # frozen BatchNorm statistics of the R50 (buffers, not parameters)
+        if k.endswith("running_var"):
+            full[k] = torch.rand(full[k].shape, generator=g) + 0.5
+        elif k.endswith("running_mean"):
+            full[k] = torch.randn(full[k].shape, generator=g) * 0.1
+    model.load_state_dict(full)
+    g = torch.Generator().manual_seed(c["input_seed"])
+    img = torch.randn(c["B"], 3, c["H"], c["W"], generator=g)
+    mask = torch.zeros(c["B"], c["H"], c["W"])
+    if c["pad"] is not None:
+        mask[-1, :, int(c["W"] * c["pad"][0]):] = 1
+        mask[-1, int(c["H"] * c["pad"][1]):, :] = 1
+    return model.eval(), full, img, mask
+
+
+def spec_digest(state_dict):
+    """order-sensitive digest of (name, shape) of the state dict: a fixture made for another layout fails loudly"""
+    h = hashlib.sha1()
+    for k, v in state_dict.items():
+        h.update(f"{k}:{tuple(v.shape)};".encode())
+    return h.hexdigest()[:16]
+
+
+def row_indices(tag, n_rows, keep):
+    """the first `keep` entries of a permutation of range(n_rows) seeded by `tag` (sorted)"""
+    seed = int(hashlib.sha1(tag.encode()).hexdigest()[:8], 16)
+    perm = torch.randperm(n_rows, generator=torch.Generator().manual_seed(seed))
+    return torch.sort(perm[:min(keep, n_rows)])[0]
+
+
+def sample_capture(name, cap):
+    """capture dict (oracle's or product's; tensors on any device / dtype) -> dict of float32 numpy row samples.
+    backbone_feats / neck_feats are lists of [B,C,H,W]; rows are (image, pixel) pairs of the flattened map."""
+    out = {}
+
+    def rows2d(t):   # [B, N, C] -> [B*N, C]
+        return t.reshape(-1, t.shape[-1])
+
+    for key, short in (("backbone_feats", "backbone"), ("neck_feats", "neck")):
+        for i, f in enumerate(cap[key]):
+            t = rows2d(f.flatten(2).transpose(1, 2))
+            idx = row_indices(f"{name}/{short}{i}", t.shape[0], ROWS[short])
+            out[f"{short}{i}"] = t[idx.to(t.device)].float().cpu().numpy()
+    for key in ("memory", "enc_outputs_class", "final_state", "outputs_classes"):
+        t = rows2d(cap[key])
+        idx = row_indices(f"{name}/{key}", t.shape[0], ROWS[key])
+        out[key] = t[idx.to(t.device)].float().cpu().numpy()
+    out["outputs_coords"] = cap["outputs_coords"].float().cpu().numpy()
+    return out
+
+
+def fixture_path(name):
+    return os.path.join(GOLDEN, f"fullsize_{name}.npz")
+
+
+def load_fixture(name):
+    return dict(np.load(fixture_path(name)))

@@ -69,7 +69,7 @@ def assert_close_lowp(actual, ref, rel_l2=1e-2, max_abs=None, what=""):
     return err
 
 
-def valid_topk(enc_cls, enc_coord, k):
+def valid_topk(enc_cls, enc_coord, k, bound=None):
     """Proposal selection for parity runs on random weights: the reference's rule (top-k of the max class
     logit, reference transformer.py:560) restricted to positions whose proposal is finite.  With
     trained weights padded positions never win; with random weights they can, and their NaN box
@@ -79,4 +79,58 @@ def valid_topk(enc_cls, enc_coord, k):
 
     score = enc_cls.max(-1)[0].clone()
     score[~torch.isfinite(enc_coord).all(-1)] = -float("inf")
+    if bound is not None:
+        # also drop positions whose proposal was replaced by finfo.max (outside (-4.6, 4.6) or on padding, reference
+        # transformer.py:365-380): finite in fp32, +inf once an fp16 model adds the box branch to 65504
+        score[(enc_coord.abs() > bound).any(-1)] = -float("inf")
     return torch.topk(score, k, dim=1)[1]
+
+
+def unmatched_detections(own, expected, score_tol=2e-6, box_tol=1e-3, tie_gap=1e-5):
+    """Detections of `expected` = (boxes [K,4], scores [K], labels [K]) that `own` (same layout) does not contain.
+
+    Both sides are top-k selections over the same kind of score table, possibly evaluated by different devices
+    (sigmoid differs by an ulp between CPU and GPU), so membership is by tolerance -- same label, |score diff| <=
+    score_tol, |box diff| <= box_tol pixels -- never by rounding to a grid (a value next to a rounding boundary
+    would land in different cells on the two sides).  Expected detections whose score lies within `tie_gap` of
+    another expected score or of the selection threshold are skipped: WHICH member of a (near-)tie wins the top-k is
+    implementation-defined.  Non-finite rows (padded proposals, see valid_topk) are skipped on both sides."""
+    import torch
+
+    ob, os_, ol = (torch.as_tensor(t).detach().cpu() for t in own)
+    eb, es, el = (torch.as_tensor(t).detach().cpu() for t in expected)
+    ob, os_, eb, es = ob.double(), os_.double(), eb.double(), es.double()
+    ok_o = torch.isfinite(ob).all(-1) & torch.isfinite(os_)
+    ok_e = torch.isfinite(eb).all(-1) & torch.isfinite(es)
+    fin = es[ok_e]
+    thresh = fin.min() if fin.numel() else torch.tensor(0.0, dtype=torch.float64)
+    missing = []
+    for i in range(es.shape[0]):
+        if not ok_e[i]:
+            continue
+        gap = (es - es[i]).abs()
+        gap[i] = float("inf")
+        if gap[ok_e].min() <= tie_gap or es[i] - thresh <= tie_gap:
+            continue
+        hit = ok_o & (ol == el[i]) & ((os_ - es[i]).abs() <= score_tol) & ((ob - eb[i]).abs().max(-1)[0] <= box_tol)
+        if not bool(hit.any()):
+            missing.append((float(es[i]), int(el[i]), [float(v) for v in eb[i]]))
+    return missing
+
+
+def poison_allocator(device, total_mb=512):
+    """Fill the caching allocator's free lists with NaN bit patterns, so that the next torch.empty of (almost) any
+    size hands out NaNs: a kernel that leaves part of its output or workspace unwritten then shows up as NaN / as a
+    run-to-run difference instead of silently reading a previous run's (correct) values."""
+    import torch
+
+    held, used = [], 0
+    for s in [1 << k for k in range(9, 27)] * 3:   # 512 B .. 64 MiB blocks
+        if used + s > total_mb << 20:
+            continue
+        t = torch.empty(s // 4, dtype=torch.float32, device=device)
+        t.fill_(float("nan"))
+        held.append(t)
+        used += s
+    torch.cuda.synchronize(device)
+    del held

@@ -16,7 +16,7 @@ import torch
 
 import codetr_fp32 as M
 from conftest import GOLDEN, ROOT
-from helpers_model import assert_close_lowp, seeded_params, unpack_param_spec, valid_topk
+from helpers_model import assert_close_lowp, seeded_params, unmatched_detections, unpack_param_spec, valid_topk
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -181,18 +181,12 @@ def _tiny_codetr_cfg(backbone):
 def test_full_codetr_fp32_vs_oracle(backbone, hw):
     """End to end: backbone -> neck -> head, padded second image, product fp32 on GPU vs CPU oracle.
 
-    The fp32 GPU run goes through ATen / rocBLAS / MIOpen library kernels (the hand-written kernels are 16-bit); its
-    errors sit 40-100x inside the bounds below (tools/micro/fp32_margins.py), yet about one fresh-box run in twenty has
-    failed here without reproducing in the same process.  One retry, reported as a warning with the first failure's
-    text, keeps that library-side transient from masking the rest of the suite."""
-    import warnings
-
-    try:
-        _full_codetr_fp32_vs_oracle(backbone, hw)
-    except AssertionError as first:
-        warnings.warn(f"fp32 GPU-vs-oracle check failed once and is retried: {str(first)[:500]}")
-        torch.cuda.synchronize()
-        _full_codetr_fp32_vs_oracle(backbone, hw)
+    (Round 1 wrapped this test in a retry because about one fresh-box run in twenty failed its last assertion.  The
+    cause was the assertion, not a kernel: detections were compared as sets of tuples ROUNDED to 6 / 2 decimals, and a
+    GPU sigmoid one ulp away from the CPU's next to a rounding boundary put the same detection into different cells --
+    tools/diag_fp32_flake.py reproduces it and shows every stage bit-stable run to run.  Membership is now by
+    tolerance, helpers_model.unmatched_detections, and there is no retry.)"""
+    _full_codetr_fp32_vs_oracle(backbone, hw)
 
 
 def _full_codetr_fp32_vs_oracle(backbone, hw):
@@ -248,17 +242,53 @@ def _full_codetr_fp32_vs_oracle(backbone, hw):
     np.testing.assert_allclose(scores.cpu().numpy(), scores_o.numpy(), rtol=5e-3, atol=1e-4)
     bx, sc, lb = M.decode_detections(cap["outputs_classes"].cpu(), cap["outputs_coords"].cpu(), H, W, 20, 80)
     torch.testing.assert_close(scores.cpu(), sc, rtol=1e-6, atol=1e-7, equal_nan=True)  # NaN: padded proposals, see helpers_model
-    own = {(round(float(s_), 6), int(l_), tuple(np.round(b_.numpy(), 2))) for s_, l_, b_ in
-           zip(scores[0].cpu(), labels[0].cpu(), boxes[0].cpu()) if torch.isfinite(b_).all() and torch.isfinite(s_)}
-    exp = {(round(float(s_), 6), int(l_), tuple(np.round(b_.numpy(), 2))) for s_, l_, b_ in zip(sc[0], lb[0], bx[0])
-           if torch.isfinite(b_).all() and torch.isfinite(s_)}
-    untied = {t for t in exp if sum(1 for u in exp if u[0] == t[0]) == 1 and t[0] > float(sc[0].min())}
-    assert untied <= own
+    for bi in range(2):
+        missing = unmatched_detections((boxes[bi], scores[bi], labels[bi]), (bx[bi], sc[bi], lb[bi]))
+        assert not missing, f"image {bi}: detections of the oracle decode missing from the product's output: {missing}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_forward_is_bit_stable_with_poisoned_allocator(dtype):
+    """The same inputs 8 times with every torch.empty handing out NaNs (helpers_model.poison_allocator): every captured
+    stage and the detections are bit-identical run to run -- no race, no atomics, no read of unwritten workspace on the
+    inference path (fp32: ATen GEMMs + the native mask-pyramid / MSDA f32 kernels; fp16: the hand-written kernels)."""
+    import codetr
+    from helpers_model import poison_allocator
+
+    torch.manual_seed(0)
+    model = codetr.CoDETR(**_tiny_codetr_cfg("swin"))
+    spec = [(k, tuple(v.shape)) for k, v in model.named_parameters()]
+    full = dict(model.state_dict())
+    full.update(seeded_params(spec, 77, scale=1.5))
+    model.load_state_dict(full)
+    model = model.to(DEV, dtype).eval()
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(2, 3, 76, 100, generator=g).to(DEV, dtype)
+    mask = torch.zeros(2, 76, 100)
+    mask[1, :, 80:] = 1
+    mask[1, 68:, :] = 1
+    mask = mask.to(DEV, dtype)
+    stages = ("memory", "enc_outputs_class", "topk_coords_unact", "final_state", "outputs_classes", "outputs_coords")
+    first = None
+    for it in range(8):
+        poison_allocator(DEV)
+        cap = {}
+        with torch.no_grad():
+            out = model(img, mask, capture=cap)
+        torch.cuda.synchronize()
+        snap = [t.clone() for t in cap["backbone_feats"]] + [t.clone() for t in cap["neck_feats"]] \
+            + [cap[k].clone() for k in stages] + [o.clone() for o in out]
+        if first is None:
+            first = snap
+            continue
+        for i, (a, b) in enumerate(zip(snap, first)):
+            assert torch.equal(torch.nan_to_num(a.float(), nan=12345.0), torch.nan_to_num(b.float(), nan=12345.0)), \
+                f"run {it}: tensor {i} differs from the first run"
 
 
 def test_token_major_path_equals_nchw_path():
     """CoDETR.forward's token-major route (Swin tokens -> linear + native GroupNorm into [B,S,256] -> head) against
-    the generic NCHW route of the same model (taken when `capture` is requested), fp16, padded second image."""
+    the generic NCHW route of the same model (`route="nchw"`), fp16, padded second image."""
     import codetr
     from codetr import _cabi
 
@@ -278,10 +308,11 @@ def test_token_major_path_equals_nchw_path():
     mask[1, :, 170:] = 1
     cap = {}
     with torch.no_grad():
-        model(img, mask, capture=cap)  # generic path, to obtain a NaN-free proposal selection
+        model(img, mask, capture=cap, route="nchw")  # generic path, to obtain a NaN-free proposal selection
         picks = valid_topk(cap["enc_outputs_class"].float().cpu(), cap["enc_outputs_coord_unact"].float().cpu(), 50).to(DEV)
         cap = {}
-        b0, s0, l0 = model(img, mask, forced_topk_indices=picks, capture=cap)        # NCHW route
+        b0, s0, l0 = model(img, mask, forced_topk_indices=picks, capture=cap, route="nchw")   # NCHW route
+        assert cap["route"] == "nchw"
         before = dict(_cabi.CALLS)
         b1, s1, l1 = model(img, mask, forced_topk_indices=picks)                     # token-major route
     assert _cabi.CALLS["groupnorm_tokens"] - before["groupnorm_tokens"] == 5  # 4 mapped levels + the stride-2 extra level
