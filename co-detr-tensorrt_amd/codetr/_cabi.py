@@ -205,7 +205,9 @@ def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None, hm_rows=0, 
     CALLS["linear"] += 1
     M, K = x2d.shape
     N = weight.shape[0]
-    CALLS["linear_" + linear_variant(M, N, K, act, residual2d is not None, hm_head_dim)] += 1
+    variant = linear_variant(M, N, K, act, residual2d is not None, hm_head_dim)
+    if variant != "unsupported":   # (the launch below reports the unsupported shape with its own error)
+        CALLS["linear_" + variant] += 1
     rc = getattr(lib, _LINEAR_BY_DTYPE[x2d.dtype])(
         current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(),
         bias.data_ptr() if bias is not None else None,

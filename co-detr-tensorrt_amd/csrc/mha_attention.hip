@@ -10,6 +10,8 @@
 // O^T = V^T . P^T; V^T fragments through ds_read_b64_tr_b16 from the row-major V image.  fp32 scores / softmax /
 // accumulation, one rounding at the store.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 #include "codetr_hip.h"
@@ -205,12 +207,17 @@ int mha_entry(void* stream, const void* q, const void* k, const void* v, void* o
   if (blocks > 0x7fffffffLL || Nq > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   const int NP = ((int)Nk + 31) & ~31;
   const size_t lds = (size_t)NP * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_attention_kernel<ET>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeys * 128);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+  {
+    // per device (the attribute belongs to the current device's function object), not per process
+    static std::atomic<bool> done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done[0].store(false);
+    if (!done[dev].load(std::memory_order_acquire)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_attention_kernel<ET>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeys * 128);
+      if (e != hipSuccess) return (int)e;
+      done[dev].store(true, std::memory_order_release);
+    }
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
   hipLaunchKernelGGL(mha_attention_kernel<ET>, dim3((unsigned)blocks), dim3(kThreads), lds,

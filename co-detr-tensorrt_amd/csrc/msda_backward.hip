@@ -13,7 +13,8 @@
 // reduction over the block (cu:320-336) becomes log2(D) xor-shuffles inside the D-lane group, and lane 0 of the
 // group stores the two location gradients and the weight gradient (each point belongs to exactly one pair: plain
 // stores).  fp16: arithmetic in fp32, value-gradient atomics as packed 2 x f16 adds (global_atomic_pk_add_f16), even
-// lane carrying its neighbour's channel.  Training-path kernel: written for correctness, not tuned.
+// lane carrying its neighbour's channel.  Channel counts that are not a power of two <= 64 take the wave-per-pair
+// kernel further down.  Training-path kernels: written for correctness, not tuned.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -140,6 +141,106 @@ __global__ __launch_bounds__(256) void msda_backward_kernel(const ST* __restrict
   }
 }
 
+// Any channel count (the reference gradchecks D = 30, 71, 1025 next to the powers of two,
+// tests/test_multi_scale_deformable_attention.py:367-414): one WAVE per (image, query, head), its lanes striding the
+// channels (c = lane, lane + 64, ...); per sample point every lane sums its channels' contributions, then one 64-lane
+// shuffle reduction and lane 0 stores.  fp16 value gradients: a single channel is added as a packed pair with a zero
+// partner on the 4-byte word that holds it (needs an even M * D so that word never straddles the end of the tensor).
+template <class AT>
+__device__ __forceinline__ AT wave_sum(AT v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <class ST>
+__device__ __forceinline__ void add_value_single(ST* g, typename BwdTraits<ST>::AT v) {
+  atomicAdd(g, v);
+}
+template <>
+__device__ __forceinline__ void add_value_single<_Float16>(_Float16* g, float v) {
+  const bool odd = (reinterpret_cast<uintptr_t>(g) & 2) != 0;
+  const f16x2 pk = odd ? f16x2{(_Float16)0.f, (_Float16)v} : f16x2{(_Float16)v, (_Float16)0.f};
+  __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) f16x2*)(odd ? g - 1 : g), pk);
+}
+
+template <class ST>
+__global__ __launch_bounds__(256) void msda_backward_generic_kernel(
+    const ST* __restrict__ grad_out, const ST* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+    const int64_t* __restrict__ level_start, const ST* __restrict__ loc, const ST* __restrict__ weight, int64_t n_pairs,
+    int S, int M, int D, int L, int Nq, int P, ST* __restrict__ grad_value, ST* __restrict__ grad_loc,
+    ST* __restrict__ grad_w) {
+  using TR = BwdTraits<ST>;
+  using AT = typename TR::AT;
+  const int lane = threadIdx.x & 63;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= n_pairs) return;  // whole waves leave together
+  const int m = (int)(pair % M);
+  const int64_t b = pair / ((int64_t)M * Nq);
+  const int64_t pt0 = pair * L * P;
+  const int w_stride = M * D;
+  const ST* go = grad_out + pair * D;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)spatial_shapes[2 * l], W = (int)spatial_shapes[2 * l + 1];
+    const int64_t base = (b * S + level_start[l]) * (int64_t)w_stride + m * D;
+    for (int p = 0; p < P; ++p) {
+      const int64_t pt = pt0 + l * P + p;
+      const AT loc_w = TR::ld(loc + 2 * pt), loc_h = TR::ld(loc + 2 * pt + 1);
+      const AT aw = TR::ld(weight + pt);
+      const AT h_im = loc_h * H - (AT)0.5, w_im = loc_w * W - (AT)0.5;
+      AT g_a = 0, g_x = 0, g_y = 0;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {  // wave-uniform
+        const AT hf = floor(h_im), wf = floor(w_im);
+        const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
+        const AT lh = h_im - hf, lw = w_im - wf, hh = 1 - lh, hw = 1 - lw;
+        const AT w1c = hh * hw, w2c = hh * lw, w3c = lh * hw, w4c = lh * lw;
+        const int64_t o00 = base + ((int64_t)h0 * W + w0) * w_stride;
+        const bool k1 = h0 >= 0 && w0 >= 0, k2 = h0 >= 0 && w1 <= W - 1, k3 = h1 <= H - 1 && w0 >= 0,
+                   k4 = h1 <= H - 1 && w1 <= W - 1;
+        for (int c = lane; c < D; c += 64) {
+          const AT top = TR::ld(go + c);
+          const AT tgv = top * aw;
+          AT gh = 0, gw = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+          if (k1) {
+            v1 = TR::ld(value + o00 + c);
+            gh -= hw * v1;
+            gw -= hh * v1;
+            add_value_single<ST>(grad_value + o00 + c, w1c * tgv);
+          }
+          if (k2) {
+            v2 = TR::ld(value + o00 + w_stride + c);
+            gh -= lw * v2;
+            gw += hh * v2;
+            add_value_single<ST>(grad_value + o00 + w_stride + c, w2c * tgv);
+          }
+          if (k3) {
+            v3 = TR::ld(value + o00 + (int64_t)W * w_stride + c);
+            gh += hw * v3;
+            gw -= lh * v3;
+            add_value_single<ST>(grad_value + o00 + (int64_t)W * w_stride + c, w3c * tgv);
+          }
+          if (k4) {
+            v4 = TR::ld(value + o00 + (int64_t)W * w_stride + w_stride + c);
+            gh += lw * v4;
+            gw += lh * v4;
+            add_value_single<ST>(grad_value + o00 + (int64_t)W * w_stride + w_stride + c, w4c * tgv);
+          }
+          g_a += top * (w1c * v1 + w2c * v2 + w3c * v3 + w4c * v4);
+          g_x += W * gw * tgv;
+          g_y += H * gh * tgv;
+        }
+      }
+      g_a = wave_sum<AT>(g_a);
+      g_x = wave_sum<AT>(g_x);
+      g_y = wave_sum<AT>(g_y);
+      if (lane == 0) {
+        TR::st(grad_w + pt, g_a);
+        TR::st(grad_loc + 2 * pt, g_x);
+        TR::st(grad_loc + 2 * pt + 1, g_y);
+      }
+    }
+  }
+}
+
 template <class ST>
 int launch_bwd(void* stream, const void* value, const void* ss, const void* ls, const void* loc, const void* w,
                const void* go, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step,
@@ -149,9 +250,22 @@ int launch_bwd(void* stream, const void* value, const void* ss, const void* ls, 
   const int64_t step = B < im2col_step ? B : im2col_step;
   if (B > 0 && B % step != 0) return CODETR_E_IM2COL_STEP;
   if (B == 0 || Nq == 0) return 0;
-  if (D > 64 || (D & (D - 1)) != 0) return CODETR_E_UNSUPPORTED;         // the D lanes of a pair reduce by xor-shuffle
-  if (sizeof(ST) == 2 && D < 2) return CODETR_E_UNSUPPORTED;              // packed f16 atomics need channel pairs
   if (S > 0x7fffffffLL || Nq > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  const bool lanes_per_channel = D <= 64 && (D & (D - 1)) == 0 && !(sizeof(ST) == 2 && D < 2);
+  if (!lanes_per_channel) {
+    // any other channel count (30, 71, 1025 ...): one wave per (image, query, head)
+    if (sizeof(ST) == 2 && ((int64_t)M * D) % 2 != 0) return CODETR_E_UNSUPPORTED;  // packed f16 atomics, see the kernel
+    const int64_t n_pairs = B * Nq * M;
+    const int64_t nblk = (n_pairs + 3) / 4;
+    if (nblk > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+    hipLaunchKernelGGL((msda_backward_generic_kernel<ST>), dim3((unsigned)nblk), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const ST*>(go), static_cast<const ST*>(value),
+                       static_cast<const int64_t*>(ss), static_cast<const int64_t*>(ls), static_cast<const ST*>(loc),
+                       static_cast<const ST*>(w), n_pairs, (int)S, M, D, L, (int)Nq, P, static_cast<ST*>(gv),
+                       static_cast<ST*>(gl), static_cast<ST*>(gw));
+    const hipError_t e2 = hipGetLastError();
+    return e2 == hipSuccess ? 0 : (int)e2;
+  }
   const int64_t n_total = B * Nq * M * D;
   const int64_t blocks = (n_total + 255) / 256;
   if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;

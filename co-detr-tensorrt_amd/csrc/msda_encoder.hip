@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "codetr_hip.h"
@@ -626,17 +627,29 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
   if (lds > (size_t)kMaxLds) return CODETR_E_UNSUPPORTED;
   const int64_t blocks = B * g.RX * g.RY * M;
   if (blocks >= (1 << 22)) return CODETR_E_UNSUPPORTED;  // (the kernel's cheap tile decode)
+#ifdef MSDA_ENC_ABLATE
+  // timing experiments only (make EXTRA=-DMSDA_ENC_ABLATE): bits skip staging / gather / prefetch / stores -- such a
+  // build returns WRONG results and must never ship; the production library has no run-time switch for this
   static const int ablate = getenv("CODETR_MSDA_ENC_ABLATE") ? atoi(getenv("CODETR_MSDA_ENC_ABLATE")) : 0;
-  static bool attr_set[4] = {false, false, false, false};
+#else
+  constexpr int ablate = 0;
+#endif
   const int kmax5 = L * P <= 20;
   auto kern = P == 4 ? (kmax5 ? msda_encoder_kernel<TR, 5, true> : msda_encoder_kernel<TR, 8, true>)
                      : (kmax5 ? msda_encoder_kernel<TR, 5, false> : msda_encoder_kernel<TR, 8, false>);
-  const int ki = kmax5 + 2 * (P == 4);
-  if (!attr_set[ki]) {
-    const hipError_t e =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    if (e != hipSuccess) return (int)e;
-    attr_set[ki] = true;
+  // > 64 KB of dynamic LDS needs the attribute on the CURRENT device's function object: remembered per (device, kernel)
+  // -- a process-wide "already set" flag would skip it when the process moves to a second GPU
+  {
+    static std::atomic<uint32_t> done[64];  // bit = kernel instantiation, index = device ordinal
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done[0].store(0);
+    const uint32_t bit = 1u << (kmax5 + 2 * (P == 4) + 4 * (sizeof(ST) == 2 && std::is_same<TR, BF16>::value));
+    if (!(done[dev].load(std::memory_order_acquire) & bit)) {
+      const hipError_t e =
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+      if (e != hipSuccess) return (int)e;
+      done[dev].fetch_or(bit, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, st, static_cast<const ST*>(value),
                      static_cast<const ST*>(offs), static_cast<const ST*>(logits), static_cast<const ST*>(ref),

@@ -160,6 +160,33 @@ class _Logger:
     info = warning
 
 
+class _DINOHeadStandIn(nn.Module):
+    """Stand-in for mmdet v3.3.0 ``DINOHead`` (-> DeformableDETRHead -> DETRHead constructor chain), reduced to what
+    the reference's ``CoDINOHead`` reads at inference: ``num_classes``, ``cls_out_channels`` (= num_classes when the
+    classification loss uses sigmoid, else + 1: DETRHead.__init__), ``num_reg_fcs`` (2), ``as_two_stage``,
+    ``test_cfg``, ``loss_cls`` (only ``use_sigmoid`` is read), then ``self._init_layers()`` -- which is the REFERENCE's
+    own method (co_dino_head.py:74-118).  Contains no reference code."""
+
+    def __init__(self, num_classes=80, embed_dims=256, num_reg_fcs=2, sync_cls_avg_factor=False, as_two_stage=False,
+                 loss_cls=None, loss_bbox=None, loss_iou=None, train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.embed_dims = embed_dims
+        self.num_reg_fcs = num_reg_fcs
+        self.as_two_stage = as_two_stage
+        self.train_cfg = train_cfg
+        self.test_cfg = _ConfigDict(test_cfg if test_cfg is not None else dict(max_per_img=100))
+        self.loss_cls = _ConfigDict(loss_cls if loss_cls is not None else dict(type="CrossEntropyLoss", use_sigmoid=False))
+        self.cls_out_channels = num_classes if self.loss_cls.get("use_sigmoid", False) else num_classes + 1
+        self._init_layers()
+
+
+def _bbox_cxcywh_to_xyxy(bbox):
+    """mmdet.structures.bbox.bbox_cxcywh_to_xyxy (published formula): (cx, cy, w, h) -> (x1, y1, x2, y2)"""
+    cx, cy, w, h = bbox.split((1, 1, 1, 1), dim=-1)
+    return torch.cat([(cx - 0.5 * w), (cy - 0.5 * h), (cx + 0.5 * w), (cy + 0.5 * h)], dim=-1)
+
+
 def install_shims():
     """Put the third-party stand-ins and the op schemas in place (idempotent)."""
     global _LIB
@@ -240,8 +267,10 @@ def install_shims():
     # --- mmdet (only the names the importable modules touch) ---
     md = _mod("mmdet")
     md.utils = _mod("mmdet.utils", OptMultiConfig=object)
-    md.models = _mod("mmdet.models")
+    md.models = _mod("mmdet.models", DINOHead=_DINOHeadStandIn)
     md.models.layers = _mod("mmdet.models.layers")
+    md.structures = _mod("mmdet.structures")
+    md.structures.bbox = _mod("mmdet.structures.bbox", bbox_cxcywh_to_xyxy=_bbox_cxcywh_to_xyxy)
 
     # --- the reference package itself, bypassing its __init__ ---
     pkg = types.ModuleType("codetr")

@@ -224,6 +224,92 @@ def make_model_goldens():
     _save("model_swin_tiny", img=img, out0=outs[0], out1=outs[1], seed=np.int64(303), **pack_param_spec(spec))
 
 
+def make_head_goldens():
+    """G8: the reference's own ``CoDINOHead.forward`` (co_dino_head.py:120-210: mask pyramid, positional encodings,
+    transformer, last-layer class / box branches, sigmoid, top-k over (query, class), label / box decode, scaling and
+    clamping) on a tiny pyramid, with the mmdet ``DINOHead`` constructor chain and ``bbox_cxcywh_to_xyxy`` supplied by
+    the stand-ins of _ref_import.py.  torch.topk is wrapped during the run to record the proposal selection, so the
+    GPU side can force it equal."""
+    import copy
+
+    hd = R.ref("co_dino_head")
+    cfg = R.transformer_cfg(num_levels=5, num_layers=(2, 2), num_query=40, ffn=64)
+    cfg["type"] = "CoDinoTransformer"
+    cfg.pop("two_stage_num_proposals")
+    torch.manual_seed(0)
+    head = hd.CoDINOHead(num_query=40, transformer=R._ConfigDict(copy.deepcopy(cfg)), num_classes=80, as_two_stage=True,
+                         positional_encoding=R._ConfigDict(type="SinePositionalEncoding", num_feats=128, temperature=20, normalize=True),
+                         loss_cls=dict(type="QualityFocalLoss", use_sigmoid=True, beta=2.0, loss_weight=1.0),
+                         test_cfg=dict(max_per_img=25)).eval()
+    g = torch.Generator().manual_seed(8)
+    shapes_l = [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]
+    B = 2
+    feats = [torch.randn(B, 256, h, w, generator=g) for h, w in shapes_l]
+    img_mask = torch.zeros(B, 48, 64)
+    img_mask[1, :, 52:] = 1
+    img_mask[1, 40:, :] = 1
+    real_topk = torch.topk
+    # with random weights a padded position can win the proposal top-k and its NaN box (reference transformer.py:338)
+    # poisons the image: take the first weight seed whose detections are all finite (padding stays in the case)
+    for seed in range(505, 540):
+        spec = R.randomize_(head, seed, prefix="query_head.")
+        calls = []
+
+        def spy(*a, **k):
+            out = real_topk(*a, **k)
+            calls.append(out[1].clone())
+            return out
+
+        torch.topk = spy
+        try:
+            boxes, scores, labels = head(feats, img_mask)
+        finally:
+            torch.topk = real_topk
+        assert len(calls) == 2 and calls[0].shape == (B, 40) and calls[1].shape == (B, 25)
+        if torch.isfinite(boxes).all() and torch.isfinite(scores).all():
+            break
+    else:
+        raise SystemExit("no seed with finite detections")
+    _save("model_head", img_mask=img_mask, boxes=boxes, scores=scores, labels=labels, proposal_topk=calls[0],
+          detection_topk=calls[1], feat_seed=np.int64(8), seed=np.int64(seed), **pack_param_spec(spec))
+
+
+def make_grad_goldens():
+    """Gradients of the reference's differentiable PyTorch formulation (ops.py:129-186) by torch.autograd in fp64, on
+    the geometry of the reference's own gradient test (tests/test_multi_scale_deformable_attention.py:367-414:
+    N=1, M=2, Lq=2, L=2, P=2, shapes (3,2),(2,1), channels 4 / 30 / 32 / 64 / 71 / 1025) plus one model-shaped case
+    (M=8, D=32, L=5, P=4 with samples outside the maps)."""
+    ops = R.ref("ops")
+    f = ops.multi_scale_deformable_attention_pytorch
+    out = {}
+
+    def case(tag, N, M, D, Lq, shapes, P, seed, spread=False):
+        shapes_t = torch.as_tensor(shapes, dtype=torch.long)
+        S = int(shapes_t.prod(1).sum())
+        L = len(shapes)
+        g = torch.Generator().manual_seed(seed)
+        value = (torch.rand(N, S, M, D, generator=g, dtype=torch.float64) * (1.0 if spread else 0.01))
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=g, dtype=torch.float64)
+        if spread:
+            loc = loc * 1.3 - 0.15
+        w = torch.rand(N, Lq, M, L, P, generator=g, dtype=torch.float64) + 1e-5
+        w = w / w.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        go = torch.randn(N, Lq, M * D, generator=g, dtype=torch.float64)
+        # inputs representable in fp16 so that lower-precision runs differentiate the same function
+        value, loc, w, go = (t.half().double() for t in (value, loc, w, go))
+        v, l_, w_ = (t.clone().requires_grad_(True) for t in (value, loc, w))
+        with torch.enable_grad():
+            y = f(v, shapes_t, l_, w_)
+            gv, gl, gw = torch.autograd.grad(y, (v, l_, w_), go)
+        out.update({f"{tag}.shapes": shapes_t, f"{tag}.value": value, f"{tag}.loc": loc, f"{tag}.w": w, f"{tag}.go": go,
+                    f"{tag}.out": y.detach(), f"{tag}.grad_value": gv, f"{tag}.grad_loc": gl, f"{tag}.grad_w": gw})
+
+    for D in (4, 30, 32, 64, 71, 1025):
+        case(f"c{D}", 1, 2, D, 2, [(3, 2), (2, 1)], 2, seed=100 + D)
+    case("model", 2, 8, 32, 19, [(12, 18), (6, 9), (3, 5), (2, 3), (1, 2)], 4, seed=77, spread=True)
+    _save("msda_grad", **out)
+
+
 def make_key_goldens():
     """state_dict key names + shapes of the reference's Swin-L backbone and Co-DINO transformer built
     from the config values (swin:10-27, lsj:58-101): the checkpoint-compatibility contract."""
@@ -238,17 +324,28 @@ def make_key_goldens():
     t = tr.CoDinoTransformer(**copy.deepcopy(R.transformer_cfg()))
     spec = [("backbone." + k, tuple(v.shape)) for k, v in s.state_dict().items()]
     spec += [("query_head.transformer." + k, tuple(v.shape)) for k, v in t.state_dict().items()]
+    # the head's own parameters as the reference's CoDINOHead._init_layers builds them (co_dino_head.py:95-118:
+    # 7 class / 7 box branches, the unused `downsample`); the mmdet DINOHead constructor chain is a stand-in
+    hd = R.ref("co_dino_head")
+    hcfg = copy.deepcopy(R.transformer_cfg())
+    hcfg["type"] = "CoDinoTransformer"
+    hcfg.pop("two_stage_num_proposals")
+    head = hd.CoDINOHead(num_query=900, transformer=R._ConfigDict(hcfg), num_classes=80, as_two_stage=True,
+                         positional_encoding=R._ConfigDict(type="SinePositionalEncoding", num_feats=128, temperature=20, normalize=True),
+                         loss_cls=dict(type="QualityFocalLoss", use_sigmoid=True), test_cfg=dict(max_per_img=300))
+    spec += [("query_head." + k, tuple(v.shape)) for k, v in head.state_dict().items() if not k.startswith("transformer.")]
     # relative_position_index VALUES of one window (the buffer is part of the checkpoint contract)
     _save("state_dict_keys", rel_index=s.stages[0].blocks[0].attn.w_msa.relative_position_index, **pack_param_spec(spec))
 
 
-GROUPS = {"msda": make_msda_goldens, "model": make_model_goldens, "keys": make_key_goldens}
+GROUPS = {"msda": make_msda_goldens, "model": make_model_goldens, "keys": make_key_goldens, "head": make_head_goldens,
+          "grad": make_grad_goldens}
 
 
 if __name__ == "__main__":
     if not R.reference_available():
         sys.exit("reference tree not found at " + R.REFERENCE_ROOT)
-    torch.set_grad_enabled(False)
+    torch.set_grad_enabled(False)   # (make_grad_goldens re-enables it locally)
     torch.set_num_threads(8)
     which = sys.argv[1:] or list(GROUPS)
     for g in which:

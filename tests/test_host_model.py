@@ -65,11 +65,17 @@ def test_state_dict_matches_reference_keys_and_shapes(swin_l_model):
     for k, shp in ref.items():
         assert k in own, f"reference key {k} missing"
         assert own[k] == shp, (k, own[k], shp)
-    extra = [k for k in own if k.startswith(("backbone.", "query_head.transformer.")) and k not in ref]
+    # backbone, transformer AND the head's own parameters (class / box branches, `downsample`) are pinned by the
+    # reference-built key list: nothing of ours under those prefixes may be missing from it either
+    extra = [k for k in own if k.startswith(("backbone.", "query_head.")) and k not in ref]
     assert not extra, extra
+    assert sum(1 for k in ref if k.startswith("query_head.cls_branches.")) == 14        # 7 x (weight, bias)
+    assert sum(1 for k in ref if k.startswith("query_head.reg_branches.")) == 42        # 7 x 3 Linears
+    assert ref["query_head.downsample.0.weight"] == (256, 256, 3, 3)
     blk = swin_l_model.backbone.stages[0].blocks[0].attn.w_msa
     assert np.array_equal(blk.relative_position_index.numpy(), g["rel_index"])
-    # the remaining keys follow mmdet's names (ConvModule / DINOHead) -- spot-check the contract of SURVEY 8(f)-2
+    # the neck's keys follow mmdet's ConvModule names (mmdet is absent: no reference-built list) -- spot-check the
+    # contract of SURVEY 8(f)-2
     for k in ("neck.convs.0.conv.weight", "neck.convs.3.gn.bias", "neck.extra_convs.0.conv.weight",
               "neck.extra_convs.0.gn.weight", "query_head.cls_branches.6.weight", "query_head.reg_branches.6.4.bias",
               "query_head.reg_branches.0.0.weight", "query_head.downsample.0.weight", "query_head.downsample.1.bias"):

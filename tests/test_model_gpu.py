@@ -255,6 +255,24 @@ def test_forward_is_bit_stable_with_poisoned_allocator(dtype):
     import codetr
     from helpers_model import poison_allocator
 
+    if dtype == torch.float32:
+        # the fp32 parity route runs the neck's convolutions through MIOpen, whose algorithm search changes the
+        # result of the 3x3 / stride-2 extra level between the first call and later ones (tools/diag_fp32_flake.py:
+        # everything up to the backbone output is bit-stable, the neck's last level is the first tensor to move);
+        # pin the library to its deterministic choice so that this test is about OUR kernels
+        saved = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    try:
+        _bit_stable(dtype)
+    finally:
+        if dtype == torch.float32:
+            torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = saved
+
+
+def _bit_stable(dtype):
+    import codetr
+    from helpers_model import poison_allocator
+
     torch.manual_seed(0)
     model = codetr.CoDETR(**_tiny_codetr_cfg("swin"))
     spec = [(k, tuple(v.shape)) for k, v in model.named_parameters()]

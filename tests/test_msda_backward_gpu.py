@@ -1,13 +1,97 @@
-"""GPU parity of the MSDA backward kernel (C ABI codetr_msda_backward_*, torch.ops.codetr.
-multi_scale_deformable_attention_backward + the autograd registration) against PyTorch autograd through a
-differentiable fp64 restatement of the forward (the bilinear formulas of reference ms_deform_attn.cu:31-77 written with
-tensor ops; the reference's own check is `gradcheck` in fp64, tests/test_multi_scale_deformable_attention.py:367-414).
+"""GPU parity of the MSDA backward kernels (C ABI codetr_msda_backward_*, torch.ops.codetr.
+multi_scale_deformable_attention_backward + the autograd registration):
+
+  * against gradients the IMPORTED reference produced (torch.autograd through its differentiable PyTorch formulation,
+    ops.py:129-186; tests/golden/msda_grad.npz) on the reference's own gradient-test geometry for every channel count it
+    checks -- 4, 30, 32, 64, 71, 1025 (tests/test_multi_scale_deformable_attention.py:367-414) -- and a model-shaped case;
+  * by torch.autograd.gradcheck in fp64 with the reference's settings (eps 1e-6, atol 1e-2), same channel counts;
+  * against the closed-form CPU oracle (oracle/msda_backward_oracle.py) and an autograd restatement on further shapes.
+
 fp64: 1e-10 relative; fp32: 1e-4; fp16 (fp32 arithmetic, fp16 atomics / stores): 2e-2 of the gradient scale."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _golden_case(tag):
+    g = np.load(os.path.join(GOLDEN, "msda_grad.npz"))
+    d = {k[len(tag) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".")}
+    ss = d["shapes"]
+    d["level_start"] = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
+    return d
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4), (torch.float16, 2e-2)])
+@pytest.mark.parametrize("tag", ["c4", "c30", "c32", "c64", "c71", "c1025", "model"])
+def test_msda_backward_vs_reference_autograd_golden(tag, dtype, tol):
+    """inputs of the fixture are fp16-representable, so every dtype differentiates the same function"""
+    from codetr import _cabi
+
+    d = _golden_case(tag)
+    ss, ls = d["shapes"].to(DEV), d["level_start"].to(DEV)
+    v, l_, w_ = (d[k].to(dtype).to(DEV).requires_grad_(True) for k in ("value", "loc", "w"))
+    before = _cabi.CALLS["msda_backward"]
+    out = torch.ops.codetr.multi_scale_deformable_attention(v, ss, ls, l_, w_, 64)
+    ftol = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 2e-3}[dtype]
+    assert (out.double().cpu() - d["out"]).abs().max() <= ftol * d["out"].abs().max() + (1e-7 if dtype != torch.float64 else 0)
+    out.backward(d["go"].to(dtype).to(DEV))
+    assert _cabi.CALLS["msda_backward"] == before + 1
+    for name, got, ref in (("value", v.grad, d["grad_value"]), ("loc", l_.grad, d["grad_loc"]), ("w", w_.grad, d["grad_w"])):
+        scale = ref.abs().max().item() + 1e-300
+        err = (got.double().cpu() - ref).abs().max().item()
+        assert err <= tol * scale, f"{tag} grad_{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("channels", [4, 30, 32, 64, 71, 1025])
+def test_gradient_numerical_as_the_reference_does(channels):
+    """the reference's own test (tests/test_multi_scale_deformable_attention.py:367-414): gradcheck in double"""
+    from torch.autograd import gradcheck
+
+    torch.manual_seed(channels)
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(3, 2), (2, 1)], dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = (torch.rand(N, S, M, channels, device=DEV) * 0.01).double().requires_grad_(True)
+    loc = torch.rand(N, Lq, M, L, P, 2, device=DEV).double().requires_grad_(True)
+    aw = torch.rand(N, Lq, M, L, P, device=DEV) + 1e-5
+    aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+    assert gradcheck(torch.ops.codetr.multi_scale_deformable_attention, (value, shapes, lsi, loc, aw, 2), eps=1e-6, atol=1e-2)
+
+
+@pytest.mark.parametrize("D", [30, 71, 96])
+def test_generic_channel_kernel_vs_backward_oracle(D):
+    """the wave-per-pair kernel on a multi-image case with out-of-range samples, against the closed-form CPU oracle"""
+    import msda_backward_oracle as BO
+
+    shapes = [(5, 7), (3, 4)]
+    value, loc, w, go, S, L = _case(2, 3, D, 5, shapes, 3, torch.float64, seed=11, border=True)
+    ss = torch.tensor(shapes, dtype=torch.int64)
+    ls = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
+    gv, gl, gw = BO.msda_backward(value.numpy(), ss.numpy(), ls.numpy(), loc.numpy(), w.numpy(), go.numpy())
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 1e-4)):
+        vd, ld, wd = (t.to(dtype).to(DEV).requires_grad_(True) for t in (value, loc, w))
+        torch.ops.codetr.multi_scale_deformable_attention(vd, ss.to(DEV), ls.to(DEV), ld, wd, 64).backward(go.to(dtype).to(DEV))
+        for name, got, ref in (("value", vd.grad, gv), ("loc", ld.grad, gl), ("w", wd.grad, gw)):
+            ref = torch.from_numpy(ref)
+            assert (got.double().cpu() - ref).abs().max() <= tol * ref.abs().max(), (D, dtype, name)
+
+
+def test_f16_odd_row_is_reported_unsupported():
+    """documented limit of the generic kernel: fp16 value-gradient atomics are packed pairs, M * D must be even"""
+    value, loc, w, go, S, L = _case(1, 1, 71, 2, [(3, 2)], 2, torch.float16, seed=2)
+    ss = torch.tensor([(3, 2)], dtype=torch.int64, device=DEV)
+    ls = torch.zeros(1, dtype=torch.int64, device=DEV)
+    v, l_, w_, g = (t.half().to(DEV) for t in (value, loc, w, go))
+    with pytest.raises(RuntimeError, match="outside what the kernel family implements|unsupported"):
+        torch.ops.codetr.multi_scale_deformable_attention_backward(v, ss, ls, l_, w_, g, torch.zeros_like(v),
+                                                                   torch.zeros_like(l_), torch.zeros_like(w_), 64)
 
 
 def msda_autograd_reference(value, shapes, loc, w):

@@ -67,6 +67,27 @@ def test_transformer_encoder_decoder_with_padding():
     np.testing.assert_allclose(refs.numpy(), g["final_refs_unact"], rtol=2e-4, atol=2e-4)
 
 
+def head_fixture():
+    g = _load("model_head")
+    sd = seeded_params(unpack_param_spec(g), int(g["seed"]))
+    gen = torch.Generator().manual_seed(int(g["feat_seed"]))
+    feats = [torch.randn(2, 256, h, w, generator=gen) for h, w in [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]]
+    return g, sd, feats
+
+
+def test_head_forward_vs_reference_codinohead():
+    """the oracle's head (mask pyramid -> encodings -> transformer -> branches -> top-k -> decode) against the
+    REFERENCE's own CoDINOHead.forward (tests/golden/model_head.npz; only mmdet's DINOHead constructor chain and
+    bbox_cxcywh_to_xyxy were stand-ins when it was captured)"""
+    g, sd, feats = head_fixture()
+    cap = {}
+    boxes, scores, labels = M.head(sd, feats, _t(g["img_mask"]), num_query=40, max_per_img=25, capture=cap)
+    assert np.array_equal(cap["topk_indices"].numpy(), g["proposal_topk"])   # the reference's own proposal selection
+    assert np.array_equal(labels.numpy(), g["labels"])
+    np.testing.assert_allclose(scores.numpy(), g["scores"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(boxes.numpy(), g["boxes"], rtol=1e-4, atol=2e-3)   # pixels of a 64 x 48 image
+
+
 def test_swin_tiny_padding_shift_merging():
     g = _load("model_swin_tiny")
     sd = seeded_params(unpack_param_spec(g), int(g["seed"]), scale=2.0)

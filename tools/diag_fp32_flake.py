@@ -94,22 +94,39 @@ def main():
     picks = valid_topk(cap["enc_outputs_class"].float().cpu(), cap["enc_outputs_coord_unact"].float().cpu(), 50).to(DEV)
     stages = ("backbone_feats", "neck_feats", "memory", "enc_outputs_class", "topk_coords_unact", "final_state",
               "outputs_classes", "outputs_coords")
-    first, unstable = None, {}
-    for it in range(a.same):
-        poison_allocator(DEV)
-        (b, s, l), cap = run(img, mask, picks)
-        d = {k: digest(cap[k]) for k in stages}
-        d.update(boxes=digest(b), scores=digest(s), labels=digest(l))
-        if first is None:
-            first = d
-        else:
-            for k in d:
-                if d[k] != first[k]:
-                    unstable.setdefault(k, []).append(it)
-    report["same_input_runs"] = a.same
-    report["stages_that_changed_bitwise"] = unstable
-    print(f"(A) {a.same} runs of the same input with a NaN-poisoned allocator: "
-          f"{'ALL stages bit-identical' if not unstable else 'UNSTABLE: ' + json.dumps(unstable)}")
+    def stability(tag):
+        first, prev, vs_first, vs_prev = None, None, {}, {}
+        for it in range(a.same):
+            poison_allocator(DEV)
+            (b, s, l), cap = run(img, mask, picks)
+            d = {}
+            for k in stages:   # lists (feature levels) are reported per level
+                v = cap[k]
+                if isinstance(v, (list, tuple)):
+                    d.update({f"{k}[{i}]": digest(x) for i, x in enumerate(v)})
+                else:
+                    d[k] = digest(v)
+            d.update(boxes=digest(b), scores=digest(s), labels=digest(l))
+            if first is not None:
+                for k in d:
+                    if d[k] != first[k]:
+                        vs_first[k] = vs_first.get(k, 0) + 1
+                    if d[k] != prev[k]:
+                        vs_prev[k] = vs_prev.get(k, 0) + 1
+            first = first or d
+            prev = d
+        order = list(d)
+        first_moving = next((k for k in order if k in vs_first), None)
+        report[tag] = {"runs": a.same, "runs_differing_from_run0": vs_first, "runs_differing_from_previous_run": vs_prev,
+                       "first_stage_that_moves": first_moving}
+        print(f"(A/{tag}) {a.same} runs of the same input, NaN-poisoned allocator: "
+              + ("ALL stages bit-identical" if not vs_first else
+                 f"first stage that moves: {first_moving}; vs run 0: {json.dumps(vs_first)}; vs previous run: {json.dumps(vs_prev)}"))
+
+    stability("library_defaults")
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    stability("cudnn_deterministic")
+    torch.backends.cudnn.deterministic = False
 
     # ---- (B) many inputs: the old rounded-set assertion vs tolerance matching
     old_fail, new_fail, sig_ulps, events = 0, 0, 0, []
