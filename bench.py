@@ -123,7 +123,7 @@ def msda_offset_stats(model, images, masks, halo=4):
 
     def find(weight):
         for a in enc_atts:
-            if getattr(a, "_fused_w", None) is weight:
+            if a._fused_projection()[0] is weight:
                 return a
         return None
 
@@ -326,10 +326,15 @@ def cpu_baseline(model, full_hw=(1280, 1920), budget_s=45.0):
     """fp32 CPU oracle on the host cores.  A 608x608 image is timed first (a few seconds); if that predicts the
     full-size image fits the budget, ONE 1920x1280 image -- the workload itself -- is run and reported directly;
     otherwise the 608x608 time is scaled by the pixel ratio (and says so)."""
+    # thread count: the oracle (ATen CPU kernels + the OpenMP C MSDA) is fastest at 16-32 threads on the GPU box's 256
+    # logical CPUs and 4-5x slower at torch's default of 128 (tools/probe_cpu_oracle_threads.py: 0.97 s at 16, 1.08 s
+    # at 32, 4.40 s at 128 for a 384x384 image) -- use what serves it best, and say so in `cores`
+    threads = max(1, min(32, (os.cpu_count() or 8) // 2, torch.get_num_threads()))
+    os.environ["OMP_NUM_THREADS"] = str(threads)   # read by the C oracle's OpenMP runtime when it is loaded below
+    torch.set_num_threads(threads)
     import codetr_fp32 as M
 
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    threads = torch.get_num_threads()
 
     def run(H, W):
         g = torch.Generator().manual_seed(42)

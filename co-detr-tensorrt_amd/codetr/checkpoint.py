@@ -7,8 +7,24 @@ import warnings
 import torch
 
 
-def load_checkpoint(filename, map_location="cpu"):
-    ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+def load_checkpoint(filename, map_location="cpu", allow_pickle=None):
+    """Tensors-and-containers only by default (``weights_only=True``: an mmdet checkpoint needs nothing else --
+    ``state_dict`` + a ``meta`` dict of strings / tuples).  A checkpoint that carries other pickled objects is refused
+    unless the caller opts in with ``allow_pickle=True`` (or CODETR_ALLOW_PICKLE=1): unpickling arbitrary objects runs
+    code from the file."""
+    import os
+    import pickle
+
+    if allow_pickle is None:
+        allow_pickle = os.environ.get("CODETR_ALLOW_PICKLE", "0") == "1"
+    try:
+        ckpt = torch.load(filename, map_location=map_location, weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        if not allow_pickle:
+            raise RuntimeError(
+                f"{filename} holds pickled objects beyond tensors and plain containers ({str(e).splitlines()[0]}); "
+                "pass allow_pickle=True (or set CODETR_ALLOW_PICKLE=1) only for files you trust") from e
+        ckpt = torch.load(filename, map_location=map_location, weights_only=False)
     if not isinstance(ckpt, dict):
         raise RuntimeError(f"No state_dict found in checkpoint file {filename}")
     return ckpt

@@ -229,6 +229,22 @@ def ffn_fused_supported(x, w1, w2, act):
             and _cabi.ffn_fused_supported(x, w1, w2, act))
 
 
+def derived(params, name, build):
+    """A tensor derived from parameter tensors (fused / permuted / gathered weights), built once by `build()` and kept
+    ON the first parameter object under attribute `name` -- so it dies with that parameter instead of sitting in a table
+    keyed by an address the allocator can hand to a different tensor later.  Rebuilt when any source changed: object
+    identity, in-place version counter, storage address (``param.data = ...``, ``.to()``), dtype or device."""
+    first = params[0]
+    key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+    hit = getattr(first, name, None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        val = build()
+    setattr(first, name, (key, val))
+    return val
+
+
 def _packed_w2(w2):
     """the kernel's pre-packed copy of a second-Linear weight.  The copy hangs on the weight tensor object itself
     (so it dies with it: a table keyed by id() / data_ptr() can hand a NEW tensor that reuses a freed tensor's address

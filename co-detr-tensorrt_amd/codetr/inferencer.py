@@ -51,6 +51,7 @@ class Inferencer:
         self.mean = tuple(float(v) for v in pre.get("mean", (0.0, 0.0, 0.0)))
         self.std = tuple(float(v) for v in pre.get("std", (1.0, 1.0, 1.0)))
         self.pad_size_divisor = int(pre.get("pad_size_divisor", 1))
+        self.pad_value = float(pre.get("pad_value", 0))   # DetDataPreprocessor: fills the divisor padding, AFTER normalisation
         # test pipeline: Resize(scale, keep_ratio) [+ Pad(size, pad_val)]
         self.scale, self.pad_size, self.pad_val = None, None, (0, 0, 0)
         for step in self.cfg.test_dataloader.dataset.pipeline:
@@ -78,11 +79,17 @@ class Inferencer:
         Hp, Wp = nh, nw
         if self.pad_size is not None:
             Wp, Hp = max(self.pad_size[0], nw), max(self.pad_size[1], nh)
-        d = self.pad_size_divisor
-        if d > 1:
-            Hp, Wp = -(-Hp // d) * d, -(-Wp // d) * d
         src = torch.from_numpy(np.ascontiguousarray(image)).to(device, non_blocking=True)
+        # the pipeline's Pad: pad_val pixels, normalised with the image (mmdet Pad runs before DetDataPreprocessor)
         x, m = hip_ops.preprocess_image(src, (nh, nw), (Hp, Wp), self.mean, self.std, self.pad_val, dtype)
+        d = self.pad_size_divisor
+        if d > 1 and (Hp % d or Wp % d):
+            # DetDataPreprocessor's own padding to a multiple of pad_size_divisor: applied to the NORMALISED tensor
+            # and filled with pad_value (default 0), not with normalised pad_val pixels; the mask marks it as padding
+            Hd, Wd = -(-Hp // d) * d, -(-Wp // d) * d
+            x = torch.nn.functional.pad(x, (0, Wd - Wp, 0, Hd - Hp), value=self.pad_value)
+            m = torch.nn.functional.pad(m, (0, Wd - Wp, 0, Hd - Hp), value=1.0)
+            Hp, Wp = Hd, Wd
         meta = dict(ori_shape=(H, W), img_shape=(nh, nw), img_unpadded_shape=(nh, nw), pad_shape=(Hp, Wp),
                     scale_factor=(nw / W, nh / H))
         return x[None], m[None], meta

@@ -3,8 +3,9 @@ codetr/multi_scale_deformable_attention.py:15-218 (same constructor kwargs, para
 forward signature, error behaviour), computing on MI355X through ``codetr.hip_ops``.
 
 Differences by design:
-* GPU only: the reference switches to a ``grid_sample`` formulation for CPU tensors (:207-210);
-  here a CPU tensor is an error (hip_ops), the CPU formulation is the oracle's job.
+* CPU tensors take ``_forward_cpu`` -- plain ``torch.nn.functional`` linears + ``ops.multi_scale_deformable_attention_
+  pytorch`` -- as the reference's module does (:203-210); everything on a HIP device goes through ``hip_ops`` and the
+  hand-written kernels, never through that branch.
 * internally batch-first: ``forward_bf`` is what the encoder/decoder call; ``forward`` keeps the
   reference's sequence-first default and just permutes around it.
 """
@@ -88,13 +89,8 @@ class MultiScaleDeformableAttention(nn.Module):
         input, so they run as a single GEMM.  Rebuilt only when a parameter tensor changes."""
         ws = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
               self.attention_weights.bias)
-        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ws)
-        if getattr(self, "_fused_key", None) != key:
-            with torch.no_grad():
-                self._fused_w = torch.cat((ws[0], ws[2]), 0).contiguous()
-                self._fused_b = torch.cat((ws[1], ws[3]), 0).contiguous()
-            self._fused_key = key
-        return self._fused_w, self._fused_b
+        return hip_ops.derived(ws, "_codetr_fused_proj", lambda: (torch.cat((ws[0], ws[2]), 0).contiguous(),
+                                                                  torch.cat((ws[1], ws[3]), 0).contiguous()))
 
     # ------------------------------------------------------------------ batch-first core
     def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
@@ -103,6 +99,9 @@ class MultiScaleDeformableAttention(nn.Module):
         query_plus_pos: `query + query_pos` if the caller already holds it.  value_projected [B,S,C]: this module's
         value_proj(value) with the padding mask applied, if the caller already computed it (the decoder projects the
         memory for all its layers in one GEMM)."""
+        if not query.is_cuda:
+            return self._forward_cpu(query if query_plus_pos is None else None, query_plus_pos, value, identity, query_pos,
+                                     key_padding_mask, reference_points, spatial_shapes, value_projected)
         pos_in_gemm = None   # query_pos still to be added: folded into the (offsets | logits) GEMM where that applies
         if query_plus_pos is not None:
             query = query_plus_pos
@@ -166,6 +165,37 @@ class MultiScaleDeformableAttention(nn.Module):
         out = hip_ops.msda(v.contiguous(), spatial_shapes, level_start_index, loc.contiguous(), weights.contiguous(),
                            self.im2col_step)
         return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
+
+    def _forward_cpu(self, query, query_plus_pos, value, identity, query_pos, key_padding_mask, reference_points,
+                     spatial_shapes, value_projected=None):
+        """CPU tensors only (reference :161-218 with the PyTorch formulation of the op, :207-210)."""
+        import torch.nn.functional as F
+
+        from .ops import multi_scale_deformable_attention_pytorch
+
+        q = query_plus_pos if query_plus_pos is not None else (query + query_pos if query_pos is not None else query)
+        B, Nq, _ = q.shape
+        S = value.shape[1]
+        H, L, P = self.num_heads, self.num_levels, self.num_points
+        if int(spatial_shapes.prod(1).sum()) != S:
+            raise AssertionError("spatial_shapes do not add up to the number of keys")
+        if value_projected is not None:
+            v = value_projected
+        else:
+            v = F.linear(value, self.value_proj.weight, self.value_proj.bias)
+            if key_padding_mask is not None:
+                v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        v = v.view(B, S, H, -1)
+        off = F.linear(q, self.sampling_offsets.weight, self.sampling_offsets.bias).view(B, Nq, H, L, P, 2)
+        aw = F.linear(q, self.attention_weights.weight, self.attention_weights.bias).view(B, Nq, H, L * P)
+        aw = aw.softmax(-1).view(B, Nq, H, L, P)
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack((spatial_shapes[..., 1], spatial_shapes[..., 0]), -1).to(off.dtype)
+            loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+        else:
+            loc = reference_points[:, :, None, :, None, :2] + off / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        out = multi_scale_deformable_attention_pytorch(v, spatial_shapes, loc, aw)
+        return F.linear(out, self.output_proj.weight, self.output_proj.bias) + identity
 
     def takes_pos_in_gemm(self, query, query_pos, value):
         """True when forward_bf adds `query_pos` inside the (offsets | logits) GEMM (so nobody needs to materialise

@@ -103,11 +103,7 @@ class ChannelMapper(nn.Module):
 
     def _extra_weight_kkc(self, w):
         """[Cout, Cin, 3, 3] conv weight as a [Cout, 9*Cin] GEMM weight with K ordered (ky, kx, c); cached"""
-        key = (w.data_ptr(), w._version, w.dtype, str(w.device))
-        hit = getattr(self, "_kkc_cache", None)
-        if hit is None or hit[0] != key:
-            hit = self._kkc_cache = (key, w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
-        return hit[1]
+        return hip_ops.derived((w,), "_codetr_kkc", lambda: w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
 
     def forward(self, inputs):
         if len(inputs) != len(self.convs):

@@ -7,9 +7,12 @@ Host-side mirror of the reference's operator layer for the inference hot path:
 * the implementation is registered for dispatch key ``CUDA`` -- the key PyTorch-ROCm uses for
   HIP tensors -- exactly as the reference registers its CUDA kernel
   (deformable_attention_torch.cpp:28-31).  No other key is registered: calling the op with CPU
-  tensors fails in the dispatcher, as it does in the reference.  There is deliberately NO
-  PyTorch/CPU formulation of the op in this package (the reference's ``grid_sample`` version,
-  ops.py:129-186, lives only in ``oracle/`` as the parity checker);
+  tensors fails in the dispatcher, as it does in the reference.  The reference's second, device-agnostic entry
+  point -- ``multi_scale_deformable_attention_pytorch`` (ops.py:129-186), which its ``MultiScaleDeformableAttention``
+  module dispatches to for CPU tensors (multi_scale_deformable_attention.py:203-210) -- exists here too, with the same
+  signature, written independently as an explicit corner gather (not ``grid_sample``, and not the oracle: nothing in
+  this package imports ``oracle/``).  It serves CPU tensors ONLY; a HIP tensor never reaches it, and a missing
+  ``libcodetr_hip.so`` is still an ImportError of the whole package;
 * the fake/meta kernel performs the reference's rank / dtype / shape checks and returns an
   empty ``(bs, num_queries, embed_dims)`` tensor (reference codetr/ops.py:19-87);
 * the argument contract enforced before the launch is the reference's AT_ASSERTM list
@@ -24,7 +27,7 @@ from torch import Tensor
 
 from . import _cabi
 
-__all__ = ["multi_scale_deformable_attention"]
+__all__ = ["multi_scale_deformable_attention", "multi_scale_deformable_attention_pytorch"]
 
 _FWD_SCHEMA = (
     "multi_scale_deformable_attention(Tensor value, Tensor spatial_shapes, "
@@ -186,3 +189,40 @@ def multi_scale_deformable_attention(value, spatial_shapes, level_start_index, s
     return torch.ops.codetr.multi_scale_deformable_attention(
         value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step
     )
+
+
+def multi_scale_deformable_attention_pytorch(value: Tensor, value_spatial_shapes: Tensor, sampling_locations: Tensor,
+                                             attention_weights: Tensor) -> Tensor:
+    """Device-agnostic PyTorch formulation with the signature of reference codetr/ops.py:129-186 (the path the
+    reference's module takes for CPU tensors).  value [bs, num_keys, M, D]; value_spatial_shapes [L, 2] (h, w);
+    sampling_locations [bs, Nq, M, L, P, 2] (x, y in [0, 1]); attention_weights [bs, Nq, M, L, P] -> [bs, Nq, M*D].
+
+    Written as the kernel computes it (ms_deform_attn.cu:31-77, 246-252) rather than through ``grid_sample``: pixel
+    coordinates ``loc * size - 0.5``, the (-1, size) range gate, four corners with per-corner bounds tests, weights
+    ``hh*hw, hh*lw, lh*hw, lh*lw``, attention-weighted sum over levels and points.  Differentiable."""
+    bs, _, M, D = value.shape
+    _, Nq, _, L, P, _ = sampling_locations.shape
+    shapes = [(int(h), int(w)) for h, w in value_spatial_shapes.tolist()]
+    out = value.new_zeros(bs, Nq, M, D)
+    b_idx = torch.arange(bs, device=value.device).view(bs, 1, 1, 1)
+    m_idx = torch.arange(M, device=value.device).view(1, 1, M, 1)
+    start = 0
+    for lvl, (H, W) in enumerate(shapes):
+        v = value[:, start:start + H * W]                        # [bs, H*W, M, D]
+        start += H * W
+        x = sampling_locations[:, :, :, lvl, :, 0] * W - 0.5     # [bs, Nq, M, P]
+        y = sampling_locations[:, :, :, lvl, :, 1] * H - 0.5
+        inside = (y > -1) & (x > -1) & (y < H) & (x < W)
+        x0, y0 = torch.floor(x), torch.floor(y)
+        lx, ly = x - x0, y - y0
+        x0, y0 = x0.long(), y0.long()
+        acc = 0
+        for dy, wy in ((0, 1 - ly), (1, ly)):
+            for dx, wx in ((0, 1 - lx), (1, lx)):
+                xi, yi = x0 + dx, y0 + dy
+                ok = inside & (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)
+                pix = yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)
+                corner = v[b_idx, pix, m_idx]                    # [bs, Nq, M, P, D]
+                acc = acc + (wy * wx * ok.to(value.dtype)).unsqueeze(-1) * corner
+        out = out + (acc * attention_weights[:, :, :, lvl, :].unsqueeze(-1)).sum(3)
+    return out.reshape(bs, Nq, M * D)

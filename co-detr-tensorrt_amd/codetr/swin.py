@@ -101,17 +101,16 @@ class PatchMerging(nn.Module):
         """(norm.weight, norm.bias, reduction.weight) with the 4C axis re-ordered from (c, ky, kx) to (ky, kx, c);
         rebuilt only when a parameter tensor changes"""
         ps = [self.reduction.weight] + ([self.norm.weight, self.norm.bias] if self.norm is not None else [])
-        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
-        hit = getattr(self, "_perm_cache", None)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                # new index (k, c) <- old index c*4 + k
-                idx = (torch.arange(C, device=ps[0].device)[None, :] * 4 + torch.arange(4, device=ps[0].device)[:, None]).reshape(-1)
-                rw = self.reduction.weight.detach()[:, idx].contiguous()
-                nw = self.norm.weight.detach()[idx].contiguous() if self.norm is not None else None
-                nb = self.norm.bias.detach()[idx].contiguous() if self.norm is not None else None
-            hit = self._perm_cache = (key, (nw, nb, rw))
-        return hit[1]
+
+        def build():
+            # new index (k, c) <- old index c*4 + k
+            idx = (torch.arange(C, device=ps[0].device)[None, :] * 4 + torch.arange(4, device=ps[0].device)[:, None]).reshape(-1)
+            rw = self.reduction.weight.detach()[:, idx].contiguous()
+            nw = self.norm.weight.detach()[idx].contiguous() if self.norm is not None else None
+            nb = self.norm.bias.detach()[idx].contiguous() if self.norm is not None else None
+            return nw, nb, rw
+
+        return hip_ops.derived(ps, "_codetr_perm", build)
 
 
 class WindowMSA(nn.Module):
@@ -132,20 +131,16 @@ class WindowMSA(nn.Module):
         self.register_buffer("relative_position_index", index.contiguous())
         self.qkv = nn.Linear(embed_dims, embed_dims * 3, bias=qkv_bias)
         self.proj = nn.Linear(embed_dims, embed_dims)
-        self._bias_cache = None
 
     def init_weights(self):
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
     def relative_position_bias(self):
-        """[nH, N, N] gathered bias, cached until the table tensor changes (eval: never)."""
+        """[nH, N, N] gathered bias, cached on the table parameter until it changes (eval: never)."""
         t = self.relative_position_bias_table
-        key = (t.data_ptr(), t._version, t.dtype, t.device)
-        if self._bias_cache is None or self._bias_cache[0] != key:
-            N = self.window_size[0] * self.window_size[1]
-            bias = t[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1).contiguous()
-            self._bias_cache = (key, bias.detach())
-        return self._bias_cache[1]
+        N = self.window_size[0] * self.window_size[1]
+        return hip_ops.derived((t,), "_codetr_rel_bias", lambda: t[self.relative_position_index.view(-1)].view(N, N, -1)
+                               .permute(2, 0, 1).contiguous().detach())
 
     def forward(self, x, mask=None):
         """x [nW*B, N, C] -> [nW*B, N, C]."""
@@ -330,6 +325,40 @@ class SwinTransformer(nn.Module):
                 nn.init.zeros_(m.bias)
             elif isinstance(m, WindowMSA):
                 m.init_weights()
+
+    def load_pretrained(self, checkpoint):
+        """Backbone initialisation from a pretrained checkpoint (reference :670-723): ``state_dict`` / ``model`` /
+        bare dict; official-Swin key names converted when ``convert_weights`` (swin_converter); ``backbone.`` and
+        ``module.`` prefixes stripped; relative-position bias tables of another window size resized bicubically
+        (:705-720: [L1, nH] -> [1, nH, S1, S1] -> bicubic to S2 x S2 -> [L2, nH]); non-strict load."""
+        sd = checkpoint.get("state_dict", checkpoint.get("model", checkpoint)) if isinstance(checkpoint, dict) else checkpoint
+        if self.convert_weights:
+            sd = swin_converter(sd)
+        state = OrderedDict()
+        for k, v in sd.items():
+            if k.startswith("backbone."):
+                state[k[9:]] = v
+        if not state:   # a bare backbone state dict
+            state = OrderedDict(sd)
+        if state and next(iter(state)).startswith("module."):
+            state = OrderedDict((k[7:], v) for k, v in state.items())
+        own = self.state_dict()
+        for key in [k for k in state if "relative_position_bias_table" in k and k in own]:
+            pre, cur = state[key], own[key]
+            (L1, nH1), (L2, nH2) = pre.shape, cur.shape
+            if nH1 != nH2:
+                warnings.warn(f"Error in loading {key}, pass")
+                state.pop(key)
+            elif L1 != L2:
+                S1, S2 = int(L1 ** 0.5), int(L2 ** 0.5)
+                r = F.interpolate(pre.permute(1, 0).reshape(1, nH1, S1, S1).float(), size=(S2, S2), mode="bicubic")
+                state[key] = r.view(nH2, L2).permute(1, 0).contiguous().to(pre.dtype)
+        # the index buffers are functions of the window size alone (rebuilt by the constructor): a checkpoint's copy
+        # for another window size cannot be loaded and is not needed
+        for key in [k for k in state if k.endswith("relative_position_index") and k in own
+                    and tuple(state[k].shape) != tuple(own[k].shape)]:
+            state.pop(key)
+        return self.load_state_dict(state, strict=False)
 
     def forward_tokens(self, x):
         """[B,3,H,W] -> list of (tokens [B, H_i*W_i, C_i], (H_i, W_i)) for i in out_indices: the stage outputs

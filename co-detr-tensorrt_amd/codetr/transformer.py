@@ -173,15 +173,11 @@ class DinoTransformerDecoder(nn.Module):
                 or memory.shape[0] * memory.shape[1] < 128 * 256):
             return None
         ps = [p for a in atts for p in (a.value_proj.weight, a.value_proj.bias)]
-        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
-        hit = getattr(self, "_vproj_cache", None)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                hit = self._vproj_cache = (key, torch.cat([a.value_proj.weight for a in atts], 0).contiguous(),
-                                           torch.cat([a.value_proj.bias for a in atts], 0).contiguous())
+        hit = hip_ops.derived(ps, "_codetr_vproj_all", lambda: (torch.cat([a.value_proj.weight for a in atts], 0).contiguous(),
+                                                                torch.cat([a.value_proj.bias for a in atts], 0).contiguous()))
         B, S, K = memory.shape
         mask = None if key_padding_mask is None else key_padding_mask.reshape(1, B * S)
-        y = hip_ops.linear(memory.reshape(1, B * S, K), hit[1], hit[2], row_mask=mask, head_major=C)  # [1, layers, B*S, C]
+        y = hip_ops.linear(memory.reshape(1, B * S, K), hit[0], hit[1], row_mask=mask, head_major=C)  # [1, layers, B*S, C]
         return [y[0, i].view(B, S, C) for i in range(len(atts))]
 
     def forward(self, query, *args, reference_points=None, valid_ratios=None, reg_branches=None, **kwargs):

@@ -66,7 +66,7 @@ struct BF16 {
 };
 
 struct EncGeom {
-  int L, P, M, halo, RX, RY, S, rows_cap, slots_cap;
+  int L, P, M, halo, RX, RY, S, rows_cap, slots_cap, band;
   int H[kMaxL], W[kMaxL], start[kMaxL];
   float invH[kMaxL], invW[kMaxL];  // 1.0f / H, 1.0f / W, correctly rounded (what the general kernel divides out)
 };
@@ -137,7 +137,7 @@ __device__ __forceinline__ void load_raw(Raw<TR, KMAX>& raw, const typename TR::
     const typename TR::storage* pr = ref + row * L * 2;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-      if (k < L) {
+      if (k < L) {   // (L == KMAX in the LFULL instantiation: the launcher passes L as a literal-equal value)
         raw.o[k] = *reinterpret_cast<const typename R::S2*>(po + 8 * k);
         raw.r[k] = *reinterpret_cast<const typename R::S2*>(pr + 2 * k);
         raw.w[k] = pg[4 * k];
@@ -188,7 +188,10 @@ __device__ __forceinline__ int slot_query(const int* __restrict__ s_meta, int L,
 
 // One iteration of a wave: 16 queries x this head.  raw = the quad's share of the offsets / logits / reference
 // points of query q; the region's neighbourhoods are in `patch`, described by s_meta.
-template <class TR, int KMAX, bool P4>
+// LFULL (P4 only): num_levels == KMAX, so the gather loops carry no run-time level test and unroll into straight-line
+// code with a static register assignment (with the test the compiler kept both row buffers alive across a loop and
+// shuffled them with 24 v_mov per 4 points: ~15 % of the kernel's vector instructions).
+template <class TR, int KMAX, bool P4, bool LFULL>
 __device__ __forceinline__ void process_queries(const Raw<TR, KMAX>& raw, const int q, const bool valid,
                                                 const int* __restrict__ s_meta, const unsigned char* __restrict__ patch,
                                                 const unsigned char* __restrict__ vimg, const unsigned pix_bytes,
@@ -201,7 +204,7 @@ __device__ __forceinline__ void process_queries(const Raw<TR, KMAX>& raw, const 
   // -- softmax over the pair's logits (quad reductions), as build_entries does --
   float pw_[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) pw_[k] = (P4 ? k < L : sub + 4 * k < LP) ? TR::to_f32(raw.w[k]) : -INFINITY;
+  for (int k = 0; k < KMAX; ++k) pw_[k] = (P4 ? (LFULL || k < L) : sub + 4 * k < LP) ? TR::to_f32(raw.w[k]) : -INFINITY;
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) mx = fmaxf(mx, pw_[k]);
@@ -233,7 +236,7 @@ __device__ __forceinline__ void process_queries(const Raw<TR, KMAX>& raw, const 
       wt[k][c] = 0.f;
     }
     hw[k] = 0;
-    if ((P4 ? k < L : pt < LP) && !(ablate & 16)) {
+    if ((P4 ? (LFULL || k < L) : pt < LP) && !(ablate & 16)) {
       typedef int i32x4 __attribute__((ext_vector_type(4)));
       const int* mt = s_meta + (P4 ? k : pt / P) * kMetaInts;
       const i32x4 mA = *reinterpret_cast<const i32x4*>(mt);       // H, W, start, px0
@@ -324,10 +327,13 @@ __device__ __forceinline__ void process_queries(const Raw<TR, KMAX>& raw, const 
         }
       };
       fetch(0, 0);
+      // the checked variant keeps its run-time level test on purpose: straight-line, its conditional global re-reads
+      // make the compiler sink all 640 FMAs below all 20 fetches (320 row registers -> spills)
+      constexpr bool STATIC = LFULL && !CHECK;
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_) {
-        if ((s_ >> 1) < L) {
-          if (s_ + 1 < NS && ((s_ + 1) >> 1) < L) fetch(s_ + 1, (s_ + 1) & 1);
+        if (STATIC || (s_ >> 1) < L) {
+          if (s_ + 1 < NS && (STATIC || ((s_ + 1) >> 1) < L)) fetch(s_ + 1, (s_ + 1) & 1);
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -335,6 +341,9 @@ __device__ __forceinline__ void process_queries(const Raw<TR, KMAX>& raw, const 
 #pragma unroll
               for (int j = 0; j < 8; ++j)
                 acc[j] = __builtin_fmaf(ww[s_ & 1][u][c], TR::to_f32(rows[s_ & 1][u][c][j]), acc[j]);
+          // straight-line code (LFULL): keep the written order -- rows of step s + 1 requested, then the FMAs of step
+          // s -- instead of letting the scheduler hoist every later step's reads (register spills)
+          if (STATIC) __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
@@ -421,6 +430,12 @@ struct TileId {
   int rx, ry, m;
 };
 // tile -> (image, region row / column, head); tile < 2^22 (host-checked), so the cheap division applies
+// Regions are walked in horizontal BANDS of kBand region rows, column by column inside a band: vertically adjacent
+// regions (whose neighbourhoods overlap by 2 * halo + 1 of ~2 * halo + 9 rows) run back to back on one XCD, so the
+// overlap is an L2 hit instead of a second trip over the fabric -- a raster walk re-fetched every value row about twice
+// (FETCH_SIZE 1.47 x the algorithmic bytes); 4 region rows x the 8 heads of a column = 2.3 MB of neighbourhoods in
+// flight per XCD, inside its 4 MB L2.
+constexpr int kBand = 4;   // default; CODETR_MSDA_BAND overrides (A/B switch, 1 = raster walk; results do not depend on it)
 __device__ __forceinline__ TileId decode_tile(unsigned tile, const EncGeom& g) {
   TileId t;
   const int unit = fdiv((int)tile, g.M);
@@ -429,8 +444,14 @@ __device__ __forceinline__ TileId decode_tile(unsigned tile, const EncGeom& g) {
   const int b = fdiv(unit, regions);
   const int reg = unit - b * regions;
   t.b = (unsigned)b;
-  t.ry = fdiv(reg, g.RX);
-  t.rx = reg - t.ry * g.RX;
+  const int kBand = g.band;
+  const int per_band = kBand * g.RX;
+  const int band = fdiv(reg, per_band);
+  const int r = reg - band * per_band;
+  const int y0 = band * kBand;
+  const int bh = min(kBand, g.RY - y0);   // the last band may be shorter
+  t.rx = fdiv(r, bh);
+  t.ry = y0 + (r - t.rx * bh);
   return t;
 }
 
@@ -481,7 +502,7 @@ constexpr int kAhead = 2;                           // iterations of a wave whos
 //   geometry -> LDS | barrier | raw operands of the wave's first iterations requested | LDS-DMA of the neighbourhoods |
 //   barrier | the wave's iterations (operands of iteration it + kAhead requested before iteration it is consumed).
 // Two workgroups share a CU (73 KB of LDS each at the model shape): one gathers while the other waits for its DMA.
-template <class TR, int KMAX, bool P4>
+template <class TR, int KMAX, bool P4, bool LFULL = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void msda_encoder_kernel(
     const typename TR::storage* __restrict__ value, const typename TR::storage* __restrict__ offs,
     const typename TR::storage* __restrict__ logits, const typename TR::storage* __restrict__ ref,
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
       load_raw<TR, KMAX, P4>(raws[kAhead - 1], offs, logits, ref, row0 + qs[kAhead - 1], t.m, sub, L, P, off_stride,
                              logit_stride);
     }
-    process_queries<TR, KMAX, P4>(raw, q, valid, s_meta, patch, vimg, pix_bytes, out, out_row, L, P, M, sub, ablate);
+    process_queries<TR, KMAX, P4, LFULL>(raw, q, valid, s_meta, patch, vimg, pix_bytes, out, out_row, L, P, M, sub, ablate);
   }
 }
 
@@ -634,8 +655,12 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
 #else
   constexpr int ablate = 0;
 #endif
+  static const int band_env = [] { const char* e = getenv("CODETR_MSDA_BAND"); return e ? atoi(e) : kBand; }();
+  static const bool static_env = [] { const char* e = getenv("CODETR_MSDA_STATIC"); return e ? atoi(e) != 0 : true; }();
+  g.band = band_env < 1 ? 1 : (band_env > 64 ? 64 : band_env);
   const int kmax5 = L * P <= 20;
-  auto kern = P == 4 ? (kmax5 ? msda_encoder_kernel<TR, 5, true> : msda_encoder_kernel<TR, 8, true>)
+  auto kern = P == 4 ? (kmax5 ? (L == 5 && static_env ? msda_encoder_kernel<TR, 5, true, true> : msda_encoder_kernel<TR, 5, true>)
+                              : msda_encoder_kernel<TR, 8, true>)
                      : (kmax5 ? msda_encoder_kernel<TR, 5, false> : msda_encoder_kernel<TR, 8, false>);
   // > 64 KB of dynamic LDS needs the attribute on the CURRENT device's function object: remembered per (device, kernel)
   // -- a process-wide "already set" flag would skip it when the process moves to a second GPU
@@ -643,7 +668,7 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
     static std::atomic<uint32_t> done[64];  // bit = kernel instantiation, index = device ordinal
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done[0].store(0);
-    const uint32_t bit = 1u << (kmax5 + 2 * (P == 4) + 4 * (sizeof(ST) == 2 && std::is_same<TR, BF16>::value));
+    const uint32_t bit = 1u << (kmax5 + 2 * (P == 4) + 4 * (P == 4 && L == 5 && static_env) + 8 * std::is_same<TR, BF16>::value);
     if (!(done[dev].load(std::memory_order_acquire) & bit)) {
       const hipError_t e =
           hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);

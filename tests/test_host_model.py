@@ -125,11 +125,51 @@ def test_msda_module_contract():
     b = m.sampling_offsets.bias.view(8, 5, 4, 2)
     torch.testing.assert_close(b[0, :, :, 0], torch.arange(1.0, 5.0).expand(5, 4))
     assert float(b[0, :, :, 1].abs().max()) < 1e-6
-    # the product never computes on the CPU
-    q = torch.zeros(3, 1, 256)
+    # hip_ops itself never computes on the CPU (the module's CPU dispatch is its own torch-only branch, tested below)
+    from codetr import hip_ops
+
     with pytest.raises(RuntimeError, match="MI355X only"):
-        m(q, reference_points=torch.zeros(1, 3, 5, 2), spatial_shapes=torch.ones(5, 2, dtype=torch.long),
-          level_start_index=torch.zeros(5, dtype=torch.long))
+        hip_ops.linear(torch.zeros(3, 256), m.value_proj.weight, m.value_proj.bias)
+
+
+def test_msda_module_cpu_dispatch_vs_reference_module():
+    """CPU tensors take the module's torch-only branch + ops.multi_scale_deformable_attention_pytorch, as the
+    reference's module does (multi_scale_deformable_attention.py:203-210); checked against outputs captured from the
+    REFERENCE's module (tests/golden/model_msda_module.npz, 2-d and 4-d reference points, padding mask)."""
+    from codetr.multi_scale_deformable_attention import MultiScaleDeformableAttention
+    from helpers_model import seeded_params
+
+    g = np.load(os.path.join(GOLDEN, "model_msda_module.npz"))
+    m = MultiScaleDeformableAttention(embed_dims=256, num_levels=5, dropout=0.0).eval()
+    m.load_state_dict(seeded_params(unpack_param_spec(g), int(g["seed"])))
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    ss, ls = t("spatial_shapes"), t("level_start_index")
+    with torch.no_grad():
+        out2 = m(t("value"), value=None, query_pos=t("query_pos"), key_padding_mask=t("key_padding_mask"),
+                 reference_points=t("ref2"), spatial_shapes=ss, level_start_index=ls)
+        out4 = m(t("query4"), value=t("value"), query_pos=t("query_pos4"), key_padding_mask=t("key_padding_mask"),
+                 reference_points=t("ref4"), spatial_shapes=ss, level_start_index=ls)
+    np.testing.assert_allclose(out2.numpy(), g["out2"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out4.numpy(), g["out4"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["msda_g1", "msda_g2", "msda_g3_dec"])
+def test_pytorch_formulation_of_the_op_vs_reference_goldens(name):
+    """ops.multi_scale_deformable_attention_pytorch (explicit corner gather) against the reference's own outputs"""
+    from codetr.ops import multi_scale_deformable_attention_pytorch as f
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    t = lambda k: torch.from_numpy(np.asarray(g[k]))  # noqa: E731
+    out = f(t("value").double(), t("spatial_shapes"), t("sampling_loc").double(), t("attn_weight").double())
+    ref = g["out_f64"] if "out_f64" in g.files else g["out"]
+    # (the g3 fixture stores its inputs rounded to fp32 next to an output computed before the rounding)
+    tol = 1e-9 if name != "msda_g3_dec" else 1e-6
+    np.testing.assert_allclose(out.numpy(), ref, rtol=tol, atol=tol * 1e-2)
+    # differentiable, like the reference's formulation (torch.autograd.gradcheck is what its test runs on the op)
+    v = t("value").double()[:, :, :1, :2].clone().requires_grad_(True)
+    loc = t("sampling_loc").double()[:, :2, :1].clone().requires_grad_(True)
+    w = t("attn_weight").double()[:, :2, :1].clone().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, b, c: f(a, t("spatial_shapes"), b, c), (v, loc, w), eps=1e-6, atol=1e-4)
 
 
 def test_swin_converter_known_answer():
@@ -148,3 +188,79 @@ def test_swin_converter_known_answer():
     exp = torch.tensor([norm[p * C + c] for c in range(C) for p in (0, 2, 1, 3)])
     torch.testing.assert_close(out["backbone.stages.0.downsample.norm.weight"], exp)
     torch.testing.assert_close(out["backbone.stages.0.downsample.reduction.weight"][1], red[1][exp.long()])
+
+
+def test_derived_weight_cache_lives_on_the_parameter_and_tracks_changes():
+    """hip_ops.derived: rebuilt on in-place edits, on `param.data = ...` and when the parameter object is
+    replaced; not rebuilt otherwise; gone with the parameter."""
+    from codetr import hip_ops
+
+    lin = torch.nn.Linear(4, 3)
+    calls = []
+
+    def get():
+        w = lin.weight
+        return hip_ops.derived((w, lin.bias), "_t_cache", lambda: (calls.append(1), w.detach().clone() * 2)[1])
+
+    a = get()
+    assert get() is a and len(calls) == 1
+    with torch.no_grad():
+        lin.weight.mul_(3.0)                       # in-place: version counter
+    b = get()
+    assert len(calls) == 2 and torch.equal(b, lin.weight.detach() * 2)
+    lin.weight.data = torch.ones(3, 4)             # storage swap, same object, same version
+    c = get()
+    assert len(calls) == 3 and torch.equal(c, torch.full((3, 4), 2.0))
+    lin.bias = torch.nn.Parameter(torch.zeros(3))  # a source other than the owner is replaced
+    get()
+    assert len(calls) == 4
+    lin.weight = torch.nn.Parameter(torch.ones(3, 4))   # the owner is replaced: the cache went with the old object
+    assert not hasattr(lin.weight, "_t_cache")
+    get()
+    assert len(calls) == 5
+
+
+def test_swin_load_pretrained_resizes_relative_position_tables():
+    """reference swin.py:705-720: a table trained with another window size is resized bicubically, [L1,nH] ->
+    [1,nH,S1,S1] -> (S2,S2) -> [L2,nH]; official-Swin key names are converted when convert_weights is set"""
+    from codetr.swin import SwinTransformer
+
+    kw = dict(embed_dims=32, depths=(2, 2), num_heads=(1, 2), strides=(4, 2), out_indices=(0, 1), patch_norm=True)
+    src = SwinTransformer(window_size=4, **kw)
+    src.init_weights()
+    dst = SwinTransformer(window_size=6, **kw)
+    res = dst.load_pretrained({"state_dict": {"backbone." + k: v for k, v in src.state_dict().items()}})
+    assert not res.unexpected_keys
+    key = "stages.1.blocks.0.attn.w_msa.relative_position_bias_table"
+    pre = src.state_dict()[key]                                   # [(2*4-1)^2, 2]
+    want = torch.nn.functional.interpolate(pre.permute(1, 0).reshape(1, 2, 7, 7), size=(11, 11), mode="bicubic")
+    torch.testing.assert_close(dst.state_dict()[key], want.view(2, 121).permute(1, 0))
+    assert torch.equal(dst.state_dict()["stages.0.blocks.1.ffn.layers.1.weight"], src.state_dict()["stages.0.blocks.1.ffn.layers.1.weight"])
+    # official key names (layers / attn / mlp.fc1 / patch_embed.proj) through swin_converter
+    official = {}
+    for k, v in src.state_dict().items():
+        if "relative_position_index" in k:
+            continue
+        k2 = k.replace("stages", "layers", 1).replace("attn.w_msa.", "attn.").replace("ffn.layers.0.0.", "mlp.fc1.") \
+            .replace("ffn.layers.1.", "mlp.fc2.").replace("patch_embed.projection", "patch_embed.proj")
+        official[k2] = v
+    dst2 = SwinTransformer(window_size=4, convert_weights=True, **kw)
+    res2 = dst2.load_pretrained({"model": official})
+    assert not res2.unexpected_keys and all("relative_position_index" in k for k in res2.missing_keys)
+    assert torch.equal(dst2.state_dict()["stages.0.blocks.0.attn.w_msa.qkv.weight"], src.state_dict()["stages.0.blocks.0.attn.w_msa.qkv.weight"])
+
+
+def test_checkpoint_loader_refuses_pickled_objects_unless_opted_in(tmp_path):
+    from codetr.checkpoint import load_checkpoint
+
+    good = tmp_path / "good.pth"
+    torch.save({"state_dict": {"w": torch.zeros(2)}, "meta": {"CLASSES": ("a", "b")}}, good)
+    assert load_checkpoint(str(good))["meta"]["CLASSES"] == ("a", "b")
+
+    import fractions
+
+    bad = tmp_path / "bad.pth"   # an arbitrary (non-allow-listed) pickled object: weights_only refuses it
+    torch.save({"state_dict": {"w": torch.zeros(2)}, "meta": fractions.Fraction(1, 2)}, bad)
+    with pytest.raises(RuntimeError, match="allow_pickle"):
+        load_checkpoint(str(bad))
+    assert load_checkpoint(str(bad), allow_pickle=True)["meta"] == fractions.Fraction(1, 2)

@@ -1,11 +1,28 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02b; mkdir -p $out
-timeout 900 python -m pytest tests/test_msda_backward_gpu.py tests/test_timed_route_gpu.py tests/test_linear_gpu.py tests/test_model_gpu.py -m gpu -q -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
-grep -E "^(FAILED|ERROR)|passed|failed|^E  " $out/pytest.log | cut -c1-400 | head -40
-timeout 300 python tools/diag_fp32_flake.py --same 12 --seeds 100 --out $out/diag_fp32_flake.json > $out/diag.log 2>&1; tail -8 $out/diag.log | cut -c1-1200
-timeout 600 python tools/probe_cpu_oracle_threads.py 384x384 > $out/cpu_threads.log 2>&1; cat $out/cpu_threads.log
-b8="--streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline --no-host-feed"
-rm -rf /tmp/tr8
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr8 -- python bench.py $b8 > /tmp/tr8.log 2>&1
-python tools/fold_trace.py "$(find /tmp/tr8 -name '*.db' | head -1)" $out/r02b_batch8 8 "rocprofv3 --kernel-trace --stats -- python bench.py $b8"
-head -60 $out/r02b_batch8_summary.txt
+out=gpurun_out/r02c; mkdir -p $out
+timeout 600 python -m pytest tests/test_msda_encoder_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3
+for noise in 0 0.5 2; do
+ for cfg in "1 0" "4 0" "1 1" "4 1" "8 1" "2 1"; do
+  set -- $cfg
+  echo -n "BAND=$1 STATIC=$2: "
+  CODETR_MSDA_BAND=$1 CODETR_MSDA_STATIC=$2 timeout 120 python tools/bench_msda_encoder.py --noise $noise --batch 4 2>&1 | tail -1
+ done
+done | tee $out/msda_ab.txt
+for cfg in "1 0" "4 1"; do
+ set -- $cfg
+ for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_enc
+  CODETR_MSDA_BAND=$1 CODETR_MSDA_STATIC=$2 timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_enc -- python tools/bench_msda_encoder.py --iters 2 --noise 2 --batch 4 > /tmp/pmc.log 2>&1
+  f=$(find /tmp/pmc_enc -name "*counter_collection.csv" | head -1)
+  echo "BAND=$1 STATIC=$2 $c (KiB per launch, mean):"
+  python - "$f" <<'PY'
+import csv, collections, sys
+acc = collections.defaultdict(float); n = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"]
+    if "msda" in k:
+        k = k[28:60]; acc[k] += float(r["Counter_Value"]); n[k] += 1
+for k in acc: print("   ", k, "%.4e" % (acc[k] / n[k]), "launches", n[k])
+PY
+ done
+done | tee $out/msda_pmc.txt
