@@ -233,6 +233,17 @@ def kernel_rooflines(model, images, masks, device):
         hip_ops.LINEAR_PROFILE = hip_ops.KERNEL_PROFILE = None
     pmc = _pmc_traffic()
     out = {}
+    prof8 = [p for p in prof if len(p) > 6]
+    prof = [p for p in prof if len(p) == 6]
+    if prof8:
+        f8 = sum(p[2] for p in prof8)
+        t8 = sum(p[0].elapsed_time(p[1]) for p in prof8) * 1e-3
+        out["roofline_fp8"] = {
+            "kernel": "linear_256_fp8_kernel (the %d e4m3 GEMM launches of one forward)" % len(prof8),
+            "bound": "mfma", "achieved": round(f8 / t8 / 1e12, 1), "peak": 2 * MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(f8 / t8 / 1e12 / (2 * MFMA_PEAK_TFLOPS), 4), "traffic": None,
+            "sum_launch_ms": round(t8 * 1e3, 3), "algorithmic_flops_per_forward": f8,
+            "peak_note": "dense fp8 MFMA peak ~5 PF (block-scaled K = 128 instruction)"}
     flops = sum(p[2] for p in prof)
     secs = sum(p[0].elapsed_time(p[1]) for p in prof) * 1e-3
     achieved = flops / secs / 1e12
@@ -429,7 +440,10 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="sub-batches replayed concurrently on separate HIP streams (graph mode; 1 = single stream)")
     ap.add_argument("--res", default="1920x1280", help="WxH")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32", "fp8"],
+                    help="fp8 = BASELINE config 5: e4m3 weights + activations on the Swin stage 1-3 linears (fp16 elsewhere), "
+                         "static scales from a calibration forward over the first sub-batch; a separate line, never the "
+                         "fp16 headline")
     ap.add_argument("--offset-noise-px", type=float, default=2.0,
                     help="query-dependent spread of the MSDA sampling offsets in pixels (0 = the default init: fixed grid)")
     ap.add_argument("--feed", default="hbm", choices=["hbm", "host"],
@@ -466,13 +480,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
-    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[a.dtype]
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32, "fp8": torch.float16}[a.dtype]
     W, H = (int(x) for x in a.res.split("x"))
     model = build_model(device, dtype, offset_noise_px=a.offset_noise_px)
     g = torch.Generator(device=device).manual_seed(42 + rank)
     images = torch.randn(a.batch, 3, H, W, device=device, generator=g).to(dtype)  # ~ mean/std-normalised image
     masks = torch.zeros(a.batch, H, W, device=device, dtype=dtype)
     from codetr.sharding import gather_detections, pack_detections
+
+    fp8_report = None
+    if a.dtype == "fp8":
+        from codetr import fp8
+
+        nb0 = max(1, a.batch // max(1, min(a.streams, a.batch)))
+        fp8.calibrate(model, images[:nb0].contiguous(), masks[:nb0].contiguous())
+        fp8.enable(model)
+        fp8_report = fp8.report(model)
 
     gathered = torch.empty(world * a.batch, 300, 6, device=device, dtype=torch.float32) if world > 1 else None
 
@@ -584,7 +607,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[a.dtype],
+            "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32",
+                      "fp8": "fp8 e4m3 (Swin stage 1-3 linears: weights + activations; f16 elsewhere, f32 accumulation)"}[a.dtype],
             "data": "synthetic (randn images %s, zero padding masks; seeded random-init weights of the "
                     "real architecture with %g px of query-dependent MSDA offset spread -- no checkpoint/COCO available "
                     "offline)" % ("already in HBM" if a.feed == "hbm" else "fed from pinned host memory every step",
@@ -602,13 +626,15 @@ def main():
         }
         if host_feed is not None:
             out["host_feed"] = host_feed
+        if fp8_report is not None:
+            out["config"]["fp8"] = fp8_report
         if world == 1 and not a.no_roofline:
             # rooflines: one eager forward over the images of ONE replayed graph (batch / streams: the launches of the
             # timed region, same shapes and kernels; the committed PMC passes ran this shape).  The stand-alone MSDA
             # operator and the latency are single-image quantities.
             op = msda_roofline(1, H, W, dtype, device)
             out["latency_batch1"] = batch1_latency(model, images[:1].contiguous(), masks[:1].contiguous(), device)
-            if dtype == torch.float16:
+            if dtype == torch.float16:   # (fp16 and fp8 runs)
                 nb = max(1, a.batch // max(1, nstreams))
                 xi, xm = images[:nb].contiguous(), masks[:nb].contiguous()
                 out.update(kernel_rooflines(model, xi, xm, device))

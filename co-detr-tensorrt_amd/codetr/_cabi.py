@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -54,6 +54,10 @@ SIGNATURES = {
     "codetr_topk_bf16": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
     "codetr_linear_variant": (_cp, [_i64, _i64, _i64, _i32, _i32, _i32]),
+    "codetr_linear_fp8": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i32, ctypes.c_float, _i64, _i64, _i64,
+                                 _i32]),
+    "codetr_cast_fp8_f16": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float]),
+    "codetr_layernorm_fp8_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, ctypes.c_float]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp]),
@@ -100,7 +104,8 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
-         "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0}
+         "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0,
+         "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0}
 
 
 def load():
@@ -621,4 +626,40 @@ def ffn_fused(x2d, w1, b1, w2, b2, out2d, ln=None, pos2d=None, out_plus_pos2d=No
         pos2d.data_ptr() if pos2d is not None else None,
         out_plus_pos2d.data_ptr() if out_plus_pos2d is not None else None)
     check(rc, "codetr_ffn_relu_ln2")
+    return out2d
+
+
+# ---- fp8 (e4m3) path: BASELINE config 5 ----------------------------------------------------------------------
+FP8 = torch.float8_e4m3fn
+
+
+def linear_fp8(x8, w8, w_scale, x_scale, bias, residual2d, act, out2d, out_scale=0.0):
+    """x8 [M,K] / w8 [N,K] e4m3 (torch.float8_e4m3fn), w_scale [N] fp32, x_scale python float; out2d fp16 [M,N], or
+    e4m3 [M,N] with out_scale (no residual then)."""
+    lib = load()
+    CALLS["linear_fp8"] += 1
+    M, K = x8.shape
+    N = w8.shape[0]
+    out8 = out2d.dtype == FP8
+    rc = lib.codetr_linear_fp8(current_stream_ptr(x8.device), x8.data_ptr(), w8.data_ptr(), w_scale.data_ptr(), float(x_scale),
+                               bias.data_ptr() if bias is not None else None,
+                               residual2d.data_ptr() if residual2d is not None else None, out2d.data_ptr(),
+                               1 if out8 else 0, float(out_scale), M, N, K, _ACT[act])
+    check(rc, "codetr_linear_fp8")
+    return out2d
+
+
+def cast_fp8(x, scale, out):
+    CALLS["cast_fp8"] += 1
+    rc = load().codetr_cast_fp8_f16(current_stream_ptr(x.device), x.data_ptr(), out.data_ptr(), x.numel(), float(scale))
+    check(rc, "codetr_cast_fp8_f16")
+    return out
+
+
+def layernorm_fp8(x2d, weight, bias, eps, scale, out2d):
+    CALLS["layernorm_fp8"] += 1
+    rows, C = x2d.shape
+    rc = load().codetr_layernorm_fp8_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                         out2d.data_ptr(), rows, C, float(eps), float(scale))
+    check(rc, "codetr_layernorm_fp8_f16")
     return out2d

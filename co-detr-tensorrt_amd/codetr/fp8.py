@@ -1,0 +1,68 @@
+"""FP8 (OCP e4m3) inference mode -- BASELINE config 5, "fp8 weights + activations (CDNA4 fp8 MFMA for Swin + transformer
+GEMMs)".  No reference counterpart (the reference's dtypes stop at half: codetr/csrc/ms_deform_attn.cu:946,
+export.py:39-44); parity target = the fp32 oracle at a wider, stated tolerance (tests/test_fp8_gpu.py).
+
+Scheme (standard post-training static quantisation):
+  * weights: per-output-channel scale = absmax / 448, quantised once (``hip_ops.fp8_weight``, cached on the parameter);
+  * activations: one static scale per GEMM input tensor = (running absmax over a calibration forward) / 448 x margin;
+    the producer of each GEMM input emits e4m3 directly -- LayerNorm (``layer_norm_fp8``), the GELU epilogue of fc1
+    (``out_scale``), a cast after window attention;
+  * arithmetic: e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the fp16 MFMA rate), fp32 accumulation, scales
+    applied once in the epilogue; residual stream, attention, norms' statistics and everything else stay fp16 / fp32.
+
+What runs in fp8 (this round): the four Linears of every Swin block whose K is a multiple of 128 and whose GEMMs fill
+the chip (stages 1-3 at the bench's batch: 88 of the backbone's 96 block GEMMs, ~85 % of the Swin flops).  Stage 0
+(C = 192), patch merging, the neck and the detection transformer stay on the fp16 kernels; ``report()`` says so."""
+import torch
+
+from . import hip_ops
+from .swin import SwinBlock
+
+MARGIN = 1.0   # scale = absmax * MARGIN / 448 (calibration and evaluation inputs are drawn alike in bench / tests)
+
+
+def _blocks(model):
+    return [m for m in model.modules() if isinstance(m, SwinBlock)]
+
+
+@torch.no_grad()
+def calibrate(model, batch_inputs, img_masks):
+    """One fp16 forward with every Swin block recording the absolute maxima of its four GEMM inputs; sets the static
+    activation scales and pre-quantises the weights.  Returns the number of blocks prepared."""
+    blocks = _blocks(model)
+    for b in blocks:
+        b.fp8_mode = "calibrate"
+        b.__dict__.pop("_fp8_amax", None)
+    try:
+        model(batch_inputs, img_masks)
+    finally:
+        for b in blocks:
+            b.fp8_mode = None
+    n = 0
+    for b in blocks:
+        amax = b.__dict__.get("_fp8_amax")
+        if not amax:
+            continue
+        b._fp8_scales = {k: max(float(v) * MARGIN / hip_ops.FP8_MAX, 1e-8) for k, v in amax.items()}   # (one host sync each)
+        for w in b._fp8_weights():
+            if w.shape[1] % 128 == 0:
+                hip_ops.fp8_weight(w)
+        n += 1
+    return n
+
+
+def enable(model, on=True):
+    """switch the calibrated blocks to the fp8 path (blocks without scales, or whose shapes the fp8 GEMM does not
+    take at run time, keep running fp16)"""
+    for b in _blocks(model):
+        b.fp8_mode = "run" if (on and hasattr(b, "_fp8_scales")) else None
+
+
+def report(model):
+    blocks = _blocks(model)
+    ready = [b for b in blocks if getattr(b, "fp8_mode", None) == "run"]
+    k_ok = [b for b in ready if all(w.shape[1] % 128 == 0 for w in b._fp8_weights())]
+    return {"swin_blocks": len(blocks), "swin_blocks_fp8": len(k_ok),
+            "fp8_layers": f"qkv / proj / fc1 / fc2 of Swin blocks with K a multiple of 128 (stages 1-3) when the GEMM has "
+                          f">= {hip_ops.FP8_MIN_TILES} 256x256 tiles",
+            "fp16_layers": "Swin stage 0, patch merging, neck, encoder / decoder / heads, window attention, MSDA"}

@@ -634,3 +634,75 @@ def msda(value, spatial_shapes, level_start_index, sampling_locations, attention
     return torch.ops.codetr.multi_scale_deformable_attention(
         value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step
     )
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) path -- BASELINE config 5.  Weights are quantised once per parameter (per-output-channel scales),
+# activations with static per-tensor scales from a calibration forward (codetr/fp8.py); fp32 accumulation.
+# ---------------------------------------------------------------------------------------------------------------
+FP8 = _cabi.FP8
+FP8_MAX = 448.0
+FP8_MIN_TILES = int(os.environ.get("CODETR_FP8_MIN_TILES", "96"))   # 256x256 output tiles below which fp16 serves the layer
+
+
+def fp8_weight(weight):
+    """(w8 [N,K] e4m3, w_scale [N] fp32) of an nn.Linear weight: per-output-channel absmax / 448; cached on the parameter"""
+    def build():
+        w = weight.detach().float()
+        scale = (w.abs().amax(1) / FP8_MAX).clamp_min(1e-12)
+        return (w / scale[:, None]).to(FP8).contiguous(), scale.contiguous()
+
+    return derived((weight,), "_codetr_fp8_w", build)
+
+
+def linear_fp8_supported(rows, weight):
+    """True when the fp8 GEMM serves this layer: K a multiple of 128 bytes, N of 8, and enough 256x256 output tiles to
+    fill the chip (smaller problems stay on the fp16 kernels)"""
+    N, K = weight.shape
+    return (weight.is_cuda and weight.dtype == torch.float16 and K % 128 == 0 and N % 8 == 0
+            and -(-rows // 256) * -(-N // 256) >= FP8_MIN_TILES)
+
+
+def linear_fp8(x8, x_scale, weight, bias=None, act=None, residual=None, out_scale=None):
+    """act((x8 * x_scale) @ weight.T + bias) (+ residual) with x8 e4m3 [..., K] and the fp16 `weight` quantised per
+    output channel (cached).  Returns fp16, or e4m3 = sat(y / out_scale) when out_scale is given."""
+    _gpu(x8, "linear_fp8")
+    w8, ws = fp8_weight(weight)
+    K, N = x8.shape[-1], weight.shape[0]
+    x2 = x8.reshape(-1, K)
+    r2 = None if residual is None else residual.reshape(-1, N).contiguous()
+    out = torch.empty((x2.shape[0], N), dtype=FP8 if out_scale is not None else torch.float16, device=x8.device)
+    with torch.cuda.device(x8.device):
+        launch = lambda: _cabi.linear_fp8(x2, w8, ws, x_scale, bias, r2, act, out, out_scale or 0.0)  # noqa: E731
+        if LINEAR_PROFILE is None:
+            launch()
+        else:
+            st = torch.cuda.current_stream(x8.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            launch()
+            e1.record(st)
+            LINEAR_PROFILE.append((e0, e1, 2.0 * x2.shape[0] * N * K, x2.shape[0], N, K, "fp8"))
+    return out.view(*x8.shape[:-1], N)
+
+
+def cast_fp8(x, scale):
+    """sat(x / scale) -> e4m3, fp16 input"""
+    _gpu(x, "cast_fp8")
+    x = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(x.shape, dtype=FP8, device=x.device)
+    with torch.cuda.device(x.device):
+        _cabi.cast_fp8(x, scale, out)
+    return out
+
+
+def layer_norm_fp8(x, weight, bias, eps, scale):
+    """sat(LayerNorm(x) / scale) -> e4m3 in one kernel (fp16 input; the norm's fp16 output is never written)"""
+    _gpu(x, "layer_norm_fp8")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    out = torch.empty(x2.shape, dtype=FP8, device=x.device)
+    with torch.cuda.device(x.device):
+        _cabi.layernorm_fp8(x2, weight, bias, eps, scale, out)
+    return out.view(x.shape)

@@ -238,6 +238,13 @@ class SwinBlock(nn.Module):
 
     def forward(self, x, hw_shape):
         n1, n2 = self.norm1, self.norm2
+        mode = getattr(self, "fp8_mode", None)
+        if mode is not None and x.is_cuda and x.dtype == torch.float16 and self.attn.takes_norm(x, hw_shape):
+            rows = x.shape[0] * x.shape[1]
+            if mode == "calibrate":
+                return self._forward_fp8_calibrate(x, hw_shape)
+            if mode == "run" and all(hip_ops.linear_fp8_supported(rows, w) for w in self._fp8_weights()):
+                return self._forward_fp8(x, hw_shape)
         if (isinstance(n1, nn.LayerNorm) and self.attn.takes_norm(x, hw_shape)
                 and hip_ops.linear_ln_supported(x, n1.weight, self.attn.w_msa.qkv.weight)):
             # norm1 folded into the qkv GEMM's operand load (only that GEMM reads the normalised rows)
@@ -253,6 +260,51 @@ class SwinBlock(nn.Module):
             return hip_ops.linear(h, fc2.weight, fc2.bias, residual=x)
         h = hip_ops.layer_norm(x, n2.weight, n2.bias, n2.eps)
         return self.ffn(h, identity=x)
+
+
+    # ---- fp8 (BASELINE config 5): the block's four Linears on the e4m3 MFMA path, see codetr/fp8.py -------------
+    def _fp8_weights(self):
+        m = self.attn.w_msa
+        return (m.qkv.weight, m.proj.weight, self.ffn.layers[0][0].weight, self.ffn.layers[1].weight)
+
+    def _forward_fp8_calibrate(self, x, hw_shape):
+        """the fp16 block, unfused, recording the absolute maxima of the four GEMM inputs (running max over calls)"""
+        n1, n2, m = self.norm1, self.norm2, self.attn.w_msa
+        fc1, fc2 = self.ffn.layers[0][0], self.ffn.layers[1]
+        amax = self.__dict__.setdefault("_fp8_amax", {})
+
+        def rec(key, t):
+            v = t.detach().abs().amax().float()
+            amax[key] = v if key not in amax else torch.maximum(amax[key], v)
+
+        h = hip_ops.layer_norm(x, n1.weight, n1.bias, n1.eps)
+        rec("ln1", h)
+        qkv = hip_ops.linear(h, m.qkv.weight, m.qkv.bias)
+        o = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads,
+                                          self.attn.window_size, self.attn.shift_size)
+        rec("attn", o)
+        x = hip_ops.linear(o, m.proj.weight, m.proj.bias, residual=x)
+        h = hip_ops.layer_norm(x, n2.weight, n2.bias, n2.eps)
+        rec("ln2", h)
+        g = hip_ops.linear(h, fc1.weight, fc1.bias, act=self.ffn.act)
+        rec("act", g)
+        return hip_ops.linear(g, fc2.weight, fc2.bias, residual=x)
+
+    def _forward_fp8(self, x, hw_shape):
+        """norm1 -> e4m3 | qkv (fp8 GEMM, fp16 out) | window attention (fp16) -> e4m3 | proj (fp8, + identity) |
+        norm2 -> e4m3 | fc1 (fp8, GELU, e4m3 out) | fc2 (fp8, + identity): the residual stream stays fp16"""
+        n1, n2, m = self.norm1, self.norm2, self.attn.w_msa
+        fc1, fc2 = self.ffn.layers[0][0], self.ffn.layers[1]
+        sc = self._fp8_scales
+        h8 = hip_ops.layer_norm_fp8(x, n1.weight, n1.bias, n1.eps, sc["ln1"])
+        qkv = hip_ops.linear_fp8(h8, sc["ln1"], m.qkv.weight, m.qkv.bias)
+        o = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads,
+                                          self.attn.window_size, self.attn.shift_size)
+        o8 = hip_ops.cast_fp8(o, sc["attn"])
+        x = hip_ops.linear_fp8(o8, sc["attn"], m.proj.weight, m.proj.bias, residual=x)
+        h8 = hip_ops.layer_norm_fp8(x, n2.weight, n2.bias, n2.eps, sc["ln2"])
+        g8 = hip_ops.linear_fp8(h8, sc["ln2"], fc1.weight, fc1.bias, act=self.ffn.act, out_scale=sc["act"])
+        return hip_ops.linear_fp8(g8, sc["act"], fc2.weight, fc2.bias, residual=x)
 
 
 class SwinBlockSequence(nn.Module):

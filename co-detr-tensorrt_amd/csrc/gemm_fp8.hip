@@ -1,0 +1,393 @@
+// FP8 (OCP e4m3) linear layer for MI355X (gfx950) -- BASELINE config 5, "fp8 weights + activations":
+//   Y[M,N] = act( (X8[M,K] . W8[N,K]^T) * x_scale * w_scale[n] + bias[n] ) (+ R[M,N])
+// X8 / W8 are e4m3 bytes (K contiguous), x_scale one fp32 per tensor (static, from a calibration forward), w_scale one
+// fp32 per output channel, accumulation in fp32 on the matrix cores with the K = 128 block-scaled instruction
+// v_mfma_scale_f32_16x16x128_f8f6f4 at unit block scales (the real scales are applied once, in the epilogue): on
+// gfx950 that instruction takes twice the cycles of v_mfma_f32_16x16x32_f16 at 4x the K, i.e. twice the fp16 rate,
+// while the plain fp8 MFMA (16x16x32_fp8_fp8) only runs at the fp16 rate (MI355X_MICROARCH.md, matrix cores).
+// Output: fp16 (default) or e4m3 with its own static scale (an fc1 whose only reader is the fp8 fc2).
+//
+// There is no reference counterpart (the reference's dtypes stop at half: codetr/csrc/ms_deform_attn.cu:946,
+// export.py:39-44); the layers it serves are the reference's nn.Linears of codetr/swin.py:91-115, 345-355.
+//
+// Structure = linear_256_kernel of gemm_f16.hip with bytes in place of halves: a 128-byte k-tile row is 128 fp8
+// values instead of 64 halves, so the LDS image (256 rows x 8 16-byte chunks per operand and stage, XOR swizzle on the
+// DMA source address), the 2-stage LDS-DMA ring and the LDS-staged epilogue are the same; one k-tile is ONE MFMA deep
+// (K = 128) per 16x16 output tile: lane l holds bytes 32 (l >> 4) .. + 31 of row l & 15 of each operand (two
+// ds_read_b128; any consistent k permutation of A and B gives the same dot product).  512 threads = 8 waves (2 x 4),
+// each 128 (m) x 64 (n) = 8 x 4 MFMA tiles; fragment reads of m-tile j + 1 are issued under the MFMAs of m-tile j.
+//
+// Requirements: K % 128 == 0, N % 8 == 0, 16-byte aligned bases; M arbitrary.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "codetr_hip.h"
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kStagePitch = 64 * 2 + 16;  // epilogue staging: bytes per staged row of a wave's 64-column slice
+constexpr float kFp8Max = 448.0f;         // largest finite e4m3 (OCP e4m3fn)
+
+__device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {  // as gemm_f16.hip (Abramowitz-Stegun 7.1.26)
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);
+  return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
+}
+
+__device__ __forceinline__ int sw(int row) { return (row >> 1) & 7; }  // 128-byte rows
+
+__device__ __forceinline__ i32x4 read_piece(const unsigned char* tile, int row, int chunk) {
+  return *reinterpret_cast<const i32x4*>(tile + row * 128 + ((chunk ^ sw(row)) * 16));
+}
+// the lane's 32 bytes of one operand row: chunks 2g and 2g + 1 (g = lane >> 4)
+__device__ __forceinline__ i32x8 read_frag(const unsigned char* tile, int row, int g) {
+  const i32x4 lo = read_piece(tile, row, 2 * g), hi = read_piece(tile, row, 2 * g + 1);
+  return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ float h2f(unsigned short bits) {
+  _Float16 h;
+  __builtin_memcpy(&h, &bits, 2);
+  return (float)h;
+}
+__device__ __forceinline__ unsigned short f2h(float v) {
+  _Float16 h = (_Float16)v;
+  unsigned short bits;
+  __builtin_memcpy(&bits, &h, 2);
+  return bits;
+}
+// two floats -> two e4m3 bytes (saturating: clamped to +-448 first; NaN stays NaN)
+__device__ __forceinline__ unsigned pk_fp8(float a, float b) {
+  a = __builtin_amdgcn_fmed3f(a, -kFp8Max, kFp8Max);
+  b = __builtin_amdgcn_fmed3f(b, -kFp8Max, kFp8Max);
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+
+// ACT: 0 none, 1 relu, 2 gelu(erf).  OUT8: Y is e4m3 (y / out_scale), else fp16.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool OUT8>
+__global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char* __restrict__ X,
+                                                             const unsigned char* __restrict__ W,
+                                                             const float* __restrict__ w_scale, const float x_scale,
+                                                             const unsigned short* __restrict__ bias,
+                                                             const unsigned short* __restrict__ R, void* __restrict__ Yv,
+                                                             const float out_inv_scale, int M, int N, int K,
+                                                             int tiles_n) {
+  constexpr int NT = 512;
+  constexpr int kTileBytes = 256 * 128;        // 32 KiB: one operand tile (256 rows x 128 bytes of K)
+  constexpr int kStageBytes = 2 * kTileBytes;  // W tile + X tile
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes];  // 128 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int frow = lane & 15, fg = lane >> 4, ncol = 4 * (lane >> 4);
+
+  f32x4 acc[4][8];  // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-thread source pointers of the 4 + 4 LDS-DMA pieces of a stage (piece q covers rows q*64 + tid/8)
+  const unsigned char* gw[4];
+  const unsigned char* gx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = q * 64 + (tid >> 3), pos = tid & 7;
+    const int chunk = pos ^ sw(r);
+    int gn = n0 + r, gm = m0 + r;
+    gn = gn < N ? gn : N - 1;
+    gm = gm < M ? gm : M - 1;
+    gw[q] = W + (size_t)gn * K + chunk * 16;
+    gx[q] = X + (size_t)gm * K + chunk * 16;
+  }
+  auto dma = [&](const unsigned char* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  };
+  const int nk = K / 128;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    dma(gw[q], lds + (q * NT + wave * 64) * 16);
+    dma(gx[q], lds + kTileBytes + (q * NT + wave * 64) * 16);
+  }
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t is in LDS for everyone; everyone is done reading tile t-1
+    const unsigned char* bufW = lds + (t & 1) * kStageBytes;
+    const unsigned char* bufX = bufW + kTileBytes;
+    // tile t+1 -> the other buffer, one piece per m-tile below (past the last tile: re-fetch it, no branch; drained
+    // before the epilogue)
+    const size_t koff = (size_t)(t + 1 < nk ? t + 1 : t) * 128;
+    unsigned char* nbuf = lds + ((t + 1) & 1) * kStageBytes;
+    i32x8 a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = read_frag(bufW, wn * 64 + i * 16 + frow, fg);
+    b[0] = read_frag(bufX, wm * 128 + frow, fg);
+    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < 7) b[(j + 1) & 1] = read_frag(bufX, wm * 128 + (j + 1) * 16 + frow, fg);
+      {
+        const int q = j >> 1;
+        if (j & 1) dma(gx[q] + koff, nbuf + kTileBytes + (q * NT + wave * 64) * 16);
+        else dma(gw[q] + koff, nbuf + (q * NT + wave * 64) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j & 1], acc[i][j], 0, 0, 0, 0, 0, 0);
+      if (j < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // all fragment reads done, no DMA in flight: LDS is free for the epilogue
+
+  // per-lane column constants: 4 consecutive n per n-tile
+  float sc[4][4], bs[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + ncol;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = n + r < N;
+      sc[i][r] = ok ? w_scale[n + r] * x_scale : 0.f;
+      bs[i][r] = (HAS_BIAS && ok) ? h2f(bias[n + r]) : 0.f;
+    }
+  }
+
+  // epilogue in two 64-row halves per wave through its private staging region (64 rows x 144 B), fp16 image
+  constexpr int kPitch = kStagePitch;
+  unsigned char* stage = lds + wave * (64 * kPitch);
+  const int srow = lane >> 3, schunk = lane & 7;
+  const int n = n0 + wn * 64 + schunk * 8;
+  unsigned char* ytile = reinterpret_cast<unsigned char*>(Yv) + ((size_t)m0 * N + n0) * (OUT8 ? 1 : 2);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f16x4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = fmaf(acc[i][h * 4 + j][r], sc[i][r], bs[i][r]);
+          if (ACT == 1) x = x < 0.f ? 0.f : x;
+          if (ACT == 2) x = gelu_erf(x);
+          hv[r] = (_Float16)x;
+        }
+        s16x4 o;
+        __builtin_memcpy(&o, &hv, 8);
+        *reinterpret_cast<s16x4*>(stage + (j * 16 + frow) * kPitch + (i * 16 + ncol) * 2) = o;
+      }
+    __builtin_amdgcn_wave_barrier();
+    s16x8 rres[8];
+    if (HAS_RES) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        int m = m0 + wm * 128 + h * 64 + it * 8 + srow;
+        m = m < M ? m : M - 1;
+        const int nn = n + 8 <= N ? n : N - 8;
+        rres[it] = *reinterpret_cast<const s16x8*>(R + (size_t)m * N + nn);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int ml = it * 8 + srow;
+      const int m = m0 + wm * 128 + h * 64 + ml;
+      if (m < M && n < N) {
+        s16x8 v = *reinterpret_cast<const s16x8*>(stage + ml * kPitch + schunk * 16);
+        if (HAS_RES) {
+          const s16x8 rr = rres[it];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (short)f2h(h2f((unsigned short)v[e]) + h2f((unsigned short)rr[e]));
+        }
+        const unsigned eoff = (unsigned)(wm * 128 + h * 64 + ml) * (unsigned)N + (unsigned)(wn * 64 + schunk * 8);
+        if (OUT8) {
+          unsigned lo = 0, hi = 0;
+          lo = pk_fp8(h2f((unsigned short)v[0]) * out_inv_scale, h2f((unsigned short)v[1]) * out_inv_scale) |
+               (pk_fp8(h2f((unsigned short)v[2]) * out_inv_scale, h2f((unsigned short)v[3]) * out_inv_scale) << 16);
+          hi = pk_fp8(h2f((unsigned short)v[4]) * out_inv_scale, h2f((unsigned short)v[5]) * out_inv_scale) |
+               (pk_fp8(h2f((unsigned short)v[6]) * out_inv_scale, h2f((unsigned short)v[7]) * out_inv_scale) << 16);
+          *reinterpret_cast<uint2*>(ytile + eoff) = uint2{lo, hi};
+        } else {
+          *reinterpret_cast<s16x8*>(ytile + eoff * 2u) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the region is rewritten by the second half
+  }
+}
+
+template <int ACT, bool OUT8>
+int launch_bias_res(hipStream_t st, const void* X, const void* W, const float* ws, float xs, const void* bias,
+                    const void* R, void* Y, float out_inv, int M, int N, int K) {
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
+  auto x = static_cast<const unsigned char*>(X);
+  auto w = static_cast<const unsigned char*>(W);
+  auto b = static_cast<const unsigned short*>(bias);
+  auto r = static_cast<const unsigned short*>(R);
+#define CODETR_FP8_LAUNCH(HB, HR) \
+  hipLaunchKernelGGL((linear_256_fp8_kernel<ACT, HB, HR, OUT8>), grid, block, 0, st, x, w, ws, xs, b, r, Y, out_inv, M, N, K, tiles_n)
+  if (bias && R) CODETR_FP8_LAUNCH(true, true);
+  else if (bias) CODETR_FP8_LAUNCH(true, false);
+  else if (R) CODETR_FP8_LAUNCH(false, true);
+  else CODETR_FP8_LAUNCH(false, false);
+#undef CODETR_FP8_LAUNCH
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+// ---- producers of e4m3 activations -------------------------------------------------------------------------
+
+// y8 = sat(x * inv_scale): n16 = number of 16-byte (8-half) groups
+__global__ __launch_bounds__(256) void cast_fp8_kernel(const s16x8* __restrict__ x, uint2* __restrict__ y, float inv_scale,
+                                                       int64_t n16) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n16) return;
+  const s16x8 v = x[i];
+  const unsigned lo = pk_fp8(h2f((unsigned short)v[0]) * inv_scale, h2f((unsigned short)v[1]) * inv_scale) |
+                      (pk_fp8(h2f((unsigned short)v[2]) * inv_scale, h2f((unsigned short)v[3]) * inv_scale) << 16);
+  const unsigned hi = pk_fp8(h2f((unsigned short)v[4]) * inv_scale, h2f((unsigned short)v[5]) * inv_scale) |
+                      (pk_fp8(h2f((unsigned short)v[6]) * inv_scale, h2f((unsigned short)v[7]) * inv_scale) << 16);
+  y[i] = uint2{lo, hi};
+}
+
+// LayerNorm over the last dimension (fp16 in, fp32 statistics, two passes over registers) -> e4m3: one wave per row,
+// C % 8 == 0, C <= 4096 (8 chunks of 8 halves per lane)
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const unsigned short* __restrict__ x,
+                                                            const unsigned short* __restrict__ gamma,
+                                                            const unsigned short* __restrict__ beta,
+                                                            unsigned char* __restrict__ y, int64_t rows, int C, float eps,
+                                                            float inv_scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = C >> 3;  // 16-byte chunks per row
+  float v[8][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nch) {
+      const s16x8 r = *reinterpret_cast<const s16x8*>(x + row * C + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[c][e] = h2f((unsigned short)r[e]);
+        sum += v[c][e];
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c * 64 + lane < nch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[c][e] - mean;
+        var += d * d;
+      }
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+  const float rstd = rsqrtf(var / (float)C + eps);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nch) {
+      const s16x8 g = *reinterpret_cast<const s16x8*>(gamma + ch * 8);
+      const s16x8 b = *reinterpret_cast<const s16x8*>(beta + ch * 8);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // the fp16 LayerNorm output the fp16 model would have produced, then quantised
+        const float ln = h2f(f2h((v[c][e] - mean) * rstd * h2f((unsigned short)g[e]) + h2f((unsigned short)b[e])));
+        o[e] = ln * inv_scale;
+      }
+      const unsigned lo = pk_fp8(o[0], o[1]) | (pk_fp8(o[2], o[3]) << 16);
+      const unsigned hi = pk_fp8(o[4], o[5]) | (pk_fp8(o[6], o[7]) << 16);
+      *reinterpret_cast<uint2*>(y + row * C + ch * 8) = uint2{lo, hi};
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_linear_fp8(void* stream, const void* x8_dev, const void* w8_dev, const float* w_scale_dev, float x_scale,
+                      const void* bias_f16_dev, const void* residual_f16_dev, void* y_dev, int out_is_fp8, float out_scale,
+                      int64_t M, int64_t N, int64_t K, int act) {
+  if (!x8_dev || !w8_dev || !w_scale_dev || !y_dev || M <= 0 || N <= 0 || K <= 0) return CODETR_E_BADARG;
+  if (K % 128 != 0 || N % 8 != 0 || act < 0 || act > 2) return CODETR_E_UNSUPPORTED;
+  if (out_is_fp8 && (!(out_scale > 0.f) || residual_f16_dev)) return CODETR_E_BADARG;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL || K > 0x7fffffffLL || M * N > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if ((reinterpret_cast<uintptr_t>(x8_dev) | reinterpret_cast<uintptr_t>(w8_dev) | reinterpret_cast<uintptr_t>(y_dev) |
+       reinterpret_cast<uintptr_t>(residual_f16_dev)) & 15)
+    return CODETR_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float inv = out_is_fp8 ? 1.0f / out_scale : 1.0f;
+#define CODETR_FP8_ACT(A)                                                                                                  \
+  return out_is_fp8 ? launch_bias_res<A, true>(st, x8_dev, w8_dev, w_scale_dev, x_scale, bias_f16_dev, residual_f16_dev,   \
+                                               y_dev, inv, (int)M, (int)N, (int)K)                                         \
+                    : launch_bias_res<A, false>(st, x8_dev, w8_dev, w_scale_dev, x_scale, bias_f16_dev, residual_f16_dev,  \
+                                                y_dev, inv, (int)M, (int)N, (int)K)
+  if (act == 0) CODETR_FP8_ACT(0);
+  if (act == 1) CODETR_FP8_ACT(1);
+  CODETR_FP8_ACT(2);
+#undef CODETR_FP8_ACT
+}
+
+int codetr_cast_fp8_f16(void* stream, const void* x_f16_dev, void* y8_dev, int64_t n, float scale) {
+  if (!x_f16_dev || !y8_dev || n < 0 || !(scale > 0.f)) return CODETR_E_BADARG;
+  if (n == 0) return 0;
+  if (n % 8 != 0 || (reinterpret_cast<uintptr_t>(x_f16_dev) & 15) || (reinterpret_cast<uintptr_t>(y8_dev) & 7))
+    return CODETR_E_UNSUPPORTED;
+  const int64_t n16 = n / 8, blocks = (n16 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  hipLaunchKernelGGL(cast_fp8_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const s16x8*>(x_f16_dev), static_cast<uint2*>(y8_dev), 1.0f / scale, n16);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+int codetr_layernorm_fp8_f16(void* stream, const void* x_f16_dev, const void* gamma_f16_dev, const void* beta_f16_dev,
+                             void* y8_dev, int64_t rows, int64_t C, float eps, float scale) {
+  if (!x_f16_dev || !gamma_f16_dev || !beta_f16_dev || !y8_dev || rows < 0 || C <= 0 || !(scale > 0.f))
+    return CODETR_E_BADARG;
+  if (rows == 0) return 0;
+  if (C % 8 != 0 || C > 4096) return CODETR_E_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x_f16_dev) | reinterpret_cast<uintptr_t>(gamma_f16_dev) |
+       reinterpret_cast<uintptr_t>(beta_f16_dev)) & 15 || (reinterpret_cast<uintptr_t>(y8_dev) & 7))
+    return CODETR_E_BADARG;
+  const int64_t blocks = (rows + 3) / 4;
+  if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  hipLaunchKernelGGL(layernorm_fp8_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(x_f16_dev), static_cast<const unsigned short*>(gamma_f16_dev),
+                     static_cast<const unsigned short*>(beta_f16_dev), static_cast<unsigned char*>(y8_dev), rows, (int)C, eps,
+                     1.0f / scale);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // extern "C"

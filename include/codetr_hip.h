@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 32
+#define CODETR_HIP_ABI_VERSION 33
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -257,6 +257,29 @@ int codetr_linear_ln_f16(void *stream, const void *x_dev, const void *ln_gamma_d
 int codetr_linear_ln_bf16(void *stream, const void *x_dev, const void *ln_gamma_dev, const void *ln_beta_dev,
                           float ln_eps, const void *w_dev, const void *bias_dev, void *y_dev, int64_t M, int64_t N,
                           int64_t K, int act);
+
+/* ------------------------------------------------------------------------------------------
+ * FP8 (OCP e4m3) linear layer and its activation producers -- BASELINE config 5 ("fp8 weights + activations").
+ * No reference counterpart (the reference's dtypes stop at half: codetr/csrc/ms_deform_attn.cu:946,
+ * export.py:39-44); the layers served are the nn.Linears of codetr/swin.py:91-115, 345-355.
+ *
+ *   codetr_linear_fp8      y = act((x8 . w8^T) * x_scale * w_scale[n] + bias[n]) (+ residual)
+ *                          x8 [M, K] / w8 [N, K] e4m3 bytes, K contiguous; w_scale [N] fp32 (per output channel);
+ *                          x_scale: the static per-tensor scale the producer divided by; bias [N] / residual [M, N]
+ *                          fp16 or NULL; y [M, N] fp16, or e4m3 = sat(y / out_scale) when out_is_fp8 (then no
+ *                          residual).  fp32 accumulation with v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales).
+ *                          K % 128 == 0, N % 8 == 0, 16-byte aligned bases; act as codetr_linear_*.
+ *   codetr_cast_fp8_f16    y8[i] = sat(x[i] / scale), n % 8 == 0 elements
+ *   codetr_layernorm_fp8_f16  LayerNorm over the last dimension C (fp32 statistics, result rounded to fp16 as the
+ *                          fp16 model would) then sat(. / scale) -> e4m3; C % 8 == 0, C <= 4096
+ * Saturation: values are clamped to +-448 (the largest finite e4m3) before conversion.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_linear_fp8(void *stream, const void *x8_dev, const void *w8_dev, const float *w_scale_dev, float x_scale,
+                      const void *bias_f16_dev, const void *residual_f16_dev, void *y_dev, int out_is_fp8,
+                      float out_scale, int64_t M, int64_t N, int64_t K, int act);
+int codetr_cast_fp8_f16(void *stream, const void *x_f16_dev, void *y8_dev, int64_t n, float scale);
+int codetr_layernorm_fp8_f16(void *stream, const void *x_f16_dev, const void *gamma_f16_dev, const void *beta_f16_dev,
+                             void *y8_dev, int64_t rows, int64_t C, float eps, float scale);
 
 /* Split-K form of the same layer for problems with few output tiles and a long K -- the neck's extra
  * 3x3 / stride-2 level (codetr/codetr.py neck, mmdet ChannelMapper extra_convs) run as a GEMM over unfolded

@@ -134,3 +134,28 @@ def poison_allocator(device, total_mb=512):
         used += s
     torch.cuda.synchronize(device)
     del held
+
+
+def detection_agreement(cap, cap_o, Himg, Wimg):
+    """Detection-level distance between a product run and the oracle run with the SAME proposal selection: for every
+    query the decoded box (pixels, xyxy) and for every (query, class) the sigmoid score -- the quantities the final
+    top-k / NMS / AP consume.  Returns mean and 95th-percentile absolute box error in pixels and score error, plus the
+    fraction of the oracle's 300 highest (query, class) scores whose pair is also in the product's 300 highest."""
+    import torch
+
+    def boxes(c):
+        cx, cy, w, h = c.float().cpu().unbind(-1)
+        s = torch.tensor([Wimg, Himg, Wimg, Himg], dtype=torch.float32)
+        return torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), -1) * s
+
+    db = (boxes(cap["outputs_coords"]) - boxes(cap_o["outputs_coords"])).abs()
+    sa, so = cap["outputs_classes"].float().cpu().sigmoid(), cap_o["outputs_classes"].float().cpu().sigmoid()
+    ds = (sa - so).abs()
+    B = sa.shape[0]
+    ta = torch.topk(sa.reshape(B, -1), 300, dim=1)[1]
+    to = torch.topk(so.reshape(B, -1), 300, dim=1)[1]
+    common = sum(len(set(a.tolist()) & set(o.tolist())) for a, o in zip(ta, to)) / (300.0 * B)
+    fin = torch.isfinite(db)
+    return {"box_err_px_mean": float(db[fin].mean()), "box_err_px_p95": float(db[fin].quantile(0.95)),
+            "score_err_mean": float(ds.mean()), "score_err_p95": float(ds.flatten()[::7].quantile(0.95)),
+            "top300_pairs_in_common": common}

@@ -28,7 +28,7 @@ import torch
 import codetr_fp32 as M
 import fullsize_cases as F
 from conftest import ROOT
-from helpers_model import assert_close_lowp, seeded_params, valid_topk
+from helpers_model import assert_close_lowp, detection_agreement, seeded_params, valid_topk
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -122,6 +122,8 @@ def test_midsize_timed_route_vs_live_oracle():
     idx = hip_ops.topk(enc_max, 900, want_values=False)[1]
     ref = torch.sort(enc_max.float(), dim=-1, descending=True, stable=True)[1][:, :900]
     assert torch.equal(idx, ref)
+    errs.update(detection_agreement(cap, cap_o, H, W))
+    assert errs["box_err_px_mean"] <= 1.0 and errs["score_err_mean"] <= 5e-3, errs   # detection level: fp16 vs fp32
     _report("midsize_2x512x768_fp16", errs)
 
 

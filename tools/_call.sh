@@ -1,28 +1,18 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02c; mkdir -p $out
-timeout 600 python -m pytest tests/test_msda_encoder_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3
-for noise in 0 0.5 2; do
- for cfg in "1 0" "4 0" "1 1" "4 1" "8 1" "2 1"; do
-  set -- $cfg
-  echo -n "BAND=$1 STATIC=$2: "
-  CODETR_MSDA_BAND=$1 CODETR_MSDA_STATIC=$2 timeout 120 python tools/bench_msda_encoder.py --noise $noise --batch 4 2>&1 | tail -1
- done
-done | tee $out/msda_ab.txt
-for cfg in "1 0" "4 1"; do
- set -- $cfg
- for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_enc
-  CODETR_MSDA_BAND=$1 CODETR_MSDA_STATIC=$2 timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_enc -- python tools/bench_msda_encoder.py --iters 2 --noise 2 --batch 4 > /tmp/pmc.log 2>&1
-  f=$(find /tmp/pmc_enc -name "*counter_collection.csv" | head -1)
-  echo "BAND=$1 STATIC=$2 $c (KiB per launch, mean):"
-  python - "$f" <<'PY'
-import csv, collections, sys
-acc = collections.defaultdict(float); n = collections.Counter()
-for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"]
-    if "msda" in k:
-        k = k[28:60]; acc[k] += float(r["Counter_Value"]); n[k] += 1
-for k in acc: print("   ", k, "%.4e" % (acc[k] / n[k]), "launches", n[k])
+out=gpurun_out/r02d; mkdir -p $out
+timeout 900 python -m pytest tests/test_fp8_gpu.py tests/test_timed_route_gpu.py -k "midsize" -m gpu -q -p no:cacheprovider -x -s > $out/pytest_fp8.log 2>&1; echo "pytest rc $?" >> $out/pytest_fp8.log
+grep -E "^(FAILED|ERROR)|passed|failed|^E  |fp8 model errors|rc " $out/pytest_fp8.log | cut -c1-600 | head -40
+timeout 600 python bench.py --dtype fp8 --no-cpu-baseline > $out/bench_fp8.json 2> $out/bench_fp8.err; tail -3 $out/bench_fp8.err
+
+python - <<'PY'
+import json
+for n in ("fp8","f16"):
+    try:
+        d=json.loads(open(f"gpurun_out/r02d/bench_{n}.json").read().strip().splitlines()[-1])
+    except Exception as e:
+        print(n,"no json",e); continue
+    print(n, d["value"], "img/s", d["p50_ms_per_image"], "ms/img; lat1", d.get("latency_batch1",{}).get("p50_ms"))
+    for k in ("roofline","roofline_fp8","roofline_ffn","roofline_msda","roofline_msda_zero_noise"):
+        r=d.get(k)
+        if r: print("   ",k,r.get("achieved"),r.get("unit"),"frac",r.get("frac"),"sum_ms",r.get("sum_launch_ms"),"avg_us",r.get("avg_launch_us"), r.get("composite",{}).get("frac"))
 PY
- done
-done | tee $out/msda_pmc.txt
