@@ -648,7 +648,15 @@ int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, c
 // stay in flight across barriers (450 vs 376 us: the write-back costs the same trickled as in bulk, so it is not
 // issue latency -- most likely the 372 MB of output passing through the L2 / Infinity Cache evicts the activation
 // rows every column tile re-reads).  Next thing to try: non-temporal stores with a column-major tile walk.
-template <class T, int ACT, bool HAS_BIAS, bool HAS_RES>
+#ifdef CODETR_GEMM_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#endif
+// XDEEP: the X operand (the one that misses L2 more: each 256-row slice is shared by the N/256 column tiles only, the W
+// slices by every row tile) is prefetched TWO k-tiles ahead through a 3-slot ring that takes the last 32 KiB of the CU's
+// 160 KiB of LDS; W stays one tile ahead in its 2-slot ring.  In-kernel stamps (tools/micro/gemm256_stamps.hip) show
+// the 2-stage loop waiting for its LDS-DMA ~48 % of the time at 8 images (4300 cycles per k-tile against 2050 of MFMA
+// work): the operand fetch takes ~2 us under load and only one tile time was there to hide it.
+template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, bool XDEEP = false>
 __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* __restrict__ X,
                                                          const unsigned short* __restrict__ W,
                                                          const unsigned short* __restrict__ bias,
@@ -657,9 +665,17 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
                                                          const unsigned char* __restrict__ row_mask, int M, int N, int K,
                                                          int tiles_n) {
   constexpr int BKT = 64, NT = 512;
+#ifdef CODETR_GEMM_STAMPS   // diagnostic build only (tools/micro/gemm256_stamps.hip): in-kernel timeline of every workgroup
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+  if (threadIdx.x == 0) {
+    st0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   constexpr int kTileBytes = 256 * BKT * 2;   // 32 KiB: one operand tile
   constexpr int kStageBytes = 2 * kTileBytes;  // W tile + X tile
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes];  // 128 KiB, one object
+  // 2-stage ring: [W0 X0][W1 X1] (128 KiB).  XDEEP: [X0 X1 X2][W0 W1] (160 KiB, the whole LDS of the CU)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[XDEEP ? 5 * kTileBytes : 2 * kStageBytes];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -712,18 +728,54 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     }
   };
   const int nk = K / BKT;
-  issue(0);
+  auto dma16 = [&](const unsigned short* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  };
+  if (XDEEP) {   // issue order W(0), X(0), X(1): the youngest four pieces may stay in flight at the first wait
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma16(gw[q], lds + 3 * kTileBytes + (q * NT + wave * 64) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma16(gx[q], lds + (q * NT + wave * 64) * 16);
+    const size_t k1 = (size_t)(nk > 1 ? 1 : 0) * BKT;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma16(gx[q] + k1, lds + kTileBytes + (q * NT + wave * 64) * 16);
+  } else {
+    issue(0);
+  }
+#ifdef CODETR_GEMM_STAMPS
+  unsigned long long wait_dma = 0, wait_bar = 0;
+#endif
+  int xs = 0;  // XDEEP: ring slot of X(t)
   for (int t = 0; t < nk; ++t) {
-    wait_vmcnt<0>();
+#ifdef CODETR_GEMM_STAMPS
+    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+    if (XDEEP) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long w2 = __builtin_amdgcn_s_memtime();
+    wait_dma += w1 - w0;
+    wait_bar += w2 - w1;
+#else
+    if (XDEEP) wait_vmcnt<4>();   // W(t) and X(t) have landed; the four pieces of X(t+1) may still be in flight
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // tile t is in LDS for everyone; everyone is done reading tile t-1
-    const unsigned char* bufW = lds + (t & 1) * kStageBytes;
-    const unsigned char* bufX = bufW + kTileBytes;
+#endif
+    const unsigned char* bufW = XDEEP ? lds + (3 + (t & 1)) * kTileBytes : lds + (t & 1) * kStageBytes;
+    const unsigned char* bufX = XDEEP ? lds + xs * kTileBytes : bufW + kTileBytes;
     // One workgroup per CU: its 8 waves reach this point together, so nothing else covers a burst of DMA issue or an
     // LDS wait.  The schedule is pinned: fragments of k-step 1 are read behind the first two MFMAs of step 0, and the
     // 8 DMA pieces of tile t+1 go out one per 3 MFMAs of step 0 (early enough to land under step 1).  Past the last
     // tile the pieces re-fetch it into the idle buffer (no branch in the pinned region); drained before the epilogue.
     const size_t koff = (size_t)(t + 1 < nk ? t + 1 : t) * BKT;
     unsigned char* nbuf = lds + ((t + 1) & 1) * kStageBytes;
+    // XDEEP: W(t+1) -> the W slot tile t-1 used, X(t+2) -> the X slot tile t-1 used (re-fetches of the last tile past
+    // the end keep the in-flight count uniform)
+    const size_t koffx = (size_t)(t + 2 < nk ? t + 2 : nk - 1) * BKT;
+    unsigned char* nbufW = XDEEP ? lds + (3 + ((t + 1) & 1)) * kTileBytes : nbuf;
+    const int xs2 = xs >= 1 ? xs - 1 : 2;   // (xs + 2) % 3
+    unsigned char* nbufX = XDEEP ? lds + xs2 * kTileBytes : nbuf + kTileBytes;
+    xs = xs == 2 ? 0 : xs + 1;
     typename T::frag a[2][4], b[2][8];
     auto read_frags = [&](int ks, int buf) {
 #pragma unroll
@@ -735,13 +787,17 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
     // ---- k-step 0 ----
     read_frags(1, 1);
+    if (XDEEP) {   // W first: it is needed one tile from now, X two
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[q] + koff),
-                                       (__attribute__((address_space(3))) void*)(nbuf + (q * NT + wave * 64) * 16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx[q] + koff),
-                                       (__attribute__((address_space(3))) void*)(nbuf + kTileBytes + (q * NT + wave * 64) * 16),
-                                       16, 0, 0);
+      for (int q = 0; q < 4; ++q) dma16(gw[q] + koff, nbufW + (q * NT + wave * 64) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma16(gx[q] + koffx, nbufX + (q * NT + wave * 64) * 16);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        dma16(gw[q] + koff, nbufW + (q * NT + wave * 64) * 16);
+        dma16(gx[q] + koff, nbufX + (q * NT + wave * 64) * 16);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -764,6 +820,9 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
   }
   wait_vmcnt<0>();  // the redundant pieces of the last iteration have landed
   __builtin_amdgcn_s_barrier();  // all fragment reads done, no DMA in flight: LDS is free for the epilogue
+#ifdef CODETR_GEMM_STAMPS
+  if (threadIdx.x == 0) st1 = __builtin_amdgcn_s_memtime();
+#endif
 
   // epilogue in two 64-row halves per wave through its private staging region (64 rows x 144 B)
   constexpr int kPitch = kStagePitch;
@@ -832,6 +891,16 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     }
     __builtin_amdgcn_wave_barrier();  // the region is rewritten by the second half
   }
+#ifdef CODETR_GEMM_STAMPS
+  if (threadIdx.x == 0 && g_stamps) {
+    st2 = __builtin_amdgcn_s_memtime();   // all stores of wave 0 issued (not completed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();   // ... and completed
+    unsigned long long* o = g_stamps + 8 * (size_t)blockIdx.x;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
+    o[6] = wait_dma; o[7] = wait_bar;
+  }
+#endif
 }
 
 // the 256-tile kernel: K >= 256 (CODETR_BIG_MIN_K; K = 256 layers whose N fills 256-wide tiles -- value / output
@@ -862,10 +931,22 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (bias && R) hipLaunchKernelGGL((linear_256_kernel<T, ACT, true, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else if (bias) hipLaunchKernelGGL((linear_256_kernel<T, ACT, true, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else if (R) hipLaunchKernelGGL((linear_256_kernel<T, ACT, false, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
-  else hipLaunchKernelGGL((linear_256_kernel<T, ACT, false, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n);
+  // A/B switch, default on (8 images: -3 ... -13 % on every Swin stage 1-3 shape, gpurun_out/r02g/xdeep.txt)
+  static const bool xdeep = [] { const char* e = getenv("CODETR_GEMM_XDEEP"); return e ? atoi(e) != 0 : true; }();
+#define CODETR_L256(HB, HR, XD) \
+  hipLaunchKernelGGL((linear_256_kernel<T, ACT, HB, HR, XD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n)
+  if (xdeep && K >= 128) {
+    if (bias && R) CODETR_L256(true, true, true);
+    else if (bias) CODETR_L256(true, false, true);
+    else if (R) CODETR_L256(false, true, true);
+    else CODETR_L256(false, false, true);
+  } else {
+    if (bias && R) CODETR_L256(true, true, false);
+    else if (bias) CODETR_L256(true, false, false);
+    else if (R) CODETR_L256(false, true, false);
+    else CODETR_L256(false, false, false);
+  }
+#undef CODETR_L256
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }

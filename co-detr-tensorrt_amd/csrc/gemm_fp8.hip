@@ -20,6 +20,7 @@
 // Requirements: K % 128 == 0, N % 8 == 0, 16-byte aligned bases; M arbitrary.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "codetr_hip.h"
 
@@ -91,8 +92,9 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
                                                              int tiles_n) {
   constexpr int NT = 512;
   constexpr int kTileBytes = 256 * 128;        // 32 KiB: one operand tile (256 rows x 128 bytes of K)
-  constexpr int kStageBytes = 2 * kTileBytes;  // W tile + X tile
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes];  // 128 KiB
+  // LDS = [X0 X1 X2][W0 W1], 160 KiB (all of the CU's): X is prefetched two k-tiles ahead, W one (the XDEEP form of
+  // linear_256_kernel -- with k-tiles half as long in time as fp16's, hiding the ~2 us operand fetch matters more here)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[5 * kTileBytes];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -124,20 +126,29 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
   };
   const int nk = K / 128;
+  // issue order W(0), X(0), X(1): the youngest four pieces may stay in flight at the first wait
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    dma(gw[q], lds + (q * NT + wave * 64) * 16);
-    dma(gx[q], lds + kTileBytes + (q * NT + wave * 64) * 16);
+  for (int q = 0; q < 4; ++q) dma(gw[q], lds + 3 * kTileBytes + (q * NT + wave * 64) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(gx[q], lds + (q * NT + wave * 64) * 16);
+  {
+    const size_t k1 = (size_t)(nk > 1 ? 1 : 0) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma(gx[q] + k1, lds + kTileBytes + (q * NT + wave * 64) * 16);
   }
+  int xs = 0;  // ring slot of X(t)
   for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // W(t), X(t) landed; the four pieces of X(t+1) may be in flight
     __builtin_amdgcn_s_barrier();  // tile t is in LDS for everyone; everyone is done reading tile t-1
-    const unsigned char* bufW = lds + (t & 1) * kStageBytes;
-    const unsigned char* bufX = bufW + kTileBytes;
-    // tile t+1 -> the other buffer, one piece per m-tile below (past the last tile: re-fetch it, no branch; drained
-    // before the epilogue)
-    const size_t koff = (size_t)(t + 1 < nk ? t + 1 : t) * 128;
-    unsigned char* nbuf = lds + ((t + 1) & 1) * kStageBytes;
+    const unsigned char* bufW = lds + (3 + (t & 1)) * kTileBytes;
+    const unsigned char* bufX = lds + xs * kTileBytes;
+    // W(t+1) -> the W slot tile t-1 used, X(t+2) -> the X slot tile t-1 used, one piece per m-tile below, W first (past
+    // the last tile: re-fetch it, no branch; drained before the epilogue)
+    const size_t koffw = (size_t)(t + 1 < nk ? t + 1 : nk - 1) * 128;
+    const size_t koffx = (size_t)(t + 2 < nk ? t + 2 : nk - 1) * 128;
+    unsigned char* nbufW = lds + (3 + ((t + 1) & 1)) * kTileBytes;
+    unsigned char* nbufX = lds + (xs >= 1 ? xs - 1 : 2) * kTileBytes;
+    xs = xs == 2 ? 0 : xs + 1;
     i32x8 a[4], b[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = read_frag(bufW, wn * 64 + i * 16 + frow, fg);
@@ -146,11 +157,8 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < 7) b[(j + 1) & 1] = read_frag(bufX, wm * 128 + (j + 1) * 16 + frow, fg);
-      {
-        const int q = j >> 1;
-        if (j & 1) dma(gx[q] + koff, nbuf + kTileBytes + (q * NT + wave * 64) * 16);
-        else dma(gw[q] + koff, nbuf + (q * NT + wave * 64) * 16);
-      }
+      if (j < 4) dma(gw[j] + koffw, nbufW + (j * NT + wave * 64) * 16);
+      else dma(gx[j - 4] + koffx, nbufX + ((j - 4) * NT + wave * 64) * 16);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j & 1], acc[i][j], 0, 0, 0, 0, 0, 0);

@@ -16,3 +16,17 @@ for name, M, N, K, act, res in S:
     tg = timeit(lambda: F.linear(x, w, b))   # GEMM + bias only (no act / residual kernels)
     fl = 2.0 * M * N * K
     print(f"{name:12s} M={M:8d} N={N:5d} K={K:5d}  native {tn*1e6:8.1f} us {fl/tn/1e12:7.1f} TF/s | hipBLASLt gemm+bias only {tg*1e6:8.1f} us {fl/tg/1e12:7.1f} TF/s")
+if "--fp8" in sys.argv:
+    FP8 = torch.float8_e4m3fn
+    from codetr import _cabi
+    for name, M, N, K, act, res in S:
+        if K % 128:
+            continue
+        x8 = (torch.randn(M, K, device="cuda") * 40).to(FP8); w8 = (torch.randn(N, K, device="cuda") * 60).to(FP8)
+        ws = torch.rand(N, device="cuda") * 1e-3; b = torch.randn(N, device="cuda").half()
+        r = torch.randn(M, N, device="cuda").half() if res else None
+        out8 = act == "gelu"
+        out = torch.empty(M, N, dtype=FP8 if out8 else torch.float16, device="cuda")
+        tn = timeit(lambda: _cabi.linear_fp8(x8, w8, ws, 0.01, b, r, act, out, 0.05 if out8 else 0.0))
+        fl = 2.0 * M * N * K
+        print(f"fp8 {name:12s} M={M:8d} N={N:5d} K={K:5d}  {tn*1e6:8.1f} us {fl/tn/1e12:7.1f} TF/s  (out {'e4m3' if out8 else 'f16'})")
