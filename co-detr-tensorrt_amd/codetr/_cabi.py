@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 33
+ABI_VERSION = 35
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -54,6 +54,11 @@ SIGNATURES = {
     "codetr_topk_bf16": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
     "codetr_linear_variant": (_cp, [_i64, _i64, _i64, _i32, _i32, _i32]),
+    "codetr_add_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64]),
+    "codetr_sigmoid_f16": (_i32, [_vp, _vp, _vp, _i64]),
+    "codetr_gather_rows_b16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
+    "codetr_decode_boxes_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, ctypes.c_float, ctypes.c_float]),
+    "codetr_valid_ratios_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32]),
     "codetr_linear_fp8": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i32, ctypes.c_float, _i64, _i64, _i64,
                                  _i32]),
     "codetr_cast_fp8_f16": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float]),
@@ -68,7 +73,7 @@ SIGNATURES = {
     "codetr_batched_nms_f32": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float, _vp]),
     "codetr_patch_merge_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float]),
     "codetr_patch_merge_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float]),
-    "codetr_mask_pyramid": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "codetr_mask_pyramid": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32]),
     "codetr_linear_splitk_plan": (_i32, [_i64, _i64, _i64, _vp]),
     "codetr_linear_splitk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
     "codetr_linear_splitk_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
@@ -105,14 +110,47 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
          "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0,
-         "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0}
+         "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0}
+
+
+# Launch recording (codetr/export.py): while RECORDER is a list, every launch-type entry point called through `load()`
+# appends (name, args) -- the raw ctypes-level arguments: ints (device pointers, sizes), floats, None, ctypes arrays
+# (host data such as level shapes).  Pure host queries (plans, variants, workspace sizes) are not launches.
+RECORDER = None
+_QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
+            "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes"}
+
+
+class _RecordingLib:
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in _QUERIES or name not in SIGNATURES:
+            return fn
+
+        def launch(*args):
+            rc = fn(*args)
+            if RECORDER is not None:
+                RECORDER.append((name, args))
+            return rc
+
+        return launch
+
+
+_rec_lib = None
 
 
 def load():
     """Load the shared library once; raise ImportError (loudly) if it is absent or stale."""
-    global _lib
+    global _lib, _rec_lib
     if _lib is not None:
-        return _lib
+        if RECORDER is None:
+            return _lib
+        if _rec_lib is None:
+            _rec_lib = _RecordingLib(_lib)
+        return _rec_lib
     if not os.path.isfile(LIB_PATH):
         raise ImportError(
             f"HIP extension not found at {LIB_PATH}; build it with "
@@ -327,7 +365,8 @@ def mask_pyramid(img_masks, shapes):
     counts = torch.empty((B, L, 2), dtype=torch.float32, device=dev)
     hw = (ctypes.c_int64 * (2 * L))(*[int(v) for s in shapes for v in s])
     rc = load().codetr_mask_pyramid(current_stream_ptr(dev), img_masks.data_ptr(), B, Hi, Wi, L, hw,
-                                    mask_flat.data_ptr(), cums[0].data_ptr(), cums[1].data_ptr(), counts.data_ptr())
+                                    mask_flat.data_ptr(), cums[0].data_ptr(), cums[1].data_ptr(), counts.data_ptr(),
+                                    img_masks.element_size())
     check(rc, "codetr_mask_pyramid")
     return mask_flat, cums[0], cums[1], counts
 
@@ -449,7 +488,7 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points,
     shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
     ncols, es = proj.shape[2], proj.element_size()
     rc = getattr(lib, _MSDA_ENCODER_BY_DTYPE[value.dtype])(
-        current_stream_ptr(value.device), value.data_ptr(), ctypes.cast(shapes, ctypes.c_void_p),
+        current_stream_ptr(value.device), value.data_ptr(), shapes,
         proj.data_ptr() + off_col * es, ncols, proj.data_ptr() + logit_col * es, ncols, ref.data_ptr(), B, S, M, D, L,
         num_points, int(halo), out.data_ptr())
     if rc == E_UNSUPPORTED:
@@ -663,3 +702,41 @@ def layernorm_fp8(x2d, weight, bias, eps, scale, out2d):
                                          out2d.data_ptr(), rows, C, float(eps), float(scale))
     check(rc, "codetr_layernorm_fp8_f16")
     return out2d
+
+
+# ---- small element-wise / gather kernels (csrc/small_ops.hip) -------------------------------------------------
+def add_f16(a, b, out, a_period):
+    CALLS["small_ops"] += 1
+    check(load().codetr_add_f16(current_stream_ptr(b.device), a.data_ptr(), b.data_ptr(), out.data_ptr(), b.numel(), a_period),
+          "codetr_add_f16")
+    return out
+
+
+def sigmoid_f16(x, out):
+    CALLS["small_ops"] += 1
+    check(load().codetr_sigmoid_f16(current_stream_ptr(x.device), x.data_ptr(), out.data_ptr(), x.numel()), "codetr_sigmoid_f16")
+    return out
+
+
+def gather_rows(src, idx, out):
+    CALLS["small_ops"] += 1
+    B, S, C = src.shape
+    check(load().codetr_gather_rows_b16(current_stream_ptr(src.device), src.data_ptr(), idx.data_ptr(), out.data_ptr(), B, S,
+                                        idx.shape[1], C), "codetr_gather_rows_b16")
+    return out
+
+
+def decode_boxes(coords_unact, idx, num_classes, img_w, img_h, boxes, labels):
+    CALLS["small_ops"] += 1
+    B, Nq, _ = coords_unact.shape
+    check(load().codetr_decode_boxes_f16(current_stream_ptr(idx.device), coords_unact.data_ptr(), idx.data_ptr(), boxes.data_ptr(),
+                                         labels.data_ptr(), B, Nq, idx.shape[1], num_classes, float(img_w), float(img_h)),
+          "codetr_decode_boxes_f16")
+
+
+def valid_ratios(counts, level_wh, out):
+    CALLS["small_ops"] += 1
+    B, L, _ = counts.shape
+    check(load().codetr_valid_ratios_f16(current_stream_ptr(counts.device), counts.data_ptr(), level_wh.data_ptr(), out.data_ptr(),
+                                         B, L), "codetr_valid_ratios_f16")
+    return out

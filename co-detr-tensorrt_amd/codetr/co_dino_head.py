@@ -141,25 +141,29 @@ class CoDINOHead(nn.Module):
         lvl = len(self.transformer.decoder.layers) - 1
         cls_head = self.cls_branches[lvl]
         cls = hip_ops.linear(state, cls_head.weight, cls_head.bias)  # [B,Nq,classes]
-        tmp = run_mlp(self.reg_branches[lvl], state)
         if refs.shape[-1] == 4:
-            tmp = tmp + refs
+            tmp = run_mlp(self.reg_branches[lvl], state, residual=refs)   # `tmp += refs` in the last Linear's epilogue
         else:
             if refs.shape[-1] != 2:
                 raise AssertionError("reference points must be 2-d or 4-d")
+            tmp = run_mlp(self.reg_branches[lvl], state)
             tmp = torch.cat((tmp[..., :2] + refs, tmp[..., 2:]), -1)
-        coords = tmp.sigmoid()
+        B = tmp.shape[0]
         if capture is not None:
-            capture.update(final_state=state, final_refs_unact=refs, outputs_classes=cls, outputs_coords=coords)
-        B = coords.shape[0]
+            capture.update(final_state=state, final_refs_unact=refs, outputs_classes=cls, outputs_coords=hip_ops.sigmoid(tmp))
         if self.use_sigmoid:
-            scores, idx = hip_ops.topk(cls.sigmoid().view(B, -1), self.max_per_img)
+            scores, idx = hip_ops.topk(hip_ops.sigmoid(cls).view(B, -1), self.max_per_img)
+            if hip_ops.decode_boxes_supported(tmp, idx):
+                # label = idx % C, query = idx // C, sigmoid, cxcywh -> xyxy, scale, clamp: one launch
+                boxes, labels = hip_ops.decode_boxes(tmp, idx, self.num_classes, Wimg, Himg)
+                return boxes, scores, labels
             labels = idx % self.num_classes
             q = idx // self.num_classes
         else:
             s, labels_all = F.softmax(cls, dim=-1)[..., :-1].max(-1)
             scores, q = hip_ops.topk(s, self.max_per_img)
             labels = torch.gather(labels_all, 1, q)
+        coords = tmp.sigmoid()
         boxes = bbox_cxcywh_to_xyxy(torch.gather(coords, 1, q.unsqueeze(-1).expand(-1, -1, 4)))
         key = (Wimg, Himg, boxes.dtype, str(boxes.device))
         scale = self._scale_cache.get(key)

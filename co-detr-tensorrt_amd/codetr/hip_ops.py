@@ -30,7 +30,9 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "patch_embed(f16/bf16: 4x4 patch gather + GEMM)",
           "mha_attention(f16/bf16: dense softmax attention, head_dim 32, <= 1024 keys)",
           "topk(f16/bf16 rows, k <= 1024: radix select + bitonic sort)",
-          "im2col_tokens(16-bit token-major maps)"}
+          "im2col_tokens(16-bit token-major maps)",
+          "small_ops(f16: add, sigmoid, gather_rows, decode_boxes, valid_ratios)",
+          "linear_fp8(e4m3 x e4m3, K%128==0) + layer_norm_fp8 + cast_fp8"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -403,8 +405,8 @@ def mask_pyramid(img_masks, shapes):
     fp32 buffers; `level_cums` slices out one level as [B,H_l,W_l]."""
     _gpu(img_masks, "mask_pyramid")
     m = img_masks
-    if m.dtype != torch.bool and m.dtype != torch.uint8:
-        m = m != 0
+    if m.dtype not in (torch.bool, torch.uint8, torch.float16, torch.bfloat16, torch.float32):
+        m = m != 0     # (other dtypes: one comparison kernel; the kernel tests the three element widths itself)
     with torch.cuda.device(m.device):
         return _cabi.mask_pyramid(m.contiguous(), [tuple(int(v) for v in s) for s in shapes])
 
@@ -706,3 +708,79 @@ def layer_norm_fp8(x, weight, bias, eps, scale):
     with torch.cuda.device(x.device):
         _cabi.layernorm_fp8(x2, weight, bias, eps, scale, out)
     return out.view(x.shape)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small element-wise / gather kernels of the decoder and the head (csrc/small_ops.hip); the torch formulation serves
+# fp32 / bf16 parity runs and autograd
+# ---------------------------------------------------------------------------------------------------------------
+def _native16(*ts):
+    return (not torch.is_grad_enabled()) and all(t.is_cuda and t.dtype == torch.float16 and t.data_ptr() % 16 == 0 for t in ts)
+
+
+def add(a, b):
+    """a + b for same-shape fp16 tensors, or `a` broadcast over b's leading dimension (a stride-0 batch view of a
+    parameter, e.g. query_embed.weight[None].expand(B, ...)): `query + query_pos` of the attention layers"""
+    _gpu(b, "add")
+    if _native16(a, b) and a.shape == b.shape and b.is_contiguous() and b.numel() % 8 == 0:
+        period = None
+        if a.is_contiguous():
+            period = b.numel()
+        elif a.dim() >= 2 and a.stride(0) == 0 and a[0].is_contiguous() and a[0].numel() % 8 == 0:
+            period = a[0].numel()
+        if period is not None:
+            out = torch.empty_like(b)
+            with torch.cuda.device(b.device):
+                _cabi.add_f16(a, b, out, period)
+            return out
+    return a + b
+
+
+def sigmoid(x):
+    _gpu(x, "sigmoid")
+    if _native16(x) and x.is_contiguous():
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _cabi.sigmoid_f16(x, out)
+        return out
+    return x.sigmoid()
+
+
+def gather_rows(src, idx):
+    """src [B,S,C], idx [B,K] int64 -> [B,K,C] = torch.gather(src, 1, idx[..., None].expand(-1, -1, C))"""
+    _gpu(src, "gather_rows")
+    C = src.shape[-1]
+    if (_native16(src) and src.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous() and C % 4 == 0
+            and src.data_ptr() % 16 == 0):
+        out = torch.empty((idx.shape[0], idx.shape[1], C), dtype=src.dtype, device=src.device)
+        with torch.cuda.device(src.device):
+            _cabi.gather_rows(src, idx, out)
+        return out
+    return torch.gather(src, 1, idx.unsqueeze(-1).expand(-1, -1, C))
+
+
+def decode_boxes_supported(coords_unact, idx):
+    return _native16(coords_unact) and coords_unact.is_contiguous() and coords_unact.shape[-1] == 4 and idx.is_contiguous()
+
+
+def decode_boxes(coords_unact, idx, num_classes, img_w, img_h):
+    """head decode in one launch (reference co_dino_head.py:177-209): coords_unact [B,Nq,4] (box branch + reference,
+    before the sigmoid), idx [B,K] into the flattened (query, class) scores -> (boxes [B,K,4] xyxy pixels, labels [B,K])"""
+    _gpu(coords_unact, "decode_boxes")
+    B, K = idx.shape
+    boxes = torch.empty((B, K, 4), dtype=coords_unact.dtype, device=coords_unact.device)
+    labels = torch.empty((B, K), dtype=torch.int64, device=coords_unact.device)
+    with torch.cuda.device(coords_unact.device):
+        _cabi.decode_boxes(coords_unact, idx, num_classes, img_w, img_h, boxes, labels)
+    return boxes, labels
+
+
+def valid_ratios(counts, level_wh):
+    """counts [B,L,2] fp32 (mask_pyramid) , level_wh [L,2] (W_l, H_l) in the model dtype -> valid ratios [B,L,2]"""
+    _gpu(counts, "valid_ratios")
+    if _native16(level_wh) and counts.dtype == torch.float32 and counts.is_contiguous() and level_wh.is_contiguous():
+        out = torch.empty(counts.shape, dtype=level_wh.dtype, device=counts.device)
+        with torch.cuda.device(counts.device):
+            _cabi.valid_ratios(counts, level_wh, out)
+        return out
+    return counts.to(level_wh.dtype) / level_wh

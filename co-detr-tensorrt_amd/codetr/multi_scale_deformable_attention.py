@@ -109,7 +109,7 @@ class MultiScaleDeformableAttention(nn.Module):
             if self.takes_pos_in_gemm(query, query_pos, value):
                 pos_in_gemm = query_pos
             else:
-                query = query + query_pos
+                query = hip_ops.add(query, query_pos)
         B, Nq, _ = query.shape
         S = value.shape[1]
         H, L, P = self.num_heads, self.num_levels, self.num_points

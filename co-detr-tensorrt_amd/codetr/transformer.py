@@ -127,12 +127,14 @@ class DinoTransformerDecoder(nn.Module):
     def forward_bf(self, query, value, key_padding_mask, reference_points, valid_ratios, reg_branches, **kw):
         """query [B,Nq,C], value [B,S,C], reference_points [B,Nq,4] unactivated."""
         out = query
-        vr = torch.cat((valid_ratios, valid_ratios), -1) if reference_points.shape[-1] == 4 else valid_ratios
+        vr = None   # (only the ATen formulation below needs the tiled valid ratios)
         v_all = self._project_values(value, key_padding_mask)
         for lid, layer in enumerate(self.layers):
             if hip_ops.query_sine_embed_supported(reference_points, valid_ratios, self.embed_dims // 2):
                 ref_in, sine = hip_ops.query_sine_embed(reference_points, valid_ratios, self.embed_dims // 2)
             else:
+                if vr is None:
+                    vr = torch.cat((valid_ratios, valid_ratios), -1) if reference_points.shape[-1] == 4 else valid_ratios
                 ref_in = reference_points[:, :, None].sigmoid() * vr[:, None]  # [B,Nq,L,4]
                 sine = self.gen_sineembed_for_position(ref_in[:, :, 0, :], self.embed_dims // 2)
             qpos = run_mlp(self.ref_point_head, sine)
@@ -376,7 +378,7 @@ class CoDinoTransformer(nn.Module):
         spatial_shapes, level_start_index = _shape_tensors(shapes, dev)
         if valid_counts is not None:
             # sum(~mask[:, 0, :]) / W, sum(~mask[:, :, 0]) / H of get_valid_ratio, from the counts of the pyramid kernel
-            valid_ratios = valid_counts.to(feat.dtype) / _level_wh(shapes, feat.dtype, dev)  # [B,L,2]
+            valid_ratios = hip_ops.valid_ratios(valid_counts, _level_wh(shapes, feat.dtype, dev))  # [B,L,2]
         else:
             valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
         native_geom = feat.is_cuda and feat.dtype == torch.float16 and mask.dtype == torch.bool
@@ -406,11 +408,16 @@ class CoDinoTransformer(nn.Module):
             topk = hip_ops.topk(hip_ops.row_max(enc_cls), self.two_stage_num_proposals, want_values=False)[1]
         else:
             topk = forced_topk_indices
-        gidx = topk.unsqueeze(-1)
         # the box branch is row-wise: run it on the selected rows only (900 instead of all S tokens)
-        sel = torch.gather(out_mem, 1, gidx.expand(-1, -1, out_mem.shape[-1]))
-        topk_coords = run_mlp(reg_branches[last], sel, residual=torch.gather(proposals, 1, gidx.expand(-1, -1, 4)))
-        query = self.query_embed.weight[None].expand(B, -1, -1)
+        sel = hip_ops.gather_rows(out_mem, topk)
+        topk_coords = run_mlp(reg_branches[last], sel, residual=hip_ops.gather_rows(proposals, topk))
+        qw = self.query_embed.weight
+        if B == 1 or not qw.is_cuda:
+            query = qw[None].expand(B, -1, -1)
+        else:
+            # one materialised [B, Nq, C] copy per batch size, kept on the parameter (the decoder's first layer uses it
+            # as a GEMM residual, which needs real rows): no per-forward broadcast copy
+            query = hip_ops.derived((qw,), f"_codetr_query_b{B}", lambda: qw.detach()[None].expand(B, -1, -1).contiguous())
         if capture is not None:
             # the reference's all-rows form (:555-557), for inspection only: what feeds the decoder is `topk_coords`
             enc_coord = run_mlp(reg_branches[last], out_mem) + proposals

@@ -106,11 +106,11 @@ class MultiheadAttention(nn.Module):
         identity = query if identity is None else identity
         if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
             key_pos = query_pos
-        q = query + query_pos if query_pos is not None else query
+        q = hip_ops.add(query, query_pos) if query_pos is not None else query
         if key is query and key_pos is query_pos:
             k = q  # self-attention: one add, and q | k projected by one GEMM below
         else:
-            k = key + key_pos if key_pos is not None else key
+            k = hip_ops.add(key, key_pos) if key_pos is not None else key
         C = self.embed_dims
         W, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         if q is k:

@@ -42,6 +42,9 @@ __device__ __forceinline__ int level_of(const Levels& lv, int L, int64_t s) {
   return l;
 }
 
+// EB = bytes per mask element: 1 (bool / uint8), 2 (fp16 / bf16) or 4 (fp32); "non-zero" ignores the sign bit of the
+// floating-point forms (-0.0 is zero, NaN is not), i.e. `mask != 0` without a separate comparison kernel
+template <int EB>
 __global__ __launch_bounds__(256) void level_mask_kernel(const unsigned char* __restrict__ img, int Hi, int Wi, Levels lv,
                                                          int L, int64_t S, int64_t total,
                                                          unsigned char* __restrict__ mask_flat) {
@@ -54,7 +57,10 @@ __global__ __launch_bounds__(256) void level_mask_kernel(const unsigned char* __
   const int H = lv.h[l], W = lv.w[l];
   const int y = r / W, x = r - y * W;
   const float sy = (float)Hi / (float)H, sx = (float)Wi / (float)W;
-  mask_flat[i] = img[((size_t)b * Hi + src_index(y, sy, Hi)) * Wi + src_index(x, sx, Wi)] != 0;
+  const size_t e = ((size_t)b * Hi + src_index(y, sy, Hi)) * Wi + src_index(x, sx, Wi);
+  if (EB == 1) mask_flat[i] = img[e] != 0;
+  else if (EB == 2) mask_flat[i] = (reinterpret_cast<const unsigned short*>(img)[e] & 0x7fffu) != 0;
+  else mask_flat[i] = (reinterpret_cast<const unsigned*>(img)[e] & 0x7fffffffu) != 0;
 }
 
 // One wave per task.  Tasks of image b: first every row of every level (xcum: ballot + popcount prefix, 64 columns
@@ -105,7 +111,8 @@ extern "C" {
 
 int codetr_mask_pyramid(void* stream, const void* img_mask_dev, int64_t B, int64_t H_img, int64_t W_img, int num_levels,
                         const int64_t* level_shapes_host, void* mask_flat_dev, float* ycum_dev, float* xcum_dev,
-                        float* valid_counts_dev) {
+                        float* valid_counts_dev, int mask_elem_bytes) {
+  if (mask_elem_bytes != 1 && mask_elem_bytes != 2 && mask_elem_bytes != 4) return CODETR_E_UNSUPPORTED;
   if (!img_mask_dev || !level_shapes_host || !mask_flat_dev || !ycum_dev || !xcum_dev || !valid_counts_dev || B <= 0 ||
       H_img <= 0 || W_img <= 0 || num_levels <= 0)
     return CODETR_E_BADARG;
@@ -126,7 +133,8 @@ int codetr_mask_pyramid(void* stream, const void* img_mask_dev, int64_t B, int64
   if ((total + 255) / 256 > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(level_mask_kernel, grid, block, 0, st, static_cast<const unsigned char*>(img_mask_dev), (int)H_img,
+  auto mk = mask_elem_bytes == 1 ? level_mask_kernel<1> : (mask_elem_bytes == 2 ? level_mask_kernel<2> : level_mask_kernel<4>);
+  hipLaunchKernelGGL(mk, grid, block, 0, st, static_cast<const unsigned char*>(img_mask_dev), (int)H_img,
                      (int)W_img, lv, num_levels, S, total, static_cast<unsigned char*>(mask_flat_dev));
   int rows_total = 0, strips_total = 0;
   for (int l = 0; l < num_levels; ++l) {

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 33
+#define CODETR_HIP_ABI_VERSION 35
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -281,6 +281,28 @@ int codetr_cast_fp8_f16(void *stream, const void *x_f16_dev, void *y8_dev, int64
 int codetr_layernorm_fp8_f16(void *stream, const void *x_f16_dev, const void *gamma_f16_dev, const void *beta_f16_dev,
                              void *y8_dev, int64_t rows, int64_t C, float eps, float scale);
 
+/* ------------------------------------------------------------------------------------------
+ * Small fp16 element-wise / gather kernels of the decoder and the detection head (csrc/small_ops.hip): the last
+ * ATen launches of the fp16 forward, bit-identical to the ATen formulation (one fp16 rounding per operation).
+ *   codetr_add_f16           out[i] = a[i % a_period] + b[i]  (`query + query_pos`, reference transformer_mmcv.py:400-404;
+ *                            a_period < n broadcasts `a`, e.g. query_embed.weight over the batch); n, a_period % 8 == 0
+ *   codetr_sigmoid_f16       out = 1 / (1 + exp(-x))            (co_dino_head.py:181)
+ *   codetr_gather_rows_b16   out[b,k,:] = src[b, idx[b,k], :]   (transformer.py:562-566; 16-bit rows, C % 4 == 0)
+ *   codetr_decode_boxes_f16  q = idx / C, label = idx % C, sigmoid -> cxcywh -> xyxy -> x (W,H,W,H) -> clamp
+ *                            (co_dino_head.py:177-209 + mmdet bbox_cxcywh_to_xyxy); coords_unact [B,Nq,4] = box branch
+ *                            output + reference (before the sigmoid); boxes [B,K,4] fp16, labels [B,K] int64
+ *   codetr_valid_ratios_f16  out[b,l,j] = fp16(counts[b,l,j]) / level_wh[l,j]   (transformer.py:384-400)
+ * ------------------------------------------------------------------------------------------ */
+int codetr_add_f16(void *stream, const void *a_dev, const void *b_dev, void *out_dev, int64_t n, int64_t a_period);
+int codetr_sigmoid_f16(void *stream, const void *x_dev, void *out_dev, int64_t n);
+int codetr_gather_rows_b16(void *stream, const void *src_dev, const int64_t *idx_dev, void *out_dev, int64_t B, int64_t S,
+                           int64_t K, int64_t C);
+int codetr_decode_boxes_f16(void *stream, const void *coords_unact_dev, const int64_t *idx_dev, void *boxes_dev,
+                            int64_t *labels_dev, int64_t B, int64_t Nq, int64_t K, int num_classes, float img_w,
+                            float img_h);
+int codetr_valid_ratios_f16(void *stream, const float *counts_dev, const void *level_wh_f16_dev, void *out_dev, int64_t B,
+                            int L);
+
 /* Split-K form of the same layer for problems with few output tiles and a long K -- the neck's extra
  * 3x3 / stride-2 level (codetr/codetr.py neck, mmdet ChannelMapper extra_convs) run as a GEMM over unfolded
  * patches is [600, 13824] x [256, 13824]^T: 10 output tiles, one pass leaves 246 CUs idle.
@@ -306,7 +328,9 @@ int codetr_linear_splitk_bf16(void *stream, const void *x_dev, const void *w_dev
  * not_mask.cumsum(1) / cumsum(2) (codetr/positional_encoding.py:78-79), the two sums of get_valid_ratio
  * (codetr/transformer.py:384-399) and mask.flatten(1) + cat (codetr/transformer.py:513-520).
  *
- *   img_mask_dev        [B, H_img, W_img] uint8 / bool, non-zero = padding
+ *   img_mask_dev        [B, H_img, W_img], non-zero = padding; mask_elem_bytes = 1 (bool / uint8), 2 (fp16 / bf16)
+ *                       or 4 (fp32): the reference hands over a float mask (inferencer.py:354-358) and tests
+ *                       `.to(bool)`; -0.0 counts as zero, NaN as non-zero
  *   level_shapes_host   HOST array of 2*num_levels int64: (H_l, W_l) per level (num_levels <= 8)
  *   mask_flat_dev       [B, S] uint8, S = sum H_l*W_l: level masks (nearest-neighbour resize, ATen's index rule),
  *                       levels concatenated -- the transformer's mask_flatten
@@ -318,7 +342,7 @@ int codetr_linear_splitk_bf16(void *stream, const void *x_dev, const void *w_dev
  * ------------------------------------------------------------------------------------------ */
 int codetr_mask_pyramid(void *stream, const void *img_mask_dev, int64_t B, int64_t H_img, int64_t W_img,
                         int num_levels, const int64_t *level_shapes_host, void *mask_flat_dev, float *ycum_dev,
-                        float *xcum_dev, float *valid_counts_dev);
+                        float *xcum_dev, float *valid_counts_dev, int mask_elem_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Decoder query positions: sigmoid + valid-ratio scaling of the reference boxes and their sine embedding.

@@ -96,3 +96,16 @@ def test_cpu_tensors_are_rejected_not_emulated():
     w = torch.zeros(1, 1, 1, 1, 1)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.codetr.multi_scale_deformable_attention(v, ss, ls, loc, w, 64)
+
+
+def test_runner_dispatch_table_is_in_sync_with_the_signature_table():
+    """runner/dispatch_gen.inc (typed trampolines of the C++ plan runner) is generated from codetr/_cabi.py SIGNATURES"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_runner_dispatch.py")], stdout=subprocess.PIPE,
+                         text=True, check=True).stdout
+    assert gen == open(os.path.join(root, "runner", "dispatch_gen.inc")).read(), \
+        "regenerate: python tools/gen_runner_dispatch.py > runner/dispatch_gen.inc"
+    assert os.access(os.path.join(root, "runner", "codetr_runner"), os.X_OK)   # built by __graft_entry__.build()
