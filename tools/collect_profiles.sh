@@ -1,20 +1,36 @@
 #!/bin/bash
-# Round-end evidence run (on the GPU box, through gpurun): bench line, kernel traces at 8 images / 1 image per step,
-# FETCH_SIZE / WRITE_SIZE passes.  Writes only small folded files under gpurun_out/final/.
-#   tools/collect_profiles.sh <tag>      e.g. r01_p
-tag=${1:-r01_p}
+# Round evidence run (on the GPU box, through gpurun): bench lines, kernel traces at 8 images / 1 image per step, PMC
+# passes (each in its own run, never with a trace).  Writes only small folded files under gpurun_out/final/.
+#   tools/collect_profiles.sh <tag>      e.g. r02
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
-timeout 900 python bench.py > $out/bench.json 2> $out/bench.err
-b8="--streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline"
-rm -rf /tmp/tr8 /tmp/tr1 /tmp/pf /tmp/pw
+timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/bench.err
+timeout 600 python bench.py --dtype fp8 --no-cpu-baseline > $out/${tag}_bench_fp8.json 2>> $out/bench.err
+common="--no-cpu-baseline --no-graph --no-roofline --no-host-feed"
+b8="--streams 1 --steps 3 --warmup 1 $common"
+rm -rf /tmp/tr8 /tmp/tr1 /tmp/pf /tmp/pw /tmp/pm
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr8 -- python bench.py $b8 > /tmp/tr8.log 2>&1
 python tools/fold_trace.py "$(find /tmp/tr8 -name '*.db' | head -1)" $out/${tag}_batch8 8 "rocprofv3 --kernel-trace --stats -- python bench.py $b8"
-b1="--batch 1 --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-roofline"
+b1="--batch 1 --steps 6 --warmup 2 $common"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr1 -- python bench.py $b1 > /tmp/tr1.log 2>&1
 python tools/fold_trace.py "$(find /tmp/tr1 -name '*.db' | head -1)" $out/${tag}_batch1 1 "rocprofv3 --kernel-trace --stats -- python bench.py $b1"
-p1="--batch 4 --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-roofline"   # = one replayed graph of the default run
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python bench.py $p1 > /tmp/pf.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python bench.py $p1 > /tmp/pw.log 2>&1
-python tools/pmc_traffic.py "$(find /tmp/pf -name '*counter_collection.csv' | head -1)" "$(find /tmp/pw -name '*counter_collection.csv' | head -1)" 0 > $out/pmc_traffic.json
-ls -la $out; tail -1 $out/bench.json | cut -c1-600
+# HBM traffic of one replayed graph's launches (4 images): what bench.py's roofline*.traffic cite
+p4="--batch 4 --streams 1 --steps 2 --warmup 1 $common"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python bench.py $p4 > /tmp/pf.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python bench.py $p4 > /tmp/pw.log 2>&1
+python tools/pmc_fold.py --fetch "$(find /tmp/pf -name '*counter_collection.csv' | head -1)" --write "$(find /tmp/pw -name '*counter_collection.csv' | head -1)" \
+   --label "bench.py $p4 (4 images = one replayed graph of the default run)" > $out/${tag}_pmc_traffic.json
+# BASELINE config 3 (1152x768): HBM GB/s + MFMA busy per kernel group
+c3="--res 1152x768 --batch 1 --steps 4 --warmup 1 $common"
+rm -rf /tmp/pf /tmp/pw /tmp/pm /tmp/tr3
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr3 -- python bench.py $c3 > /tmp/tr3.log 2>&1
+python tools/fold_trace.py "$(find /tmp/tr3 -name '*.db' | head -1)" $out/${tag}_1152x768_batch1 1 "rocprofv3 --kernel-trace --stats -- python bench.py $c3"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python bench.py $c3 > /tmp/pf.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python bench.py $c3 > /tmp/pw.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pm -- python bench.py $c3 > /tmp/pm.log 2>&1
+python tools/pmc_fold.py --fetch "$(find /tmp/pf -name '*counter_collection.csv' | head -1)" --write "$(find /tmp/pw -name '*counter_collection.csv' | head -1)" \
+   --mfma "$(find /tmp/pm -name '*counter_collection.csv' | head -1)" --stats $out/${tag}_1152x768_batch1_kernel_stats.csv \
+   --label "bench.py $c3 (BASELINE config 3)" > $out/${tag}_pmc_1152x768.json
+timeout 600 python tools/export_and_run_plan.py --res 1920x1280 --batch 1 > $out/${tag}_runner_1920x1280.json 2> $out/runner.err
+ls -la $out; tail -1 $out/${tag}_bench.json | cut -c1-300; cat $out/${tag}_runner_1920x1280.json | cut -c1-600

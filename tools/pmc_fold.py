@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Fold separate rocprofv3 --pmc passes (never combined with a trace) over `bench.py --no-graph` into per-kernel-group
+numbers:  HBM-side bytes (FETCH_SIZE / WRITE_SIZE, KiB; reads corrected x2 as MI355X_MICROARCH.md prescribes for gfx950),
+MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE / 8 shader cycles on 1024 SIMDs) and, from the kernel-trace
+stats CSV of the same command, time -> HBM GB/s.
+
+    python tools/pmc_fold.py --fetch F.csv --write W.csv [--mfma M.csv] [--stats kernel_stats.csv] [--label "..."] > out.json"""
+import argparse
+import collections
+import csv
+import json
+import re
+
+GROUPS = [("linear_256_fp8", "linear_fp8"), ("linear_", "linear (f16: 128-tile / 256-tile / XS / split-K)"),
+          ("splitk_reduce", "linear (f16: 128-tile / 256-tile / XS / split-K)"), ("ffn_fused", "ffn_fused"),
+          ("msda_encoder", "msda_encoder"), ("msda_tiled", "msda (general fused, decoder)"), ("window_attention", "window_attention"),
+          ("layernorm", "layernorm"), ("mha_attention", "mha_attention"), ("gn_", "groupnorm_tokens")]
+
+
+def group_of(name):
+    for key, label in GROUPS:
+        if key in name:
+            return label
+    return "other"
+
+
+def fold(path, counters):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(int)
+    mx = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(path)):
+        c = r["Counter_Name"]
+        if c not in counters:
+            continue
+        g = group_of(r["Kernel_Name"])
+        v = float(r["Counter_Value"])
+        acc[g][c] += v
+        mx[g][c] = max(mx[g][c], v)
+        if c == counters[0]:
+            n[g] += 1
+    return acc, n, mx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write", required=True)
+    ap.add_argument("--mfma")
+    ap.add_argument("--stats")
+    ap.add_argument("--label", default="")
+    a = ap.parse_args()
+    fa, fn, fmx = fold(a.fetch, ["FETCH_SIZE"])
+    wa, _, wmx = fold(a.write, ["WRITE_SIZE"])
+    # forwards in the profiled run: encoder_geometry_kernel runs once per forward
+    fwd = sum(1 for r in csv.DictReader(open(a.fetch)) if r["Counter_Name"] == "FETCH_SIZE" and "encoder_geometry" in r["Kernel_Name"]) or 1
+    out = {"workload": a.label, "forwards_profiled": fwd, "unit": "bytes / cycles per forward",
+           "note": "FETCH_SIZE / WRITE_SIZE in KiB x 1024; read = 2 x FETCH_SIZE (gfx950 tallies a 128-B request as 64 B); "
+                   "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)", "kernels": {}}
+    ma = mn = None
+    if a.mfma:
+        ma, mn, _ = fold(a.mfma, ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"])
+    times = collections.defaultdict(float)
+    if a.stats:
+        for r in csv.DictReader(open(a.stats)):
+            times[group_of(r["Name"])] += float(r["TotalDurationNs"])
+        total_calls = sum(float(r["Calls"]) for r in csv.DictReader(open(a.stats)) if "encoder_geometry" in r["Name"]) or fwd
+    for g in sorted(fa, key=lambda k: -fa[k]["FETCH_SIZE"]):
+        rd, wr = 2 * fa[g]["FETCH_SIZE"] * 1024.0, wa[g]["WRITE_SIZE"] * 1024.0
+        e = {"launches_per_forward": fn[g] / fwd, "hbm_read_bytes(corrected x2)": rd / fwd, "hbm_write_bytes": wr / fwd,
+             "hbm_bytes_per_forward": (rd + wr) / fwd, "hbm_bytes_per_launch": (rd + wr) / max(fn[g], 1),
+             "hbm_bytes_largest_launch": 1024.0 * (2 * fmx[g]["FETCH_SIZE"] + wmx[g]["WRITE_SIZE"])}
+        if a.stats and times.get(g):
+            t = times[g] * 1e-9 / total_calls
+            e["time_ms_per_forward"] = round(t * 1e3, 4)
+            e["hbm_GBps"] = round((rd + wr) / fwd / t / 1e9, 1)
+        if ma is not None and g in ma and ma[g]["GRBM_GUI_ACTIVE"] > 0:
+            shader = ma[g]["GRBM_GUI_ACTIVE"] / 8.0
+            e["mfma_busy_cycles"] = ma[g]["SQ_VALU_MFMA_BUSY_CYCLES"] / fwd
+            e["mfma_busy_frac_of_1024_simds"] = round(ma[g]["SQ_VALU_MFMA_BUSY_CYCLES"] / (shader * 1024.0), 4)
+        out["kernels"][g] = e
+    # names bench.py looks up
+    alias = {"linear (f16: 128-tile / 256-tile / XS / split-K)": "linear_kernel", "msda (general fused, decoder)": "msda"}
+    for k, v in list(out["kernels"].items()):
+        if k in alias:
+            out["kernels"][alias[k]] = v
+    json.dump(out, open("/dev/stdout", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
