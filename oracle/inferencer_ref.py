@@ -63,8 +63,10 @@ def resize_bilinear_u8(img, new_h, new_w):
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
-def preprocess(img, scale, pad_size, mean, std, pad_val=(0, 0, 0), dtype=np.float32):
-    """img [H, W, 3] uint8 RGB -> (inputs [3, Hp, Wp] dtype, mask [Hp, Wp] dtype (1 = padding), meta dict)"""
+def preprocess(img, scale, pad_size, mean, std, pad_val=(0, 0, 0), dtype=np.float32, pad_size_divisor=1, pad_value=0.0):
+    """img [H, W, 3] uint8 RGB -> (inputs [3, Hp, Wp] dtype, mask [Hp, Wp] dtype (1 = padding), meta dict).
+    Two paddings, as mmdet applies them: the pipeline's Pad(size, pad_val) on uint8 pixels BEFORE normalisation, and
+    DetDataPreprocessor's padding to a multiple of pad_size_divisor AFTER it, filled with pad_value."""
     H, W, _ = img.shape
     nh, nw, _ = rescale_size(H, W, scale)
     r = resize_bilinear_u8(img, nh, nw)
@@ -76,6 +78,14 @@ def preprocess(img, scale, pad_size, mean, std, pad_val=(0, 0, 0), dtype=np.floa
     x = (canvas.astype(np.float32) - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
     mask = np.ones((Hp, Wp), np.float32)
     mask[:nh, :nw] = 0
+    d = int(pad_size_divisor)
+    if d > 1 and (Hp % d or Wp % d):
+        Hd, Wd = -(-Hp // d) * d, -(-Wp // d) * d
+        xd = np.full((Hd, Wd, 3), np.float32(pad_value), np.float32)
+        xd[:Hp, :Wp] = x
+        md = np.ones((Hd, Wd), np.float32)
+        md[:Hp, :Wp] = mask
+        x, mask, Hp, Wp = xd, md, Hd, Wd
     meta = dict(ori_shape=(H, W), img_shape=(nh, nw), img_unpadded_shape=(nh, nw), pad_shape=(Hp, Wp),
                 scale_factor=(nw / W, nh / H))
     return x.transpose(2, 0, 1).astype(dtype), mask.astype(dtype), meta

@@ -90,3 +90,29 @@ def test_inferencer_pre_and_post_around_a_stub_model():
     assert len(pred["labels"]) == 2  # the near-duplicate of class 3 (IoU .96) and the 0.01 box are gone
     with pytest.raises(NotImplementedError):
         inf([img], return_vis=True)
+
+
+def test_inferencer_pad_size_divisor_pads_in_normalised_space():
+    """DetDataPreprocessor(pad_size_divisor=32, pad_value=0): the divisor padding is added AFTER normalisation and holds
+    pad_value, while the pipeline's Pad holds normalised pad_val pixels; masks mark both as padding."""
+    from codetr.inferencer import Inferencer
+
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (333, 517, 3), dtype=np.uint8)
+    seen = {}
+
+    def model(batch_inputs, img_masks):
+        seen["x"], seen["m"] = batch_inputs, img_masks
+        z = torch.zeros(1, 0, 4, device=DEV)
+        return z, torch.zeros(1, 0, device=DEV), torch.zeros(1, 0, dtype=torch.long, device=DEV)
+
+    inf = Inferencer(model, CFG, dataset_meta=None)
+    inf.pad_size_divisor, inf.pad_value = 32, 0.0
+    inf.scale, inf.pad_size, inf.pad_val = (500, 300), (500, 300), (114, 114, 114)
+    inf([img], device=DEV, dtype=torch.float32)
+    x0, m0, meta = R.preprocess(img, (500, 300), (500, 300), MEAN, STD, (114, 114, 114), pad_size_divisor=32, pad_value=0.0)
+    assert meta["pad_shape"] == (320, 512) and seen["x"].shape == (1, 3, 320, 512)
+    assert torch.equal(seen["x"][0].cpu(), torch.from_numpy(x0)) and torch.equal(seen["m"][0].cpu(), torch.from_numpy(m0))
+    # the two paddings differ: Pad's region holds (114 - mean) / std, the divisor region holds 0
+    assert float(seen["x"][0, 0, 299, 499].abs()) > 0.05 and float(seen["x"][0, :, 310, :].abs().max()) == 0.0
+    assert float(seen["m"][0, 310, 0]) == 1.0 and float(seen["m"][0, 0, 505]) == 1.0

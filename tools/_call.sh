@@ -1,6 +1,10 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02i; mkdir -p $out
-timeout 900 python -m pytest tests/test_small_ops_gpu.py tests/test_runner_gpu.py -m gpu -q -p no:cacheprovider -x > $out/pytest_new.log 2>&1; echo "rc $?" >> $out/pytest_new.log
-grep -E "^(FAILED|ERROR)|passed|failed|^E  |rc " $out/pytest_new.log | cut -c1-900 | head -30
-timeout 900 python -m pytest tests/test_full_size_gpu.py tests/test_mask_pyramid_gpu.py tests/test_cabi_from_c.py -m gpu -q -p no:cacheprovider > $out/pytest_model.log 2>&1; echo "rc $?" >> $out/pytest_model.log
-grep -E "^(FAILED|ERROR)|passed|failed|^E  |rc " $out/pytest_model.log | cut -c1-600 | head -30
+out=gpurun_out/r02j; mkdir -p $out
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
+grep -E "^(FAILED|ERROR)|passed|failed|rc " $out/pytest.log | cut -c1-300 | head -20
+timeout 600 python bench.py --offset-noise-px 0 --no-cpu-baseline > $out/bench_0px.json 2> $out/bench_0px.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r02j/bench_0px.json").read().strip().splitlines()[-1])
+print("0px", d["value"], "img/s", d["p50_ms_per_image"], "ms/img; lat1", d.get("latency_batch1",{}).get("p50_ms"))
+PY
