@@ -471,14 +471,20 @@ def main():
         return dry_run(a, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    if local_rank >= torch.cuda.device_count():
+    # CODETR_BENCH_SHARE_GPU=1 (control-flow test on a 1-GPU box): ranks share the visible GPUs round-robin and gather
+    # over gloo -- RCCL refuses two ranks on one device.  Never a measurement configuration.
+    share = os.environ.get("CODETR_BENCH_SHARE_GPU", "0") == "1"
+    if local_rank >= torch.cuda.device_count() and not share:
         sys.exit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
-    binding = bind_rank(local_rank, local_world)
+    binding = bind_rank(device.index, local_world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32, "fp8": torch.float16}[a.dtype]
     W, H = (int(x) for x in a.res.split("x"))
@@ -559,6 +565,7 @@ def main():
             gather_detections(static_out, world * a.batch, out=gathered)  # the only collective: 7.2 KB per image
 
     def fence():
+        torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
@@ -578,7 +585,7 @@ def main():
         elapsed = time.perf_counter() - t0
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
         if world > 1:
-            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, per_step
@@ -618,6 +625,7 @@ def main():
                             % (a.res, a.batch),
                 "global_batch": a.batch * world, "parallelism": "image-sharded replicas x%d" % world,
                 "hipgraph": graph is not None, "streams": nstreams, "feed": a.feed, "rank0_binding": binding,
+                "shared_gpu_test_mode": share,
                 "msda_offset_noise_px": a.offset_noise_px,
                 "native_kernels": sorted(__import__("codetr.hip_ops", fromlist=["NATIVE"]).NATIVE),
             },

@@ -42,7 +42,13 @@ def gather_detections(local, n_items=None, out=None):
         local = torch.cat((local, local.new_zeros(b_max - b_local, k, c)), 0)
     if out is None or out.shape[0] != b_max * world:
         out = local.new_empty(b_max * world, k, c)
-    dist.all_gather_into_tensor(out, local.contiguous())
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # test configuration only (several ranks sharing one GPU, CPU collective): gloo gathers host tensors
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.contiguous().cpu())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, local.contiguous())
     if b_max * world == n_items:
         return out
     keep = []
