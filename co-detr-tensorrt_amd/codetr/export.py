@@ -25,6 +25,9 @@ import torch
 from . import _cabi
 
 MAGIC = b"CODETRPLAN\x00\x02"
+# substrings of kernel / activity names that are not this library's (ATen, rocBLAS / hipBLASLt, MIOpen, rocPRIM, copies)
+FOREIGN_KERNEL_MARKS = ("at::native", "elementwise", "Cijk", "rocprim", "miopen", "MIOpen", "CatArray", "hipblas", "rocblas",
+                        "Memcpy", "Memset")
 KIND_INT, KIND_FLOAT, KIND_DEV, KIND_NULL, KIND_HOST, KIND_STREAM = 0, 1, 2, 3, 4, 5
 
 
@@ -77,11 +80,20 @@ def export_plan(model, batch_inputs, img_masks, path, warmup=2):
         initial = [(a, n, _read_device(hip, a, n)) for a, n in live_before]
         _cabi.RECORDER = []
         try:
-            boxes, scores, labels = model(batch_inputs, img_masks)
-            torch.cuda.synchronize(dev)
+            # the plan can only hold libcodetr_hip.so launches: profile the recorded forward and refuse to export if
+            # anything else ran on the device (an ATen kernel or a device copy -- e.g. PatchMerging's F.pad on an
+            # odd-sized Swin map, or a dtype the small kernels do not take)
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                boxes, scores, labels = model(batch_inputs, img_masks)
+                torch.cuda.synchronize(dev)
             calls = _cabi.RECORDER
         finally:
             _cabi.RECORDER = None
+        foreign = sorted({e.name[:100] for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA
+                          and any(t in e.name for t in FOREIGN_KERNEL_MARKS)})
+        if foreign:
+            raise RuntimeError("this model / input shape is not exportable: the forward ran device work outside "
+                               f"libcodetr_hip.so that a plan cannot replay: {foreign}")
         segs = _segments(dev)
 
     def locate(addr, what):

@@ -91,3 +91,14 @@ def test_runner_fails_loudly(tmp_path):
     assert p.returncode != 0 and "not a plan" in p.stderr
     p = _run(["--plan", str(tmp_path / "bad.plan"), "--lib", str(tmp_path / "nolib.so")])
     assert p.returncode != 0 and "cannot load" in p.stderr
+
+
+def test_export_refuses_a_forward_with_foreign_kernels(tmp_path):
+    """an odd-sized Swin map takes PatchMerging's F.pad (ATen): a plan could not replay it, so the export must refuse"""
+    from codetr.export import export_plan
+
+    model = _model()
+    img = torch.randn(1, 3, 152, 200, device=DEV).half()       # 38 x 50 -> 19 x 25 (odd) -> pad
+    mask = torch.zeros(1, 152, 200, device=DEV, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="not exportable"):
+        export_plan(model, img, mask, str(tmp_path / "odd.plan"))
