@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -96,6 +96,8 @@ SIGNATURES = {
     "codetr_ffn_relu_ln2_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float,
                                        _vp, _vp, ctypes.c_float, _vp, _vp]),
     "codetr_ffn_pack_w2_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
+    "codetr_ffn_fp8": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
+                              _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
     "codetr_window_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
 }
@@ -110,7 +112,7 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
          "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0,
-         "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0}
+         "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0, "ffn_fp8": 0}
 
 
 # Launch recording (codetr/export.py): while RECORDER is a list, every launch-type entry point called through `load()`
@@ -685,6 +687,25 @@ def linear_fp8(x8, w8, w_scale, x_scale, bias, residual2d, act, out2d, out_scale
                                residual2d.data_ptr() if residual2d is not None else None, out2d.data_ptr(),
                                1 if out8 else 0, float(out_scale), M, N, K, _ACT[act])
     check(rc, "codetr_linear_fp8")
+    return out2d
+
+
+def ffn_fp8(x2d, w1q, w1_scale, b1, w2q_packed, w2_scale, b2, out2d, x_scale, h_scale, ln=None, pos2d=None,
+            out_plus_pos2d=None, ln_in=None):
+    """codetr_ffn_fp8 (include/codetr_hip.h): x2d / out2d fp16 [M, 256]; w1q [hidden, 256] / w2q_packed [256, hidden]
+    e4m3, the latter in the kernel's column order (hip_ops.ffn_fp8_weights)."""
+    CALLS["ffn_fp8"] += 1
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    gi, bi, epsi = ln_in if ln_in is not None else (None, None, 0.0)
+    rc = load().codetr_ffn_fp8(
+        current_stream_ptr(x2d.device), x2d.data_ptr(), w1q.data_ptr(), w1_scale.data_ptr(), b1.data_ptr(),
+        w2q_packed.data_ptr(), w2_scale.data_ptr(), b2.data_ptr(), out2d.data_ptr(), x2d.shape[0], x2d.shape[1],
+        w1q.shape[0], float(x_scale), float(h_scale),
+        gi.data_ptr() if gi is not None else None, bi.data_ptr() if bi is not None else None, float(epsi),
+        g.data_ptr() if g is not None else None, b.data_ptr() if b is not None else None, float(eps),
+        pos2d.data_ptr() if pos2d is not None else None,
+        out_plus_pos2d.data_ptr() if out_plus_pos2d is not None else None)
+    check(rc, "codetr_ffn_fp8")
     return out2d
 
 

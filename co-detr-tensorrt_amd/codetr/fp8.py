@@ -10,13 +10,17 @@ Scheme (standard post-training static quantisation):
   * arithmetic: e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the fp16 MFMA rate), fp32 accumulation, scales
     applied once in the epilogue; residual stream, attention, norms' statistics and everything else stay fp16 / fp32.
 
-What runs in fp8 (this round): the four Linears of every Swin block whose K is a multiple of 128 and whose GEMMs fill
-the chip (stages 1-3 at the bench's batch: 88 of the backbone's 96 block GEMMs, ~85 % of the Swin flops).  Stage 0
-(C = 192), patch merging, the neck and the detection transformer stay on the fp16 kernels; ``report()`` says so."""
+What runs in fp8: the four Linears of every Swin block whose K is a multiple of 128 and whose GEMMs fill the chip
+(stages 1-3 at the bench's batch: 88 of the backbone's 96 block GEMMs, ~85 % of the Swin flops), and BOTH products of
+the deformable encoder's fused FFN (``codetr_ffn_fp8``: the LayerNorm'ed input is quantised in registers, the hidden
+activation is quantised as it leaves the first product's accumulators and never exists in fp16).  Stage 0 (C = 192),
+patch merging, the neck, the attention projections, the decoder and the heads stay on the fp16 kernels; ``report()``
+says so."""
 import torch
 
 from . import hip_ops
 from .swin import SwinBlock
+from .transformer_layers import FFN
 
 MARGIN = 1.0   # scale = absmax * MARGIN / 448 (calibration and evaluation inputs are drawn alike in bench / tests)
 
@@ -25,20 +29,29 @@ def _blocks(model):
     return [m for m in model.modules() if isinstance(m, SwinBlock)]
 
 
+def _ffns(model):
+    return [m for m in model.modules() if isinstance(m, FFN)]
+
+
 @torch.no_grad()
 def calibrate(model, batch_inputs, img_masks):
     """One fp16 forward with every Swin block recording the absolute maxima of its four GEMM inputs; sets the static
     activation scales and pre-quantises the weights.  Returns the number of blocks prepared."""
-    blocks = _blocks(model)
-    for b in blocks:
+    blocks, ffns = _blocks(model), _ffns(model)
+    for b in blocks + ffns:
         b.fp8_mode = "calibrate"
         b.__dict__.pop("_fp8_amax", None)
     try:
         model(batch_inputs, img_masks)
     finally:
-        for b in blocks:
+        for b in blocks + ffns:
             b.fp8_mode = None
     n = 0
+    for f in ffns:      # only the FFNs the fused kernel served observed anything (the encoder's, at the bench's sizes)
+        amax = f.__dict__.get("_fp8_amax")
+        if amax:
+            f._fp8_scales = {k: max(float(v) * MARGIN / hip_ops.FP8_MAX, 1e-8) for k, v in amax.items()}
+            hip_ops.ffn_fp8_weights(f.layers[0][0].weight, f.layers[1].weight)
     for b in blocks:
         amax = b.__dict__.get("_fp8_amax")
         if not amax:
@@ -54,7 +67,7 @@ def calibrate(model, batch_inputs, img_masks):
 def enable(model, on=True):
     """switch the calibrated blocks to the fp8 path (blocks without scales, or whose shapes the fp8 GEMM does not
     take at run time, keep running fp16)"""
-    for b in _blocks(model):
+    for b in _blocks(model) + _ffns(model):
         b.fp8_mode = "run" if (on and hasattr(b, "_fp8_scales")) else None
 
 
@@ -62,7 +75,10 @@ def report(model):
     blocks = _blocks(model)
     ready = [b for b in blocks if getattr(b, "fp8_mode", None) == "run"]
     k_ok = [b for b in ready if all(w.shape[1] % 128 == 0 for w in b._fp8_weights())]
+    ffns = _ffns(model)
     return {"swin_blocks": len(blocks), "swin_blocks_fp8": len(k_ok),
+            "ffns": len(ffns), "ffns_fp8": sum(1 for f in ffns if f.fp8_mode == "run"),
             "fp8_layers": f"qkv / proj / fc1 / fc2 of Swin blocks with K a multiple of 128 (stages 1-3) when the GEMM has "
-                          f">= {hip_ops.FP8_MIN_TILES} 256x256 tiles",
-            "fp16_layers": "Swin stage 0, patch merging, neck, encoder / decoder / heads, window attention, MSDA"}
+                          f">= {hip_ops.FP8_MIN_TILES} 256x256 tiles; both products of the encoder's fused FFN "
+                          f"(rows >= {hip_ops.FFN_FUSED_MIN_ROWS})",
+            "fp16_layers": "Swin stage 0, patch merging, neck, attention projections, decoder, heads, window attention, MSDA"}

@@ -657,6 +657,56 @@ def fp8_weight(weight):
     return derived((weight,), "_codetr_fp8_w", build)
 
 
+def ffn_fp8_supported(x, w1, w2, act):
+    """the fp8 fused FFN serves the same layers as ffn_fused with hidden a multiple of 128 (<= 2048), fp16 storage"""
+    return (ffn_fused_supported(x, w1, w2, act) and x.dtype == torch.float16 and w1.shape[0] % 128 == 0
+            and w1.shape[0] <= 2048)
+
+
+def ffn_fp8_weights(w1, w2):
+    """(w1q [hidden,256] e4m3, s1 [hidden], w2q_packed [256,hidden] e4m3, s2 [256]) of an FFN's two Linear weights:
+    per-row absmax / 448 scales; W2's columns permuted inside every 128-block into the order in which the first
+    product's accumulators become the second product's operand (packed column 32 g + 4 t + r <- unit 16 t + 4 g + r).
+    Cached on w1."""
+    def build():
+        a, b = w1.detach().float(), w2.detach().float()
+        s1 = (a.abs().amax(1) / FP8_MAX).clamp_min(1e-12)
+        s2 = (b.abs().amax(1) / FP8_MAX).clamp_min(1e-12)
+        p = torch.arange(128, device=w2.device)
+        g, t, r = p // 32, (p % 32) // 4, p % 4
+        src = 16 * t + 4 * g + r
+        bq = (b / s2[:, None]).to(FP8).view(torch.uint8).view(b.shape[0], -1, 128)[:, :, src].reshape(b.shape).contiguous()
+        return (a / s1[:, None]).to(FP8).contiguous(), s1.contiguous(), bq.view(FP8), s2.contiguous()
+
+    return derived((w1, w2), "_codetr_ffn_fp8_w", build)
+
+
+def ffn_fp8(x, w1, b1, w2, b2, x_scale, h_scale, ln=None, pos=None, ln_in=None):
+    """ffn_fused on the e4m3 matrix path: both products in fp8 with static activation scales (x_scale for the -- possibly
+    LayerNorm'ed -- input, h_scale for the hidden activation), fp16 in and out; same epilogue options."""
+    _gpu(x, "ffn_fp8")
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    out = torch.empty_like(x2)
+    p2 = out2 = None
+    if pos is not None:
+        p2 = pos.reshape(-1, pos.shape[-1])
+        if p2.shape != x2.shape or p2.dtype != x2.dtype:
+            raise ValueError("pos must match x in shape and dtype")
+        if not p2.is_contiguous():
+            p2 = p2.contiguous()
+        out2 = torch.empty_like(x2)
+    w1q, s1, w2q, s2 = ffn_fp8_weights(w1, w2)
+    if x2.shape[0] > 0:
+        with torch.cuda.device(x.device):
+            _timed("ffn_fp8", {"M": x2.shape[0], "C": x2.shape[1], "hidden": w1.shape[0]},
+                   lambda: _cabi.ffn_fp8(x2, w1q, s1, b1, w2q, s2, b2, out, x_scale, h_scale, ln, p2, out2, ln_in), x.device)
+    if pos is not None:
+        return out.view(x.shape), out2.view(x.shape)
+    return out.view(x.shape)
+
+
 def linear_fp8_supported(rows, weight):
     """True when the fp8 GEMM serves this layer: K a multiple of 128 bytes, N of 8, and enough 256x256 output tiles to
     fill the chip (smaller problems stay on the fp16 kernels)"""

@@ -65,11 +65,35 @@ class FFN(nn.Module):
         return (self.add_identity and identity is None and fc1.bias is not None and fc2.bias is not None
                 and hip_ops.ffn_fused_supported(x, fc1.weight, fc2.weight, self.act))
 
+    # fp8 inference mode (codetr/fp8.py): None | "calibrate" (fp16 forward that records the absolute maxima of the FFN
+    # input and of the hidden activation) | "run" (both products on the e4m3 MFMA path, static scales _fp8_scales)
+    fp8_mode = None
+
+    def _fp8_observe(self, x, ln_in):
+        fc1 = self.layers[0][0]
+        x1 = x if ln_in is None else hip_ops.layer_norm(x, *ln_in)
+        h = hip_ops.linear(x1, fc1.weight, fc1.bias, act=self.act)
+        amax = self.__dict__.setdefault("_fp8_amax", {})
+        for k, t in (("x", x1), ("h", h)):
+            a = t.detach().abs().amax().float()
+            amax[k] = a if k not in amax else torch.maximum(amax[k], a)
+
+    def _fp8_ready(self, x):
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        return (self.fp8_mode == "run" and hasattr(self, "_fp8_scales") and not torch.is_grad_enabled()
+                and hip_ops.ffn_fp8_supported(x, fc1.weight, fc2.weight, self.act))
+
     def forward_norm(self, x, norm, pos=None, norm_in=None):
         """LayerNorm(x + ffn(x)) -- and, with `pos`, also that + pos -- in the fused kernel's epilogue
         (call only when fused_supported(x)).  norm_in: a LayerNorm applied to x first, inside the kernel."""
         fc1, fc2 = self.layers[0][0], self.layers[1]
         ln_in = None if norm_in is None else (norm_in.weight, norm_in.bias, norm_in.eps)
+        if self.fp8_mode == "calibrate":
+            self._fp8_observe(x, ln_in)
+        elif self._fp8_ready(x):
+            sc = self._fp8_scales
+            return hip_ops.ffn_fp8(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, sc["x"], sc["h"],
+                                   ln=(norm.weight, norm.bias, norm.eps), pos=pos, ln_in=ln_in)
         return hip_ops.ffn_fused(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln=(norm.weight, norm.bias, norm.eps),
                                  pos=pos, ln_in=ln_in)
 
@@ -77,6 +101,11 @@ class FFN(nn.Module):
         fc1, fc2 = self.layers[0][0], self.layers[1]
         if self.fused_supported(x, identity):
             # encoder / decoder FFN (256 -> 2048 -> 256, ReLU): one kernel, the hidden activation never reaches HBM
+            if self.fp8_mode == "calibrate":
+                self._fp8_observe(x, None)
+            elif self._fp8_ready(x):
+                sc = self._fp8_scales
+                return hip_ops.ffn_fp8(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, sc["x"], sc["h"])
             return hip_ops.ffn_fused(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
         h = hip_ops.linear(x, fc1.weight, fc1.bias, act=self.act)
         if not self.add_identity:

@@ -87,7 +87,15 @@ __device__ __forceinline__ Tok<WS> map_token(int i, int wy, int wx, const Geomet
   return t;
 }
 
-__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+// XOR swizzle of the 16-byte chunk of a 64-byte (head_dim 32) LDS row.  With j = (row >> 2) & 3 the key f(j) = j ^ ((j & 1) << 1)
+// = {0, 3, 2, 1} keeps both read shapes conflict-free under the hardware's lane groups (tests/test_lds_bank_model.py):
+// the K fragments (ds_read_b128: a group of 16 lanes holds rows {0-3, 12-15} at chunk g and rows {4-11} at chunk g ^ 1)
+// and the transposing V reads (ds_read_b64_tr_b16: 32 lanes = 8 rows x two chunks; rows r and r + 4 alias mod 256 B and
+// need keys that differ in bit 1).  The plain key f(j) = j is 2-way conflicted on both.
+__device__ __forceinline__ int swz(int row, int chunk) {
+  const int j = (row >> 2) & 3;
+  return chunk ^ j ^ ((j & 1) << 1);
+}
 
 template <class ET, int WS>
 __global__ __launch_bounds__(kThreads) void window_attention_kernel(

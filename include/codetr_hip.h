@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 35
+#define CODETR_HIP_ABI_VERSION 36
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -590,6 +590,25 @@ int codetr_ffn_relu_ln2_f16(void *stream, const void *x_dev, const void *w1_dev,
                             int64_t hidden, const void *ln_in_gamma_dev, const void *ln_in_beta_dev, float ln_in_eps,
                             const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps, const void *pos_dev,
                             void *y_plus_pos_dev);
+/* The fused FFN on the e4m3 matrix path (BASELINE config 5; no reference counterpart for 8-bit arithmetic -- the layer
+ * is the same FFN, codetr/transformer_mmcv.py:484-500, inside the same post-norm encoder layer :709-749):
+ *   x1 = LayerNorm_in(x) (or x);  xq = sat(x1 / x_scale) -> e4m3
+ *   h  = relu((xq . w1q^T) * w1_scale[j] * x_scale + b1[j]);  hq = sat(h / h_scale) -> e4m3
+ *   y  = LayerNorm(x1 + (hq . w2q^T) * w2_scale[n] * h_scale + b2[n]) * gamma + beta;  y_plus_pos = y + pos
+ * x / y / pos / biases / LayerNorm parameters f16 as in codetr_ffn_relu_ln2_f16; w1q_dev [hidden, 256] e4m3 bytes with
+ * per-hidden-unit scales w1_scale_dev [hidden] fp32; w2q_packed_dev [256, hidden] e4m3 bytes with per-output-channel
+ * scales w2_scale_dev [256] fp32, its columns permuted inside every 128-block: packed column 32 g + 4 t + r holds
+ * hidden unit 16 t + 4 g + r of the block (g < 4, t < 8, r < 4 -- the order in which the first product's accumulators
+ * become the second product's operand).  x_scale / h_scale: static per-tensor activation scales from calibration.
+ * fp32 accumulation with v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales); conversions saturate at +-448.
+ * C_in must be 256, hidden a multiple of 128 and <= 2048; CODETR_E_UNSUPPORTED otherwise. */
+int codetr_ffn_fp8(void *stream, const void *x_f16_dev, const void *w1q_dev, const float *w1_scale_dev,
+                   const void *b1_f16_dev, const void *w2q_packed_dev, const float *w2_scale_dev,
+                   const void *b2_f16_dev, void *y_f16_dev, int64_t M, int64_t C_in, int64_t hidden, float x_scale,
+                   float h_scale, const void *ln_in_gamma_dev, const void *ln_in_beta_dev, float ln_in_eps,
+                   const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps, const void *pos_dev,
+                   void *y_plus_pos_dev);
+
 /* bf16 storage form of the same kernel (all tensors bf16; the packed W2 comes from codetr_ffn_pack_w2_f16, which only
  * moves 16-bit elements) */
 int codetr_ffn_relu_ln2_bf16(void *stream, const void *x_dev, const void *w1_dev, const void *b1_dev,

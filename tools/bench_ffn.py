@@ -34,3 +34,8 @@ for M in (204600, 73656, 30785):
     fl = 2 * 2.0 * M * 256 * 2048
     print(f"M={M}: FFN+LN+pos one kernel {tl * 1e6:.1f} us, as three kernels {t3 * 1e6:.1f} us")
     print(f"M={M}: fused FFN {tf * 1e6:.1f} us ({fl / tf / 1e12:.0f} TF/s)   two native GEMMs {t2 * 1e6:.1f} us ({fl / t2 / 1e12:.0f} TF/s)")
+    if "--fp8" in sys.argv:
+        lnp = (gam, bet, 1e-5)
+        t8 = timeit(lambda: hip_ops.ffn_fp8(x, w1, b1, w2, b2, 0.012, 0.02, ln=lnp, pos=pos, ln_in=lnp))
+        t16 = timeit(lambda: hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=lnp, pos=pos, ln_in=lnp))
+        print(f"M={M}: LN+FFN+LN+pos  fp8 {t8 * 1e6:.1f} us ({fl / t8 / 1e12:.0f} TF/s)   fp16 {t16 * 1e6:.1f} us ({fl / t16 / 1e12:.0f} TF/s)")
