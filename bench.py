@@ -280,6 +280,22 @@ def kernel_rooflines(model, images, masks, device):
             "traffic": pmc.get("ffn_fused", {}).get("hbm_bytes_per_launch"),
             "avg_launch_us": round(t / len(ffn) * 1e6, 1),
         }
+    ffn8 = kprof.get("ffn_fp8", [])
+    if ffn8:
+        fl = sum(4.0 * m["M"] * m["C"] * m["hidden"] for _, _, m in ffn8)
+        t = sum(a.elapsed_time(b) for a, b, _ in ffn8) * 1e-3
+        # algorithmic HBM bytes per launch: the rows in, out, + pos in and rows + pos out (2 B each); W is L2-resident
+        nbytes = sum(4.0 * m["M"] * m["C"] * 2 for _, _, m in ffn8)
+        out["roofline_ffn_fp8"] = {
+            "kernel": "ffn_fp8_kernel (%d encoder launches, M = %d: LayerNorm, both products in e4m3, LayerNorm, + pos)"
+                      % (len(ffn8), ffn8[0][2]["M"]),
+            "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2 * MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(fl / t / 1e12 / (2 * MFMA_PEAK_TFLOPS), 4), "traffic": None,
+            "avg_launch_us": round(t / len(ffn8) * 1e6, 1),
+            "hbm_floor_us": round(nbytes / len(ffn8) / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
+            "note": "at the e4m3 rate the kernel's row traffic (x, y, pos, y + pos) is within 2x of its MFMA time: "
+                    "the composite floor is max(flops / 5 PF, bytes / 8 TB/s) per launch",
+        }
     enc = [(a, b, m) for a, b, m in kprof.get("msda_fused", []) if m["Nq"] == m["S"]]
     if enc:
         from codetr import _cabi as _cabi_mod
@@ -615,7 +631,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32",
-                      "fp8": "fp8 e4m3 (Swin stage 1-3 linears: weights + activations; f16 elsewhere, f32 accumulation)"}[a.dtype],
+                      "fp8": "fp8 e4m3 (Swin stage 1-3 linears and both products of the encoder FFN: weights + activations; f16 elsewhere, f32 accumulation)"}[a.dtype],
             "data": "synthetic (randn images %s, zero padding masks; seeded random-init weights of the "
                     "real architecture with %g px of query-dependent MSDA offset spread -- no checkpoint/COCO available "
                     "offline)" % ("already in HBM" if a.feed == "hbm" else "fed from pinned host memory every step",

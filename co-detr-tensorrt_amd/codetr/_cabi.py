@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -100,6 +100,8 @@ SIGNATURES = {
                               _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
     "codetr_window_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
+    "codetr_window_attention_fp8out_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i64, _i64, _i32, _i32,
+                                                  _i32, _i32]),
 }
 
 _lib = None
@@ -438,9 +440,16 @@ def window_attention_supported(dtype, embed_dims, num_heads, window_size) -> boo
     return dtype in (torch.float16, torch.bfloat16) and embed_dims == num_heads * 32 and window_size in (4, 7, 8, 12)
 
 
-def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_size, shift):
+def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_size, shift, out_scale=None):
+    """out: 16-bit like qkv, or (with out_scale, f16 qkv) torch.float8_e4m3fn = sat(f16(o) / out_scale)"""
     CALLS["window_attention"] += 1
     lib = load()
+    if out_scale is not None:
+        rc = lib.codetr_window_attention_fp8out_f16(current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(),
+                                                    rel_bias.data_ptr(), out.data_ptr(), float(out_scale), B, H, W,
+                                                    num_heads, 32, window_size, shift)
+        check(rc, "codetr_window_attention_fp8out_f16")
+        return out
     fn = lib.codetr_window_attention_bf16 if qkv.dtype == torch.bfloat16 else lib.codetr_window_attention_f16
     rc = fn(current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(), rel_bias.data_ptr(), out.data_ptr(),
             B, H, W, num_heads, 32, window_size, shift)

@@ -6,7 +6,7 @@ Scheme (standard post-training static quantisation):
   * weights: per-output-channel scale = absmax / 448, quantised once (``hip_ops.fp8_weight``, cached on the parameter);
   * activations: one static scale per GEMM input tensor = (running absmax over a calibration forward) / 448 x margin;
     the producer of each GEMM input emits e4m3 directly -- LayerNorm (``layer_norm_fp8``), the GELU epilogue of fc1
-    (``out_scale``), a cast after window attention;
+    (``out_scale``), the window-attention kernel's output store (``swin_window_attention(..., out_scale=)``);
   * arithmetic: e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the fp16 MFMA rate), fp32 accumulation, scales
     applied once in the epilogue; residual stream, attention, norms' statistics and everything else stay fp16 / fp32.
 

@@ -32,7 +32,7 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "topk(f16/bf16 rows, k <= 1024: radix select + bitonic sort)",
           "im2col_tokens(16-bit token-major maps)",
           "small_ops(f16: add, sigmoid, gather_rows, decode_boxes, valid_ratios)",
-          "linear_fp8(e4m3 x e4m3, K%128==0) + layer_norm_fp8 + cast_fp8"}
+          "linear_fp8(e4m3 x e4m3, K%128==0) + layer_norm_fp8 + cast_fp8", "ffn_fp8(fused FFN, both products e4m3)"}
 
 
 # bench.py sets this to a list to time every native linear launch with HIP events on its launch stream
@@ -469,11 +469,12 @@ def swin_window_attention_supported(x, embed_dims, num_heads, window_size):
     return x.is_cuda and _cabi.window_attention_supported(x.dtype, embed_dims, num_heads, window_size)
 
 
-def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_size, shift):
+def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_size, shift, out_scale=None):
     """Fused (shifted-)window attention on the UNPADDED spatial token map.
     qkv [B, H*W, 3C] (output of the qkv Linear on real tokens only), qkv_bias [3C] or None,
     rel_bias [nH, N, N] -> [B, H*W, C].  Pad / roll / partition / softmax / reverse are all inside
-    the kernel (reference codetr/swin.py:191-252, 92-112)."""
+    the kernel (reference codetr/swin.py:191-252, 92-112).
+    out_scale (fp16 qkv only): the result is e4m3 = sat(f16(o) / out_scale), the operand of the fp8 proj GEMM."""
     _gpu(qkv, "swin_window_attention")
     B, L, C3 = qkv.shape
     H, W = hw_shape
@@ -483,9 +484,11 @@ def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_s
         qkv = qkv.contiguous()
     if qkv_bias is None:
         qkv_bias = torch.zeros(C3, dtype=qkv.dtype, device=qkv.device)
-    out = torch.empty((B, L, C3 // 3), dtype=qkv.dtype, device=qkv.device)
+    if out_scale is not None and qkv.dtype != torch.float16:
+        raise ValueError("the e4m3 output form takes fp16 qkv")
+    out = torch.empty((B, L, C3 // 3), dtype=qkv.dtype if out_scale is None else FP8, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        _cabi.window_attention(qkv, qkv_bias, rel_bias.contiguous(), out, B, H, W, num_heads, window_size, shift)
+        _cabi.window_attention(qkv, qkv_bias, rel_bias.contiguous(), out, B, H, W, num_heads, window_size, shift, out_scale)
     return out
 
 

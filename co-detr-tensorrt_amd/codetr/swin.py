@@ -291,16 +291,15 @@ class SwinBlock(nn.Module):
         return hip_ops.linear(g, fc2.weight, fc2.bias, residual=x)
 
     def _forward_fp8(self, x, hw_shape):
-        """norm1 -> e4m3 | qkv (fp8 GEMM, fp16 out) | window attention (fp16) -> e4m3 | proj (fp8, + identity) |
+        """norm1 -> e4m3 | qkv (fp8 GEMM, fp16 out) | window attention (fp16 in, e4m3 out) | proj (fp8, + identity) |
         norm2 -> e4m3 | fc1 (fp8, GELU, e4m3 out) | fc2 (fp8, + identity): the residual stream stays fp16"""
         n1, n2, m = self.norm1, self.norm2, self.attn.w_msa
         fc1, fc2 = self.ffn.layers[0][0], self.ffn.layers[1]
         sc = self._fp8_scales
         h8 = hip_ops.layer_norm_fp8(x, n1.weight, n1.bias, n1.eps, sc["ln1"])
         qkv = hip_ops.linear_fp8(h8, sc["ln1"], m.qkv.weight, m.qkv.bias)
-        o = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads,
-                                          self.attn.window_size, self.attn.shift_size)
-        o8 = hip_ops.cast_fp8(o, sc["attn"])
+        o8 = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads,
+                                           self.attn.window_size, self.attn.shift_size, out_scale=sc["attn"])
         x = hip_ops.linear_fp8(o8, sc["attn"], m.proj.weight, m.proj.bias, residual=x)
         h8 = hip_ops.layer_norm_fp8(x, n2.weight, n2.bias, n2.eps, sc["ln2"])
         g8 = hip_ops.linear_fp8(h8, sc["ln2"], fc1.weight, fc1.bias, act=self.ffn.act, out_scale=sc["act"])

@@ -97,13 +97,15 @@ __device__ __forceinline__ int swz(int row, int chunk) {
   return chunk ^ j ^ ((j & 1) << 1);
 }
 
-template <class ET, int WS>
+// OUT8: the output is e4m3 = sat(f16(o) * out_inv_scale) (the operand of the fp8 proj GEMM, BASELINE config 5) instead of
+// 16-bit -- what codetr_cast_fp8_f16 would make of the 16-bit output, without that tensor's round trip
+template <class ET, int WS, bool OUT8 = false>
 __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     const typename ET::e* __restrict__ qkv,       // [B, H*W, 3C]
     const typename ET::e* __restrict__ qkv_bias,  // [3C] (zeros if the layer has no bias)
     const typename ET::e* __restrict__ rel_bias,  // [nH, N, N]
-    typename ET::e* __restrict__ out,             // [B, H*W, C]
-    Geometry g, int n_problems) {
+    void* __restrict__ out_v,                     // [B, H*W, C] 16-bit, or e4m3 bytes (OUT8)
+    Geometry g, int n_problems, float out_inv_scale) {
   using E = typename ET::e;
   using V8 = typename ET::v8;
   using V4 = typename ET::v4;
@@ -296,38 +298,44 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     // ---- normalise and store: lane holds channels 16*dt + 4*grp + r of query l15 ----
     if (q_in && tq.valid) {
       const float inv = 1.0f / sum;
-      E* dst = out + ((size_t)b * g.H * g.W + tq.token) * C + hoff + grp * 4;
+      const size_t doff = ((size_t)b * g.H * g.W + tq.token) * C + hoff + grp * 4;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         V4 ov;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ov[r] = (E)(o[dt][r] * inv);
-        *reinterpret_cast<V4*>(dst + dt * 16) = ov;
+        if constexpr (OUT8) {
+          float f[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[r] = __builtin_amdgcn_fmed3f((float)ov[r] * out_inv_scale, -448.0f, 448.0f);
+          int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+          *reinterpret_cast<int*>(static_cast<unsigned char*>(out_v) + doff + dt * 16) = w;
+        } else {
+          *reinterpret_cast<V4*>(static_cast<E*>(out_v) + doff + dt * 16) = ov;
+        }
       }
     }
   }
 }
 
-template <class ET, int WS>
-int launch_ws(hipStream_t st, const void* qkv, const void* qkv_bias, const void* rel_bias, void* out, Geometry g) {
+template <class ET, int WS, bool OUT8>
+int launch_ws(hipStream_t st, const void* qkv, const void* qkv_bias, const void* rel_bias, void* out, Geometry g,
+              float out_inv_scale) {
   const int64_t n = (int64_t)g.B * g.nWin * g.nH;
   if (n > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
-  hipLaunchKernelGGL((window_attention_kernel<ET, WS>), dim3(blocks), dim3(kThreads), 0, st,
+  hipLaunchKernelGGL((window_attention_kernel<ET, WS, OUT8>), dim3(blocks), dim3(kThreads), 0, st,
                      static_cast<const typename ET::e*>(qkv), static_cast<const typename ET::e*>(qkv_bias),
-                     static_cast<const typename ET::e*>(rel_bias), static_cast<typename ET::e*>(out), g, (int)n);
+                     static_cast<const typename ET::e*>(rel_bias), out, g, (int)n, out_inv_scale);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
 
-}  // namespace
-
-namespace {
-
-template <class ET>
+template <class ET, bool OUT8 = false>
 int window_attention_entry(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
                                 void* out_dev, int64_t B, int64_t H, int64_t W, int num_heads, int head_dim,
-                                int window_size, int shift) {
+                                int window_size, int shift, float out_inv_scale = 1.0f) {
   if (!qkv_dev || !qkv_bias_dev || !rel_bias_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || num_heads <= 0)
     return CODETR_E_BADARG;
   if (head_dim != HD || shift < 0 || shift >= window_size) return CODETR_E_UNSUPPORTED;
@@ -344,10 +352,10 @@ int window_attention_entry(void* stream, const void* qkv_dev, const void* qkv_bi
   g.nWin = (g.Hp / window_size) * g.nWx;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (window_size) {
-    case 12: return launch_ws<ET, 12>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
-    case 8: return launch_ws<ET, 8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
-    case 7: return launch_ws<ET, 7>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
-    case 4: return launch_ws<ET, 4>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g);
+    case 12: return launch_ws<ET, 12, OUT8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale);
+    case 8: return launch_ws<ET, 8, OUT8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale);
+    case 7: return launch_ws<ET, 7, OUT8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale);
+    case 4: return launch_ws<ET, 4, OUT8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale);
   }
   return CODETR_E_UNSUPPORTED;
 }
@@ -369,6 +377,15 @@ int codetr_window_attention_bf16(void* stream, const void* qkv_dev, const void* 
                                  int window_size, int shift) {
   return window_attention_entry<BF16E>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, B, H, W, num_heads,
                                        head_dim, window_size, shift);
+}
+
+int codetr_window_attention_fp8out_f16(void* stream, const void* qkv_dev, const void* qkv_bias_dev,
+                                       const void* rel_bias_dev, void* out8_dev, float out_scale, int64_t B, int64_t H,
+                                       int64_t W, int num_heads, int head_dim, int window_size, int shift) {
+  if (!(out_scale > 0.f)) return CODETR_E_BADARG;
+  if ((num_heads * (int64_t)head_dim) % 4 != 0 || (reinterpret_cast<uintptr_t>(out8_dev) & 3)) return CODETR_E_BADARG;
+  return window_attention_entry<F16E, true>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out8_dev, B, H, W, num_heads,
+                                            head_dim, window_size, shift, 1.0f / out_scale);
 }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 36
+#define CODETR_HIP_ABI_VERSION 37
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -493,6 +493,12 @@ int codetr_window_attention_f16(void *stream, const void *qkv_dev, const void *q
 int codetr_window_attention_bf16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
                                  const void *rel_bias_dev, void *out_dev, int64_t B, int64_t H, int64_t W,
                                  int num_heads, int head_dim, int window_size, int shift);
+/* The same attention with the output emitted as OCP e4m3 bytes, out8[i] = sat(f16(o[i]) / out_scale): the operand of
+ * the fp8 proj GEMM (BASELINE config 5) without the 16-bit tensor's round trip: codetr_cast_fp8_f16 applied to the
+ * kernel's own fp16 result (tests: equal to the two-kernel path but for ~1 element per million on a rounding boundary).  out8_dev [B, H*W, C] bytes, 4-byte aligned. */
+int codetr_window_attention_fp8out_f16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
+                                       const void *rel_bias_dev, void *out8_dev, float out_scale, int64_t B,
+                                       int64_t H, int64_t W, int num_heads, int head_dim, int window_size, int shift);
 
 /* ------------------------------------------------------------------------------------------
  * Dense multi-head softmax attention, head_dim 32: the core of nn.MultiheadAttention(256, 8) in the decoder's
