@@ -38,6 +38,14 @@ constexpr float kFp8Max = 448.0f;
 #define FFN8_ABLATE 0
 #endif
 constexpr int kAbl = FFN8_ABLATE;
+#ifndef FFN8_DMA_PLACE
+#define FFN8_DMA_PLACE 0
+#endif
+#ifndef FFN8_STAGGER
+#define FFN8_STAGGER 0
+#endif
+constexpr int kStagger = FFN8_STAGGER;      // experiment: workgroup b starts (b & 3) * kStagger * 8128 cycles late
+constexpr int kDmaPlace = FFN8_DMA_PLACE;   // experiment: 0 spread between the MFMAs, 1 a phase's 8 pieces right after its barrier, 2 at its end
 #ifdef FFN8_STAMPS   // diagnostic build only: per-workgroup cycle sums of the loop's phases (tools/micro/ffn8_ablate.hip)
 __device__ unsigned long long* g_ffn8_stamps = nullptr;
 #define FFN8_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
@@ -176,6 +184,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 
   const float inv_sx = 1.0f / sx;
   int gc = 0;  // chunks consumed so far: ring stage = gc & 1
+  if constexpr (kStagger > 0) {
+    for (int i = 0; i < (int)(blockIdx.x & 3) * kStagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 #ifdef FFN8_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
   const unsigned long long st_begin = st_last;
@@ -326,8 +337,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
           bb[p & 1][u] = *reinterpret_cast<const f32x4*>(sB1 + hu);
         }
         if constexpr (!(kAbl & 1)) {
-          stage_w1(2 * p, cn, nW1);
-          stage_w1(2 * p + 1, cn, nW1);
+          if constexpr (kDmaPlace == 0) {
+            stage_w1(2 * p, cn, nW1);
+            stage_w1(2 * p + 1, cn, nW1);
+          } else if ((kDmaPlace == 1 && p == 0) || (kDmaPlace == 2 && p == 3)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) stage_w1(q, cn, nW1);
+          }
         }
         // 4 independent accumulators, k-block 0 then k-block 1: no MFMA waits for the one before it
 #pragma unroll
@@ -372,8 +388,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
           if constexpr (kAbl & 32) a2[(nt + 3) & 3] = a2[nt & 3];
           else a2[(nt + 3) & 3] = read_w2(nt + 3);
         }
-        if constexpr (!(kAbl & 1))
-          if (nt & 1) stage_w2(nt >> 1, cn, nW2);
+        if constexpr (!(kAbl & 1)) {
+          if constexpr (kDmaPlace == 0) {
+            if (nt & 1) stage_w2(nt >> 1, cn, nW2);
+          } else if ((kDmaPlace == 1 && nt == 0) || (kDmaPlace == 2 && nt == 15)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) stage_w2(q, cn, nW2);
+          }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           if constexpr (kAbl & 4) yacc[nt][mt][0] += (float)(a2[nt & 3][0] ^ pf[mt][nt & 7]);
@@ -384,38 +406,65 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 
     FFN8_T(4);
-    // ---- epilogue on the accumulators as they stand: lane (column l15 = row m of the tile, group g) holds
-    // Y^T[n = 16 nt + 4 g + r][m].  y = yacc * s2' + b2 -> fp16, + identity (the fp16 LayerNorm'ed input, rebuilt from
-    // X and the lane's statistics) -> fp16, LayerNorm over the row (in-lane sums + the four lanes of a row), + pos.
+    // ---- epilogue out of the accumulators (no LDS staging): lane (column l15 = row m of the tile, group g) holds
+    // Y^T[n = 16 nt + 4 g + r][m].  y = yacc * s2' + b2 -> fp16 there; then lanes g and g ^ 1 (16 lanes apart) swap
+    // halves so that every lane owns 8 CONSECUTIVE channels of 8 of the 16 tiles (g even: the even tiles, g odd: the
+    // odd ones; g >> 1 picks channels 0-7 or 8-15 of the tile) -- every load and store below is then 16 bytes per lane
+    // and a wave-instruction touches 64 contiguous bytes per row instead of 32 (the epilogue is bound by the number
+    // of vector-memory instructions: 4-channel accesses took 57k cycles per tile, as long as the MFMA loop).
+    // In that layout: + identity (the fp16 LayerNorm'ed input, rebuilt from X and the row statistics) -> fp16,
+    // LayerNorm over the row (64 in-lane values + the four lanes of a row), + pos.
     // The next tile's input rows are requested first and arrive while this runs.
     {
       const int next = tile + (int)gridDim.x;
       load_x(next < ntiles ? next : tile);
     }
+    const int odd = grp & 1;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = m0 + mt * 16 + l15;
       const int mc = m < M ? m : M - 1;
-      const unsigned short* xrow = X + (size_t)mc * C + grp * 4;
-      f16x4 xr[16];
+      const int cbase = 16 * odd + 8 * (grp >> 1);            // the lane's channels of pair j: 32 j + cbase .. + 7
+      const unsigned short* xrow = X + (size_t)mc * C + cbase;
+      f16x8 xr[8];
 #pragma unroll
-      for (int nt = 0; nt < 16; ++nt) xr[nt] = *reinterpret_cast<const f16x4*>(xrow + nt * 16);
-      float o[16][4];
-      float sm = 0.f;
+      for (int j = 0; j < 8; ++j) xr[j] = *reinterpret_cast<const f16x8*>(xrow + 32 * j);
+      // y -> fp16 pairs in the accumulator layout
+      unsigned yp[16][2];
 #pragma unroll
       for (int nt = 0; nt < 16; ++nt) {
         const EpiRec* rec = sEpi + nt * 4 + grp;
         const f32x4 s2v = *reinterpret_cast<const f32x4*>(rec->s2);
         const f16x4 b2v = *reinterpret_cast<const f16x4*>(rec->b2);
-        const f16x4 giw = *reinterpret_cast<const f16x4*>(rec->gin_w);
-        const f16x4 gib = *reinterpret_cast<const f16x4*>(rec->gin_b);
+        _Float16 y[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const _Float16 y = (_Float16)fmaf(yacc[nt][mt][r], s2v[r], (float)b2v[r]);
-          _Float16 x1 = xr[nt][r];
-          if (lnin_g) x1 = (_Float16)fmaf(((float)x1 - mean_in[mt]) * rstd_in[mt], (float)giw[r], (float)gib[r]);
-          o[nt][r] = (float)(_Float16)((float)y + (float)x1);
-          sm += o[nt][r];
+        for (int r = 0; r < 4; ++r) y[r] = (_Float16)fmaf(yacc[nt][mt][r], s2v[r], (float)b2v[r]);
+        yp[nt][0] = (unsigned)__builtin_bit_cast(unsigned short, y[0]) | ((unsigned)__builtin_bit_cast(unsigned short, y[1]) << 16);
+        yp[nt][1] = (unsigned)__builtin_bit_cast(unsigned short, y[2]) | ((unsigned)__builtin_bit_cast(unsigned short, y[3]) << 16);
+      }
+      float o[8][8];
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // the partner takes this lane's half of the tile the partner owns, and gives its half of this lane's tile
+        const unsigned s0 = odd ? yp[2 * j][0] : yp[2 * j + 1][0], s1 = odd ? yp[2 * j][1] : yp[2 * j + 1][1];
+        const unsigned k0 = odd ? yp[2 * j + 1][0] : yp[2 * j][0], k1 = odd ? yp[2 * j + 1][1] : yp[2 * j][1];
+        const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+        const unsigned z[4] = {odd ? r0 : k0, odd ? r1 : k1, odd ? k0 : r0, odd ? k1 : r1};   // channels cbase .. + 7
+        const EpiRec* rec = sEpi + 8 * j + (cbase >> 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f16x4 giw = *reinterpret_cast<const f16x4*>(rec[q].gin_w);
+          const f16x4 gib = *reinterpret_cast<const f16x4*>(rec[q].gin_b);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned w = z[2 * q + (r >> 1)];
+            const _Float16 y = __builtin_bit_cast(_Float16, (unsigned short)((r & 1) ? (w >> 16) : (w & 0xffffu)));
+            _Float16 x1 = xr[j][4 * q + r];
+            if (lnin_g) x1 = (_Float16)fmaf(((float)x1 - mean_in[mt]) * rstd_in[mt], (float)giw[r], (float)gib[r]);
+            o[j][4 * q + r] = (float)(_Float16)((float)y + (float)x1);
+            sm += o[j][4 * q + r];
+          }
         }
       }
       if (ln_g) {
@@ -424,43 +473,47 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         const float mean = sm * (1.0f / C);
         float q = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt)
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float d = o[nt][r] - mean;
+          for (int e = 0; e < 8; ++e) {
+            const float d = o[j][e] - mean;
             q = fmaf(d, d, q);
           }
         q += __shfl_xor(q, 16, 64);
         q += __shfl_xor(q, 32, 64);
         const float rstd = rsqrtf(q * (1.0f / C) + ln_eps);
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt) {
-          const EpiRec* rec = sEpi + nt * 4 + grp;
-          const f16x4 gw = *reinterpret_cast<const f16x4*>(rec->g_w);
-          const f16x4 gb = *reinterpret_cast<const f16x4*>(rec->g_b);
+        for (int j = 0; j < 8; ++j) {
+          const EpiRec* rec = sEpi + 8 * j + (cbase >> 2);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[nt][r] = (float)(_Float16)fmaf((o[nt][r] - mean) * rstd, (float)gw[r], (float)gb[r]);
+          for (int qq = 0; qq < 2; ++qq) {
+            const f16x4 gw = *reinterpret_cast<const f16x4*>(rec[qq].g_w);
+            const f16x4 gb = *reinterpret_cast<const f16x4*>(rec[qq].g_b);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              o[j][4 * qq + r] = (float)(_Float16)fmaf((o[j][4 * qq + r] - mean) * rstd, (float)gw[r], (float)gb[r]);
+          }
         }
       }
       if (m < M) {
-        unsigned short* yrow = Y + (size_t)m * C + grp * 4;
+        unsigned short* yrow = Y + (size_t)m * C + cbase;
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt) {
-          f16x4 ov;
+        for (int j = 0; j < 8; ++j) {
+          f16x8 ov;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = (_Float16)o[nt][r];
-          *reinterpret_cast<f16x4*>(yrow + nt * 16) = ov;
+          for (int e = 0; e < 8; ++e) ov[e] = (_Float16)o[j][e];
+          *reinterpret_cast<f16x8*>(yrow + 32 * j) = ov;
         }
         if (Y2) {
-          const unsigned short* prow = pos + (size_t)m * C + grp * 4;
-          unsigned short* y2row = Y2 + (size_t)m * C + grp * 4;
+          const unsigned short* prow = pos + (size_t)m * C + cbase;
+          unsigned short* y2row = Y2 + (size_t)m * C + cbase;
 #pragma unroll
-          for (int nt = 0; nt < 16; ++nt) {
-            const f16x4 pv = *reinterpret_cast<const f16x4*>(prow + nt * 16);
-            f16x4 ov;
+          for (int j = 0; j < 8; ++j) {
+            const f16x8 pv = *reinterpret_cast<const f16x8*>(prow + 32 * j);
+            f16x8 ov;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (_Float16)(o[nt][r] + (float)pv[r]);
-            *reinterpret_cast<f16x4*>(y2row + nt * 16) = ov;
+            for (int e = 0; e < 8; ++e) ov[e] = (_Float16)(o[j][e] + (float)pv[e]);
+            *reinterpret_cast<f16x8*>(y2row + 32 * j) = ov;
           }
         }
       }
