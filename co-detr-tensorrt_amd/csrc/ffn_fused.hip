@@ -36,7 +36,6 @@ constexpr int kThreads = 256;
 constexpr int kW1Bytes = BH * C * 2;   // 32 KiB: [64 h][256 k]
 constexpr int kW2Bytes = C * BH * 2;   // 32 KiB: [256 n][64 h]
 constexpr int kStageBytes = kW1Bytes + kW2Bytes;
-constexpr int kOutPitch = C * 2 + 16;  // staged output row: 512 B + 16
 constexpr int kMaxHidden = 8192;       // b1 lives in LDS behind the two stages (16 KiB)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -75,355 +74,344 @@ struct BF16E {
   }
 };
 
-__device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
-  const unsigned q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+// one LDS-DMA piece: 256 threads x 16 B = 4 KiB.  `src` is wave-uniform (kernel argument + scalar offsets), `voff` the
+// thread's byte offset, `dst` the wave's uniform LDS destination.  Inline assembly, not __builtin_amdgcn_global_load_lds:
+// the compiler's wait-count pass files the builtin with out-of-order LDS traffic and from then on turns every wait for a
+// ds_read into lgkmcnt(0), which voids the fragment read-ahead; the instruction only counts in vmcnt, which this kernel
+// waits on by hand (see ffn_fp8.hip).
+__device__ __forceinline__ void dma16(const unsigned char* src, unsigned voff, unsigned char* dst) {
+  const unsigned lds_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds_addr) : "memory");
 }
 
-// One LDS-DMA piece (256 threads x 16 B = 4 KiB) of chunk `c` (hidden units c*64 .. c*64+63) of W1 [Hd, 256] and
-// W2 [256, Hd]: pieces 0..7 fill the W1 image, 8..15 the W2 image of one LDS stage.
-template <int PIECE>
-__device__ __forceinline__ void stage_piece(const unsigned short* __restrict__ W1, const unsigned short* __restrict__ W2,
-                                            int Hd, int c, unsigned char* stage, int tid) {
-  const int wave = tid >> 6;
-  if constexpr (PIECE < 8) {
-    // W1 chunk: 64 rows x 32 chunks of 16 B; LDS position p of row r holds source chunk p ^ (r & 15) (low 4 bits)
-    const int u = PIECE * kThreads + tid;
-    const int r = u >> 5, pos = u & 31;
-    const int chunk = pos ^ (r & 15);
-    const unsigned short* g = W1 + (size_t)(c * BH + r) * C + chunk * 8;
-    unsigned char* l = stage + (PIECE * kThreads + wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-  } else {
-    // W2 chunk: 256 rows (n) x 8 chunks of 16 B (64 hidden units); position p of row n holds chunk p ^ ((n >> 1) & 7)
-    constexpr int q = PIECE - 8;
-    const int u = q * kThreads + tid;
-    const int n = u >> 3, pos = u & 7;
-    const int chunk = pos ^ ((n >> 1) & 7);
-    const unsigned short* g = W2 + (size_t)n * Hd + c * BH + chunk * 8;
-    unsigned char* l = stage + kW1Bytes + (q * kThreads + wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-  }
-}
-
-template <int... P>
-__device__ __forceinline__ void stage_pieces(const unsigned short* __restrict__ W1, const unsigned short* __restrict__ W2,
-                                             int Hd, int c, unsigned char* stage, int tid) {
-  (stage_piece<P>(W1, W2, Hd, c, stage, tid), ...);
-}
-
-__device__ __forceinline__ void stage_chunk(const unsigned short* __restrict__ W1, const unsigned short* __restrict__ W2,
-                                            int Hd, int c, unsigned char* stage, int tid) {
-  stage_pieces<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(W1, W2, Hd, c, stage, tid);
-}
-
-// piece number as a loop variable of an unrolled loop
 template <int N>
-struct PieceSwitch {
-  static __device__ __forceinline__ void run(int piece, const unsigned short* __restrict__ W1,
-                                             const unsigned short* __restrict__ W2, int Hd, int c, unsigned char* stage,
-                                             int tid) {
-    if (piece == N) stage_piece<N>(W1, W2, Hd, c, stage, tid);
-    else PieceSwitch<N - 1>::run(piece, W1, W2, Hd, c, stage, tid);
-  }
-};
-template <>
-struct PieceSwitch<-1> {
-  static __device__ __forceinline__ void run(int, const unsigned short*, const unsigned short*, int, int, unsigned char*,
-                                             int) {}
-};
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-// MT = 16-row tiles per wave (rows per workgroup = 64 * MT)
-template <class ET, int MT>
+// Persistent: gridDim.x workgroups (one per CU) walk the 128-row tiles blockIdx.x, + gridDim.x, ...; the W ring keeps
+// streaming across tiles (every tile reads the same W), the next tile's rows are requested at the start of the
+// epilogue, and the epilogue works out of the accumulators (no LDS staging, no barrier) while the next tile's first W
+// chunks arrive.
+template <class ET>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
     int Hd, const unsigned short* __restrict__ ln_g, const unsigned short* __restrict__ ln_b, float ln_eps,
-    const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2, int row0,
-    const unsigned short* __restrict__ lnin_g, const unsigned short* __restrict__ lnin_b, float lnin_eps) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2 + 256 * 8];  // 146 KiB, one object
+    const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2,
+    const unsigned short* __restrict__ lnin_g, const unsigned short* __restrict__ lnin_b, float lnin_eps, int ntiles) {
+  // [W1 stage 0 | W1 stage 1 | W2 stage 0 | W2 stage 1 | b1 | LayerNorm gamma, beta | b2]: 145.5 KiB, one object
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2 + 1536];
   using E = typename ET::e;
   using V8 = typename ET::v8;
   using V4 = typename ET::v4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int MT = 2, WR = 32;   // 16-row tiles / rows per wave; 128 rows per workgroup
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, grp = lane >> 4;
-  constexpr int BM = 64 * MT, WR = 16 * MT;  // rows per workgroup / per wave
-  const int m0 = row0 + (int)xcd_tile(blockIdx.x, gridDim.x) * BM + wave * WR;  // this wave's first row
   const int nchunks = Hd / BH;
+  unsigned char* ringA = lds;                   // W1 chunks [64 h][256 k]
+  unsigned char* ringB = lds + 2 * kW1Bytes;    // packed W2 chunks [256 n][64 h]
+  unsigned short* sB1 = reinterpret_cast<unsigned short*>(lds + 2 * kStageBytes);
+  unsigned short* sLn = reinterpret_cast<unsigned short*>(lds + 2 * kStageBytes + kMaxHidden * 2);  // gamma[256], beta[256]
+  unsigned short* sB2 = sLn + 512;
 
-  stage_chunk(W1, W2, Hd, 0, lds, tid);
-
-  // X fragments of this wave's 32 rows (B operand: lane (j = l15, g) holds X[m][32*ks + 8g .. +7]), kept for good
-  V8 xf[MT][8];
+  // LDS-DMA geometry (the images of the previous version of this kernel: tests/test_lds_bank_model.py).
+  // W1 chunk: 64 rows x 32 chunks of 16 B; piece p (0..7) = rows 8 p + (tid >> 5), position tid & 31 of row r holds
+  // source chunk (tid & 31) ^ (r & 15): the key depends on the piece's parity only.  W2 chunk: 256 rows x 8 chunks;
+  // piece q = rows 32 q + (tid >> 3), position tid & 7 holds chunk (tid & 7) ^ ((row >> 1) & 7): piece-independent.
+  unsigned w1_voff[2];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int m = m0 + mt * 16 + l15;
+  for (int par = 0; par < 2; ++par)
+    w1_voff[par] = (unsigned)((tid >> 5) * (C * 2) + (((tid & 31) ^ ((par * 8 + (tid >> 5)) & 15)) * 16));
+  const unsigned w2_voff = (unsigned)((tid >> 3) * Hd * 2 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16));
+  const unsigned char* W1b = reinterpret_cast<const unsigned char*>(W1);
+  const unsigned char* W2b = reinterpret_cast<const unsigned char*>(W2);
+  auto stage_w1 = [&](int p, int c, unsigned char* dst) {
+    dma16(W1b + (size_t)c * kW1Bytes + p * 4096, w1_voff[p & 1], dst + (p * kThreads + wave * 64) * 16);
+  };
+  auto stage_w2 = [&](int q, int c, unsigned char* dst) {
+    dma16(W2b + (size_t)q * 64 * Hd + c * (BH * 2), w2_voff, dst + (q * kThreads + wave * 64) * 16);
+  };
+#pragma unroll
+  for (int p = 0; p < 8; ++p) stage_w1(p, 0, ringA);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) stage_w2(p, 0, ringB);
+
+  // a tile's input rows as they come from memory (B-operand layout: lane (j = l15, g) holds X[m][32 ks + 8 g .. + 7])
+  V8 xn[MT][8];
+  auto load_x = [&](int tile, int mt) {
+    int m = tile * 128 + wave * WR + mt * 16 + l15;
     m = m < M ? m : M - 1;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      xf[mt][ks] = *reinterpret_cast<const V8*>(X + (size_t)m * C + ks * 32 + grp * 8);
-  }
-  // Optional LayerNorm of the INPUT rows (the post-norm layer's first norm, whose output nothing else reads): the
-  // 256 values of row (mt, l15) sit in the four lanes l15 + 16 g of this wave (8 k-steps x 8 values each), so the
-  // statistics are two xor-shuffles away; fp32 two-pass like layernorm_kernel, result rounded to f16 = the operand the
-  // separate kernel would have written.  (mean, rstd) go to LDS so that the epilogue rebuilds exactly the same rows
-  // for the residual.
-  float* sStat = reinterpret_cast<float*>(lds + 2 * kStageBytes + kMaxHidden * 2) + wave * (WR * 2);
-  if (lnin_g) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float sm = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sm += (float)xf[mt][ks][e];
-      sm += __shfl_xor(sm, 16, 64);
-      sm += __shfl_xor(sm, 32, 64);
-      const float mean = sm * (1.0f / C);
-      float q = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = (float)xf[mt][ks][e] - mean;
-          q = fmaf(d, d, q);
-        }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
-      const float rstd = rsqrtf(q * (1.0f / C) + lnin_eps);
-      if (grp == 0) {
-        sStat[(mt * 16 + l15) * 2] = mean;
-        sStat[(mt * 16 + l15) * 2 + 1] = rstd;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const V8 gw = *reinterpret_cast<const V8*>(lnin_g + ks * 32 + grp * 8);
-        const V8 gb = *reinterpret_cast<const V8*>(lnin_b + ks * 32 + grp * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          xf[mt][ks][e] = (E)fmaf(((float)xf[mt][ks][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
-      }
-    }
-  }
-  // Y accumulators start at b2 (lane's 4 consecutive n of tile nt: n = 16*nt + 4*grp + r)
-  f32x4 yacc[16][MT];
-#pragma unroll
-  for (int nt = 0; nt < 16; ++nt) {
-    const V4 bb = *reinterpret_cast<const V4*>(b2 + nt * 16 + grp * 4);
-    const f32x4 b4 = {(float)bb[0], (float)bb[1], (float)bb[2], (float)bb[3]};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) yacc[nt][mt] = b4;
-  }
-
-  // b1 goes to LDS once (read per chunk by ds_read_b64: no vector-memory op in the main loop but the LDS-DMA pieces,
-  // so no s_waitcnt vmcnt lands between them)
-  unsigned short* sB1 = reinterpret_cast<unsigned short*>(lds + 2 * kStageBytes);
+    for (int ks = 0; ks < 8; ++ks) xn[mt][ks] = *reinterpret_cast<const V8*>(X + (size_t)m * C + ks * 32 + grp * 8);
+  };
+  load_x(blockIdx.x, 0);
+  load_x(blockIdx.x, 1);
+  // b1 and the output LayerNorm's parameters go to LDS once per workgroup (read by ds_read in the loop / epilogue: no
+  // vector-memory op in the main loop but the LDS-DMA pieces)
   for (int i = tid; i < Hd / 8; i += kThreads)
     *reinterpret_cast<s16x8*>(sB1 + i * 8) = *reinterpret_cast<const s16x8*>(b1 + i * 8);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // ... written before the first barrier below
-
-  for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c landed (and the X loads issued earlier)
-    __builtin_amdgcn_s_barrier();                      // ... for everyone; everyone is done with chunk c-1's stage
-    // the next chunk's 16 LDS-DMA pieces are issued one per MFMA group below (a burst here costs the wave ~100 issue
-    // cycles per piece with nothing else to run on its SIMD); past the last chunk they re-fetch it (no branch in the
-    // pinned schedule), which the s_waitcnt before the epilogue barrier drains
-    const int cn = c + 1 < nchunks ? c + 1 : c;
-    unsigned char* next_stage = lds + ((c + 1) & 1) * kStageBytes;
-    const unsigned char* sW1 = lds + (c & 1) * kStageBytes;
-    const unsigned char* sW2 = sW1 + kW1Bytes;
-
-    // ---- H^T = W1c . X^T : D[i = h][j = m] ----
-    f32x4 hacc[4][MT];
-#pragma unroll
-    for (int ht = 0; ht < 4; ++ht) {
-      // bias of this lane's 4 consecutive hidden units of tile ht
-      const V4 bv = *reinterpret_cast<const V4*>(sB1 + c * BH + ht * 16 + grp * 4);
-      const f32x4 b4 = {(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = b4;
-    }
-    // one wave per SIMD: nobody else hides LDS latency, so the A fragments of k-step ks+1 are read while the
-    // MFMAs of k-step ks issue (explicit register double buffering)
-    auto read_w1 = [&](int ks, V8 (&a)[4]) {
-#pragma unroll
-      for (int ht = 0; ht < 4; ++ht) {
-        const int row = ht * 16 + l15;
-        const int chunk = (ks * 4 + grp) ^ (row & 15);
-        a[ht] = *reinterpret_cast<const V8*>(sW1 + row * (C * 2) + chunk * 16);
-      }
-    };
-    V8 aw[2][4];
-    read_w1(0, aw[0]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      // group ks: 2 MFMAs, then the 4 reads of step ks+1 (the reads of step ks, issued a group earlier, have landed
-      // by the time hipcc's s_waitcnt in front of the first MFMA runs), one LDS-DMA piece of the next chunk, then the
-      // other 4*MT-2 MFMAs.  The DMA instruction ends a scheduling region, so the order is spelled out in source and
-      // the pins only keep the reads behind the first two MFMAs.
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        hacc[i / MT][i % MT] =
-            ET::mfma(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT]);
-      if (ks + 1 < 8) {
-        read_w1(ks + 1, aw[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      }
-      PieceSwitch<7>::run(ks, W1, W2, Hd, cn, next_stage, tid);
-#pragma unroll
-      for (int i = 2; i < 4 * MT; ++i)
-        hacc[i / MT][i % MT] =
-            ET::mfma(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT]);
-    }
-    // ---- ReLU + pack: B operand of the second product, k-slot 8g+j = rows 4g..4g+3 of tiles 2s and 2s+1 ----
-    V8 pf[2][MT];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pf[s][mt][h * 4 + r] = (E)hacc[2 * s + h][mt][r];
-    // ReLU on the packed halves (v_pk_max_f16: one op per two values).  max(NaN, 0) = 0 drops a NaN of the hidden
-    // unit, but a NaN there can only come from a NaN / inf in this row of X, which the residual add puts back.
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        pf[s][mt] = ET::relu(pf[s][mt]);
-      }
-    // ---- Y^T += W2c . relu(H)^T : D[i = n][j = m], k = hidden unit (permuted identically on both operands) ----
-    // W2 fragments (pre-packed: the 8 k-slots of lane group g are 16 contiguous bytes) are read two n-tiles
-    // ahead of their MFMAs, same double buffering
-    auto read_w2 = [&](int ntp, V8 (&a)[4]) {  // n-tiles 2*ntp, 2*ntp+1; index [t*2 + s]
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int n = (2 * ntp + t) * 16 + l15;
-        const unsigned char* rowp = sW2 + n * (BH * 2);
-        const int sw = (n >> 1) & 7;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          a[t * 2 + s] = *reinterpret_cast<const V8*>(rowp + ((4 * s + grp) ^ sw) * 16);
-      }
-    };
-    V8 a2[2][4];
-    read_w2(0, a2[0]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int ntp = 0; ntp < 8; ++ntp) {
-      // same group shape: MFMA index i -> (t, s, mt)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / 2;
-        yacc[nt][mt] = ET::mfma(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt]);
-      }
-      if (ntp + 1 < 8) {
-        read_w2(ntp + 1, a2[(ntp + 1) & 1]);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      }
-      PieceSwitch<15>::run(8 + ntp, W1, W2, Hd, cn, next_stage, tid);
-#pragma unroll
-      for (int i = 2; i < 4 * MT; ++i) {
-        const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / 2;
-        yacc[nt][mt] = ET::mfma(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt]);
-      }
-    }
+  if (ln_g && tid < 64) {
+    const int i = tid & 31;
+    *reinterpret_cast<s16x8*>(sLn + (tid >> 5) * 256 + i * 8) = *reinterpret_cast<const s16x8*>((tid >> 5 ? ln_b : ln_g) + i * 8);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant DMA of the last iteration has landed
-  __builtin_amdgcn_s_barrier();                      // every wave is done with the last stage: LDS is free
+  if (tid >= 64 && tid < 96) *reinterpret_cast<s16x8*>(sB2 + (tid - 64) * 8) = *reinterpret_cast<const s16x8*>(b2 + (tid - 64) * 8);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tables written; the first barrier below publishes them
 
-  // ---- epilogue: Y tile of this wave (32 rows x 256) through LDS, + residual X, whole 512-byte rows out ----
-  unsigned char* stage = lds + wave * (WR * kOutPitch);
-#pragma unroll
-  for (int nt = 0; nt < 16; ++nt)
+  int gc = 0;  // chunks consumed so far: ring stage = gc & 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 128 + wave * WR;
+    // ---- the MFMA operand of the first product and the identity: the rows, or their LayerNorm (the post-norm layer's
+    // first norm, whose output nothing else reads).  The 256 values of row (mt, l15) sit in the four lanes l15 + 16 g
+    // (8 k-steps x 8 values each): statistics are two xor-shuffles away; fp32 two-pass like layernorm_kernel, result
+    // rounded to E = the tensor the separate kernel would have written.
+    V8 xf[MT][8];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const V4 o = {(E)yacc[nt][mt][0], (E)yacc[nt][mt][1], (E)yacc[nt][mt][2],
-                       (E)yacc[nt][mt][3]};
-      *reinterpret_cast<V4*>(stage + (mt * 16 + l15) * kOutPitch + (nt * 16 + grp * 4) * 2) = o;
+      if (lnin_g) {
+        float sm = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sm += (float)xn[mt][ks][e];
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        const float mean = sm * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = (float)xn[mt][ks][e] - mean;
+            q = fmaf(d, d, q);
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q * (1.0f / C) + lnin_eps);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const V8 gw = *reinterpret_cast<const V8*>(lnin_g + ks * 32 + grp * 8);
+          const V8 gb = *reinterpret_cast<const V8*>(lnin_b + ks * 32 + grp * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            xf[mt][ks][e] = (E)fmaf(((float)xn[mt][ks][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xf[mt][ks] = xn[mt][ks];
+      }
     }
-  __builtin_amdgcn_wave_barrier();
-  // WR rows x 32 chunks of 16 B: lane -> (row = it*2 + lane/32, chunk = lane%32).  With one wave per SIMD a
-  // load -> add -> store chain per row pair would expose one memory latency per iteration (measured +85 us per launch
-  // once the epilogue also read pos): all residual / pos rows are requested first -- the accumulators are dead by
-  // now, the registers are free -- and consumed afterwards.
-  const int chunk = lane & 31;
-  V8 xr[WR / 2], pr[WR / 2];
+    // (b2 is added in the epilogue, from LDS: as the accumulators' initial value it is loop-invariant across tiles and
+    // the compiler keeps all 64 converted values alive through the whole loop -- spills)
+    f32x4 yacc[16][MT];
 #pragma unroll
-  for (int it = 0; it < WR / 2; ++it) {
-    int m = m0 + it * 2 + (lane >> 5);
-    m = m < M ? m : M - 1;
-    xr[it] = *reinterpret_cast<const V8*>(X + (size_t)m * C + chunk * 8);
-  }
-  if (Y2) {
+    for (int nt = 0; nt < 16; ++nt)
 #pragma unroll
-    for (int it = 0; it < WR / 2; ++it) {
-      int m = m0 + it * 2 + (lane >> 5);
-      m = m < M ? m : M - 1;
-      pr[it] = *reinterpret_cast<const V8*>(pos + (size_t)m * C + chunk * 8);
+      for (int mt = 0; mt < MT; ++mt) yacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Schedule of one chunk c (ring stage gc & 1; vmcnt counts LDS-DMA pieces, loads and stores in issue order):
+    //   T: wait until W1[c] landed (the 8 younger pieces are W2[c]'s), barrier.  Not in a tile's chunk 0: its pieces
+    //     are older than the tile's input rows, which the code above has waited for -- and a counted wait there would
+    //     also wait for the previous tile's output stores
+    //   product 1, one LDS-DMA piece of W1[c+1] per k-step
+    //   M: wait until W2[c] landed (the 8 younger pieces are W1[c+1]'s), barrier
+    //   product 2, one piece of W2[c+1] per pair of output tiles
+    // W1[c+1] goes to the stage product 1 of chunk c-1 read (every wave passed M of c-1), W2[c+1] to the one product 2
+    // of chunk c-1 read (every wave passed T of c).  Chunk nchunks wraps to chunk 0 of the next tile (past the last
+    // tile: a fetch nobody reads, drained at the end).
+    for (int c = 0; c < nchunks; ++c, ++gc) {
+      const int cn = c + 1 < nchunks ? c + 1 : 0;
+      const unsigned char* sW1 = ringA + (gc & 1) * kW1Bytes;
+      const unsigned char* sW2 = ringB + (gc & 1) * kW2Bytes;
+      unsigned char* nW1 = ringA + ((gc + 1) & 1) * kW1Bytes;
+      unsigned char* nW2 = ringB + ((gc + 1) & 1) * kW2Bytes;
+      if (c > 0) wait_vmcnt<8>();
+      __builtin_amdgcn_s_barrier();  // T
+
+      // ---- H^T = W1c . X^T : D[i = h][j = m] ----
+      f32x4 hacc[4][MT];
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht) {
+        // bias of this lane's 4 consecutive hidden units of tile ht
+        const V4 bv = *reinterpret_cast<const V4*>(sB1 + c * BH + ht * 16 + grp * 4);
+        const f32x4 b4 = {(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = b4;
+      }
+      // one wave per SIMD: nobody else hides LDS latency, so the A fragments of k-step ks+1 are read while the
+      // MFMAs of k-step ks issue (explicit register double buffering)
+      auto read_w1 = [&](int ks, V8 (&a)[4]) {
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+          const int row = ht * 16 + l15;
+          const int chunk = (ks * 4 + grp) ^ (row & 15);
+          a[ht] = *reinterpret_cast<const V8*>(sW1 + row * (C * 2) + chunk * 16);
+        }
+      };
+      V8 aw[2][4];
+      read_w1(0, aw[0]);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) read_w1(ks + 1, aw[(ks + 1) & 1]);
+        stage_w1(ks, cn, nW1);
+#pragma unroll
+        for (int i = 0; i < 4 * MT; ++i)
+          hacc[i / MT][i % MT] = ET::mfma(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT]);
+        // 2 MFMAs, then the 4 reads of the next step and the DMA piece, then the other 6
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- ReLU + pack: B operand of the second product, k-slot 8g+j = rows 4g..4g+3 of tiles 2s and 2s+1 ----
+      V8 pf[2][MT];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pf[s][mt][h * 4 + r] = (E)hacc[2 * s + h][mt][r];
+      // ReLU on the packed halves (one op per two values).  max(NaN, 0) = 0 drops a NaN of the hidden unit, but a NaN
+      // there can only come from a NaN / inf in this row of X, which the residual add puts back.
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pf[s][mt] = ET::relu(pf[s][mt]);
+      if (c > 0) wait_vmcnt<8>();
+      __builtin_amdgcn_s_barrier();  // M
+      // ---- Y^T += W2c . relu(H)^T : D[i = n][j = m], k = hidden unit (permuted identically on both operands) ----
+      // W2 fragments (pre-packed: the 8 k-slots of lane group g are 16 contiguous bytes), read two n-tiles ahead
+      auto read_w2 = [&](int ntp, V8 (&a)[4]) {  // n-tiles 2*ntp, 2*ntp+1; index [t*2 + s]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int n = (2 * ntp + t) * 16 + l15;
+          const unsigned char* rowp = sW2 + n * (BH * 2);
+          const int sw = (n >> 1) & 7;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) a[t * 2 + s] = *reinterpret_cast<const V8*>(rowp + ((4 * s + grp) ^ sw) * 16);
+        }
+      };
+      V8 a2[2][4];
+      read_w2(0, a2[0]);
+#pragma unroll
+      for (int ntp = 0; ntp < 8; ++ntp) {
+        if (ntp + 1 < 8) read_w2(ntp + 1, a2[(ntp + 1) & 1]);
+        stage_w2(ntp, cn, nW2);
+#pragma unroll
+        for (int i = 0; i < 4 * MT; ++i) {   // MFMA index i -> (t, s, mt)
+          const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / 2;
+          yacc[nt][mt] = ET::mfma(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  }
-  V8 gw, gb, gin_w, gin_b;
-  if (ln_g) {
-    gw = *reinterpret_cast<const V8*>(ln_g + chunk * 8);
-    gb = *reinterpret_cast<const V8*>(ln_b + chunk * 8);
-  }
-  if (lnin_g) {
-    gin_w = *reinterpret_cast<const V8*>(lnin_g + chunk * 8);
-    gin_b = *reinterpret_cast<const V8*>(lnin_b + chunk * 8);
-  }
+
+    // ---- epilogue out of the accumulators (no LDS staging): lane (column l15 = row m of the tile, group g) holds
+    // Y^T[n = 16 nt + 4 g + r][m].  y -> E there; then lanes g and g ^ 1 (16 lanes apart) swap halves so that every lane
+    // owns 8 CONSECUTIVE channels of 8 of the 16 tiles (g even: the even tiles, g odd: the odd ones; g >> 1 picks
+    // channels 0-7 or 8-15): channels 32 j + cbase .. + 7, j < 8 -- every load and store is 16 bytes per lane and a
+    // wave-instruction touches 64 contiguous bytes per row.  The identity X[m][32 j + 8 v ..] (v = cbase / 8) is the
+    // register xf[mt][j] of lane group v: one lane permutation (groups 1 and 2 swap) instead of a second read of X.
+    // Then + identity -> E, LayerNorm over the row (64 in-lane values + the four lanes of a row), + pos.
+    // The next tile's input rows are requested as the epilogue goes (each half once the registers of the half just
+    // written are free) and arrive while it runs.
+    const int next_tile = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+    const int odd = grp & 1;
+    const int cbase = 16 * odd + 8 * (grp >> 1);
+    const int src_lane4 = (l15 + 16 * (2 * odd + (grp >> 1))) * 4;   // byte address of the lane that holds the identity
 #pragma unroll
-  for (int it = 0; it < WR / 2; ++it) {
-    const int row = it * 2 + (lane >> 5);
-    const int m = m0 + row;
-    const V8 y = *reinterpret_cast<const V8*>(stage + row * kOutPitch + chunk * 16);
-    V8 xrow = xr[it];
-    if (lnin_g) {  // identity = LayerNorm(input row), the same arithmetic on the same statistics as the prologue
-      const float mean = sStat[row * 2], rstd = sStat[row * 2 + 1];
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + l15;
+      if (mt == 0) load_x(next_tile, 0);
+      unsigned yp[16][2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xrow[e] = (E)fmaf(((float)xrow[e] - mean) * rstd, (float)gin_w[e], (float)gin_b[e]);
-    }
-    V8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (E)((float)y[e] + (float)xrow[e]);  // identity + ffn(x): fp16 + fp16 -> fp16
-    if (ln_g) {
-      // LayerNorm over the row (its 256 values sit in the 32 lanes of this half-wave): the arithmetic of
-      // layernorm_kernel<LnHalf, 32, 1>, statement for statement, so the result is bit-identical to running that
-      // kernel on the stored sum
+      for (int nt = 0; nt < 16; ++nt) {
+        const V4 bb = *reinterpret_cast<const V4*>(sB2 + nt * 16 + grp * 4);
+        const V4 y = {(E)(yacc[nt][mt][0] + (float)bb[0]), (E)(yacc[nt][mt][1] + (float)bb[1]),
+                      (E)(yacc[nt][mt][2] + (float)bb[2]), (E)(yacc[nt][mt][3] + (float)bb[3])};
+        __builtin_memcpy(yp[nt], &y, 8);
+      }
+      float o[8][8];
       float sm = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sm += (float)o[e];
+      for (int j = 0; j < 8; ++j) {
+        // the partner takes this lane's half of the tile the partner owns, and gives its half of this lane's tile
+        const unsigned s0 = odd ? yp[2 * j][0] : yp[2 * j + 1][0], s1 = odd ? yp[2 * j][1] : yp[2 * j + 1][1];
+        const unsigned k0 = odd ? yp[2 * j + 1][0] : yp[2 * j][0], k1 = odd ? yp[2 * j + 1][1] : yp[2 * j][1];
+        const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+        const unsigned z[4] = {odd ? r0 : k0, odd ? r1 : k1, odd ? k0 : r0, odd ? k1 : r1};   // channels cbase .. + 7
+        V8 yv, xid;
+        __builtin_memcpy(&yv, z, 16);
+        int xw[4];
+        __builtin_memcpy(xw, &xf[mt][j], 16);
 #pragma unroll
-      for (int d = 16; d > 0; d >>= 1) sm += __shfl_xor(sm, d, 64);
-      const float mean = sm * (1.0f / C);
-      float q = 0.f;
+        for (int d = 0; d < 4; ++d) xw[d] = __builtin_amdgcn_ds_bpermute(src_lane4, xw[d]);
+        __builtin_memcpy(&xid, xw, 16);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float dv = (float)o[e] - mean;
-        q = fmaf(dv, dv, q);
+        for (int e = 0; e < 8; ++e) {
+          o[j][e] = (float)(E)((float)yv[e] + (float)xid[e]);   // identity + ffn(x): E + E -> E
+          sm += o[j][e];
+        }
       }
+      V8 pr[8];
+      if (Y2) {   // (requested here: the statistics and the normalisation below cover part of the latency)
+        const unsigned short* prow = pos + (size_t)(m < M ? m : M - 1) * C + cbase;
 #pragma unroll
-      for (int d = 16; d > 0; d >>= 1) q += __shfl_xor(q, d, 64);
-      const float rstd = rsqrtf(q * (1.0f / C) + ln_eps);
+        for (int j = 0; j < 8; ++j) pr[j] = *reinterpret_cast<const V8*>(prow + 32 * j);
+      }
+      if (mt == 0) load_x(next_tile, 1);   // xf[0] / yacc[.][0] are dead from here on
+      if (ln_g) {
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        const float mean = sm * (1.0f / C);
+        float q = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (E)fmaf(((float)o[e] - mean) * rstd, (float)gw[e], (float)gb[e]);
-    }
-    if (m < M) {
-      *reinterpret_cast<V8*>(Y + (size_t)m * C + chunk * 8) = o;
-      if (Y2) {  // the next layer's attention input: this row + its positional encoding (fp16 + fp16 -> fp16)
-        V8 o2;
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o2[e] = (E)((float)o[e] + (float)pr[it][e]);
-        *reinterpret_cast<V8*>(Y2 + (size_t)m * C + chunk * 8) = o2;
+          for (int e = 0; e < 8; ++e) {
+            const float d = o[j][e] - mean;
+            q = fmaf(d, d, q);
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q * (1.0f / C) + ln_eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const V8 gw = *reinterpret_cast<const V8*>(sLn + 32 * j + cbase);
+          const V8 gb = *reinterpret_cast<const V8*>(sLn + 256 + 32 * j + cbase);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[j][e] = (float)(E)fmaf((o[j][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
+        }
+      }
+      if (m < M) {
+        unsigned short* yrow = Y + (size_t)m * C + cbase;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          V8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = (E)o[j][e];
+          *reinterpret_cast<V8*>(yrow + 32 * j) = ov;
+        }
+        if (Y2) {  // the next layer's attention input: this row + its positional encoding (E + E -> E)
+          unsigned short* y2row = Y2 + (size_t)m * C + cbase;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            V8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (E)(o[j][e] + (float)pr[j][e]);
+            *reinterpret_cast<V8*>(y2row + 32 * j) = ov;
+          }
+        }
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // W2 [256, hidden] -> same shape with the columns of every 64-block reordered to MFMA k-slot order:
@@ -454,21 +442,22 @@ int ffn_entry(void* stream, const void* x_dev, const void* w1_dev, const void* b
     return CODETR_E_BADARG;
   if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
   if (M > 0x7fffffffLL - 256 || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  // MT = 2 (128 rows per workgroup).  MT = 3 fits the register file only without the interleaved DMA issue (236 VGPR
-  // + 240 AGPR, 570 us at M = 204 600 against 545 us for this variant); with it hipcc spills (1147 us).
-  // (Splitting off the last, mostly empty round of 256 workgroups as 64-row workgroups measured -1 %: workgroups are
-  // not dispatched in lockstep rounds, so the tail is already spread.)
-  constexpr int kMT = 2;
-  const unsigned blocks = (unsigned)((M + 64 * kMT - 1) / (64 * kMT));
-  hipLaunchKernelGGL((ffn_fused_kernel<ET, kMT>), dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+  // 128 rows per tile (2 x 16 rows per wave; 3 x 16 does not fit the register file with the interleaved DMA issue).
+  // Persistent grid: one workgroup per CU.
+  const int ntiles = (int)((M + 127) / 128);
+  int cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  const unsigned blocks = (unsigned)(ntiles < cus ? ntiles : cus);
+  hipLaunchKernelGGL((ffn_fused_kernel<ET>), dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
                      static_cast<const unsigned short*>(x_dev), static_cast<const unsigned short*>(w1_dev),
                      static_cast<const unsigned short*>(b1_dev), static_cast<const unsigned short*>(w2_dev),
                      static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
                      (int)hidden, static_cast<const unsigned short*>(ln_gamma_dev),
                      static_cast<const unsigned short*>(ln_beta_dev), ln_eps,
-                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev), 0,
+                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev),
                      static_cast<const unsigned short*>(ln_in_gamma_dev),
-                     static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps);
+                     static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps, ntiles);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }

@@ -579,8 +579,9 @@ int codetr_ffn_relu_f16(void *stream, const void *x_dev, const void *w1_dev, con
  * of the next layer's attention, codetr/multi_scale_deformable_attention.py:161-162):
  *   y      = LayerNorm(x + ffn(x)) * gamma + beta        ln_gamma_dev / ln_beta_dev [256] f16, both or neither
  *   y_plus_pos = y + pos                                  pos_dev / y_plus_pos_dev [M, 256] f16, both or neither
- * The LayerNorm arithmetic is that of codetr_layernorm_f16 (fp32 two-pass statistics over the f16-rounded sum),
- * bit-identical to running the three kernels one after another. */
+ * The LayerNorm arithmetic is that of codetr_layernorm_f16 (fp32 two-pass statistics over the f16-rounded sum), summed
+ * in the accumulators' lane order: equal to running the three kernels one after another up to the last f16 bit of a
+ * few outputs (< 2 %); y_plus_pos is exactly y + pos. */
 int codetr_ffn_relu_ln_f16(void *stream, const void *x_dev, const void *w1_dev, const void *b1_dev,
                            const void *w2_packed_dev, const void *b2_dev, void *y_dev, int64_t M, int64_t C_in,
                            int64_t hidden, const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps,

@@ -65,8 +65,11 @@ def test_ffn_module_takes_fused_path_and_matches_two_gemm_path():
     torch.testing.assert_close(ys.float(), y2[:, :450].float(), rtol=2e-3, atol=4e-3)
 
 
-def test_ffn_layernorm_pos_epilogue_is_bit_identical_to_three_kernels():
-    """codetr_ffn_relu_ln_f16 == fused FFN -> codetr_layernorm_f16 -> fp16 add, bit for bit."""
+def test_ffn_layernorm_pos_epilogue_matches_three_kernels():
+    """codetr_ffn_relu_ln_f16 == fused FFN -> codetr_layernorm_f16 -> fp16 add.  The epilogue normalises out of the
+    accumulator layout: the same two-pass fp32 statistics as layernorm_kernel but summed in a different order (64 in-lane
+    values, then the four lanes of a row), so a few outputs differ in the last fp16 bit; the `+ pos` output is exactly
+    the kernel's own normalised output + pos."""
     from codetr import _cabi, hip_ops
 
     g = torch.Generator(device=DEV).manual_seed(3)
@@ -85,8 +88,10 @@ def test_ffn_layernorm_pos_epilogue_is_bit_identical_to_three_kernels():
     n1 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5))
     n2, q2 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), pos=pos)
     assert _cabi.CALLS["layernorm"] == before
-    assert torch.equal(n1, n0) and torch.equal(n2, n0)
-    assert torch.equal(q2, n0 + pos)
+    assert torch.equal(n1, n2)
+    assert (n1 != n0).float().mean().item() < 0.02
+    torch.testing.assert_close(n1.float(), n0.float(), rtol=0, atol=4e-3)   # 1 fp16 ulp at |value| < 4
+    assert torch.equal(q2, n2 + pos)
     y3, q3 = hip_ops.ffn_fused(x, w1, b1, w2, b2, pos=pos)  # second output without the norm
     assert torch.equal(y3, y0) and torch.equal(q3, y0 + pos)
     # input LayerNorm folded in: == layer_norm -> fused FFN (+ LN + pos).  The statistics are summed in a different
@@ -179,7 +184,8 @@ def test_ffn_bf16_layernorm_pos_epilogue_matches_three_kernels():
     y0 = hip_ops.ffn_fused(x, w1, b1, w2, b2)
     n0 = hip_ops.layer_norm(y0, gam, bet, 1e-5)
     n1, q1 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), pos=pos)
-    assert torch.equal(n1, n0) and torch.equal(q1, n0 + pos)
+    assert (n1 != n0).float().mean().item() < 0.02 and torch.equal(q1, n1 + pos)   # (summation order: see the f16 test)
+    torch.testing.assert_close(n1.float(), n0.float(), rtol=0, atol=3.2e-2)         # 1 bf16 ulp at |value| < 4
     x1 = hip_ops.layer_norm(x, gam, bet, 1e-5)
     r0 = hip_ops.ffn_fused(x1, w1, b1, w2, b2, ln=(gam, bet, 1e-5))
     r1 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), ln_in=(gam, bet, 1e-5))
