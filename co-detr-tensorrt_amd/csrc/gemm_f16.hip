@@ -164,6 +164,19 @@ __device__ __forceinline__ typename T::frag read_frag(const unsigned char* lds_t
   return *reinterpret_cast<const typename T::frag*>(lds_tile + row * (BKT * 2) + pos * 16);
 }
 
+// one LDS-DMA piece (16 B per lane, 1 KiB per wave-instruction) with a wave-uniform source base in SGPRs and a per-thread
+// byte offset; `dst` is the wave's uniform LDS destination.  Inline assembly: the compiler's wait-count pass files
+// __builtin_amdgcn_global_load_lds with out-of-order LDS traffic and turns every later wait for a ds_read into
+// lgkmcnt(0); the instruction itself only counts in vmcnt, which the callers wait on by hand.
+__device__ __forceinline__ void lds_dma16s(const unsigned char* src, unsigned voff, unsigned char* dst) {
+  const unsigned lds_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -984,29 +997,38 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
   constexpr int kStage = 4 * 32 * kXsPitch;       // 18 KiB: 4 waves x 32 rows
   constexpr int kMaxBias = 1568;
   constexpr int SWZ = (CH % 16 == 0) ? 15 : 7;    // XOR mask that keeps a swizzled chunk inside its row
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kChunkBytes + kStage + kMaxBias * 2];
-  unsigned char* stage_base = lds + 2 * kChunkBytes;
-  unsigned short* sBias = reinterpret_cast<unsigned short*>(lds + 2 * kChunkBytes + kStage);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int kRing = 3;                        // W chunks in flight: c (being multiplied), c + 1, c + 2
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kRing * kChunkBytes + kStage + kMaxBias * 2];
+  unsigned char* stage_base = lds + kRing * kChunkBytes;
+  unsigned short* sBias = reinterpret_cast<unsigned short*>(lds + kRing * kChunkBytes + kStage);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, grp = lane >> 4;
   const int m0 = (int)xcd_tile(blockIdx.x, gridDim.x) * 128 + wave * 32;
   const int nchunks = (N + CN - 1) / CN;
 
+  // LDS-DMA of one W chunk (32 rows x K, kPieces pieces of 4 KiB): piece q covers rows (q * 256 + tid) / CH.  Inline
+  // assembly with a wave-uniform base and a per-thread byte offset (see lds_dma16s): no vector arithmetic per piece but
+  // the row clamp of a ragged last chunk, and the compiler keeps counting its ds_read waits.
+  unsigned piece_row[kPieces], piece_off[kPieces];
+#pragma unroll
+  for (int q = 0; q < kPieces; ++q) {
+    const int u = q * 256 + tid;
+    const int r = u / CH, pos = u % CH;
+    piece_row[q] = (unsigned)r;
+    piece_off[q] = (unsigned)((pos ^ (r & SWZ)) * 16);
+  }
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
   auto stage_chunk = [&](int c, unsigned char* dst) {
+    const unsigned rmax = (unsigned)(N - 1 - c * CN);  // ragged last chunk: re-read the last row, its columns are never stored
 #pragma unroll
     for (int q = 0; q < kPieces; ++q) {
-      const int u = q * 256 + tid;
-      const int r = u / CH, pos = u % CH;
-      const int chunk = pos ^ (r & SWZ);
-      int n = c * CN + r;
-      n = n < N ? n : N - 1;  // ragged last chunk: re-read the last row, its columns are never stored
-      const unsigned short* g = W + (size_t)n * K + chunk * 8;
-      unsigned char* l = dst + (q * 256 + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      const unsigned r = piece_row[q] < rmax ? piece_row[q] : rmax;
+      lds_dma16s(Wb + (size_t)c * kChunkBytes, r * (unsigned)(K * 2) + piece_off[q], dst + (q * 256 + wave * 64) * 16);
     }
   };
   stage_chunk(0, lds);
+  stage_chunk(nchunks > 1 ? 1 : 0, lds + kChunkBytes);   // (a single chunk: a second fetch nobody reads keeps the counts uniform)
 
   // this wave's 32 rows of X, B-operand fragments: lane (j = l15, g = grp) holds X[m][32*ks + 8g .. +7]
   typename T::frag xf[2][KS];
@@ -1072,25 +1094,82 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
   // 16 B per step, 4 steps.
   const int srow = lane >> 3, schunk = lane & 7;
   s16x8 rr[4];
-  for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c landed (and X, first iteration)
-    __builtin_amdgcn_s_barrier();                      // ... for everyone; chunk c-1's buffer is free
-    const int n0 = c * CN;
-    const int np = (c & ~1) * CN;  // first column of the pair
-    // residual rows of this pair of chunks, requested ahead of the DMA burst so that waiting for them later leaves
-    // the DMA of the next chunk in flight
-    if (HAS_RES && !(c & 1)) {
+  // residual rows of the pair that starts at column np (requested one chunk before they are added)
+  auto load_residual = [&](int np) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        int m = m0 + it * 8 + srow;
-        m = m < M ? m : M - 1;
-        int n = np + schunk * 8;
-        n = n + 8 <= N ? n : N - 8;
-        rr[it] = *reinterpret_cast<const s16x8*>(R + (size_t)m * N + n);
+    for (int it = 0; it < 4; ++it) {
+      int m = m0 + it * 8 + srow;
+      m = m < M ? m : M - 1;
+      int n = np + schunk * 8;
+      n = n + 8 <= N ? n : N - 8;
+      rr[it] = *reinterpret_cast<const s16x8*>(R + (size_t)m * N + n);
+    }
+  };
+  // the staged pair that starts at column np: + residual / row mask, 16-byte stores of whole 128-byte row segments
+  auto flush_pair = [&](int np) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int ml = it * 8 + srow;
+      const int m = m0 + ml;
+      const int n = np + schunk * 8;
+      s16x8 v = *reinterpret_cast<const s16x8*>(my_stage + ml * kXsPitch + schunk * 16);
+      if (m < M && n < N) {  // N % 8 == 0: a chunk of 8 columns is inside or outside as a whole
+        if (row_mask) {
+          const unsigned char mk = row_mask[m];
+          if (mk == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = bias ? T::to_f32(sBias[n + e]) : 0.f;
+              if (ACT == 1) x = x < 0.f ? 0.f : x;
+              if (ACT == 2) x = gelu_erf(x);
+              v[e] = (short)T::from_f32(x);
+            }
+          } else if (mk) {
+            v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          }
+        }
+        if (HAS_RES) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[it][e]));
+        }
+        size_t off = (size_t)m * N + n;
+        if (hm_hd > 0) {  // column-block-major destination y[b][n / hm_hd][position][n % hm_hd] (hm_hd % 64 == 0 here)
+          const int bb = m / hm_rows, pos = m - bb * hm_rows;
+          const int head = n / hm_hd, ch = n - head * hm_hd;
+          off = (((size_t)bb * (N / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
+        }
+        *reinterpret_cast<s16x8*>(Y + off) = v;
       }
     }
-    if (c + 1 < nchunks) stage_chunk(c + 1, lds + ((c + 1) & 1) * kChunkBytes);
-    const unsigned char* sW = lds + (c & 1) * kChunkBytes;
+    __builtin_amdgcn_wave_barrier();  // the staging region is rewritten by the next pair
+  };
+  // Schedule (vmcnt counts LDS-DMA pieces, loads and stores in issue order).  Chunk c:
+  //   wait until W[c] landed: everything but the kPieces pieces of W[c+1], the youngest operations, is complete --
+  //     including the stores of the pair flushed a whole chunk earlier, so nobody ever waits for a store just issued
+  //     (the 2-stage form of this loop waited `vmcnt(0)` right behind its own stores: 2.8 us per chunk for 0.25 us of
+  //     MFMAs); barrier: W[c] is visible, everyone is done with W[c-1]
+  //   even c >= 2: flush the pair (c-2, c-1) staged by the previous two chunks; odd c: request that pair's residual rows
+  //   issue W[c+2] into the stage W[c-1] used
+  //   32 x 32 outputs per wave: MFMAs, activation, fp16 image into the wave's staging region
+  int slot = 0;  // ring slot of W[c]
+  for (int c = 0; c < nchunks; ++c) {
+    wait_vmcnt_n<kPieces>();
+    __builtin_amdgcn_s_barrier();
+    const int n0 = c * CN;
+    if (!(c & 1)) {
+      if (c >= 2) flush_pair((c - 2) * CN);
+    } else if (HAS_RES) {
+      load_residual((c - 1) * CN);
+    }
+    {
+      const int c2 = c + 2 < nchunks ? c + 2 : nchunks - 1;  // (past the end: a fetch nobody reads, same counts)
+      const int s2 = slot == 0 ? 2 : slot - 1;               // the slot W[c-1] used
+      stage_chunk(c2, lds + s2 * kChunkBytes);
+    }
+    const unsigned char* sW = lds + slot * kChunkBytes;
+    slot = slot == 2 ? 0 : slot + 1;
 
     f32x4 acc[2][2];  // [n-tile][m-tile]
 #pragma unroll
@@ -1134,45 +1213,14 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
         *reinterpret_cast<s16x4*>(my_stage + (mt * 16 + l15) * kXsPitch + ((c & 1) * CN + nt * 16 + grp * 4) * 2) =
             T::pack4(v);
       }
-    if (!(c & 1) && c + 1 < nchunks) continue;  // the pair's second chunk follows
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int ml = it * 8 + srow;
-      const int m = m0 + ml;
-      const int n = np + schunk * 8;
-      s16x8 v = *reinterpret_cast<const s16x8*>(my_stage + ml * kXsPitch + schunk * 16);
-      if (m < M && n < N) {  // N % 8 == 0: a chunk of 8 columns is inside or outside as a whole
-        if (row_mask) {
-          const unsigned char mk = row_mask[m];
-          if (mk == 2) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float x = bias ? T::to_f32(sBias[n + e]) : 0.f;
-              if (ACT == 1) x = x < 0.f ? 0.f : x;
-              if (ACT == 2) x = gelu_erf(x);
-              v[e] = (short)T::from_f32(x);
-            }
-          } else if (mk) {
-            v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          }
-        }
-        if (HAS_RES) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[it][e]));
-        }
-        size_t off = (size_t)m * N + n;
-        if (hm_hd > 0) {  // column-block-major destination y[b][n / hm_hd][position][n % hm_hd] (hm_hd % 64 == 0 here)
-          const int bb = m / hm_rows, pos = m - bb * hm_rows;
-          const int head = n / hm_hd, ch = n - head * hm_hd;
-          off = (((size_t)bb * (N / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
-        }
-        *reinterpret_cast<s16x8*>(Y + off) = v;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // the staging region is rewritten by the next pair
   }
+  // the last pair (one chunk if nchunks is odd)
+  {
+    const int np = ((nchunks - 1) & ~1) * CN;
+    if (HAS_RES && (nchunks & 1)) load_residual(np);   // (an even count requested it in the last chunk)
+    flush_pair(np);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant fetches of the last two iterations
 }
 
 // The short-K kernel serves f16 / bf16, K in {192, 256}, N % 8 == 0 (16-byte row chunks), 128 <= N <= 1536 (bias in
