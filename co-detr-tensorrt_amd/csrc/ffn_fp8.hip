@@ -3,20 +3,23 @@
 // (reference codetr/transformer_mmcv.py:484-500 FFN inside the post-norm encoder layer :709-749: norm, ffn, norm, and
 // the next layer's `query + query_pos`; no reference counterpart for the 8-bit arithmetic: its dtypes stop at half).
 //
-// Same dataflow as ffn_fused.hip -- a 256-thread workgroup owns 128 rows, each wave keeps its 32 rows of the input as
-// MFMA B fragments and its 32 x 256 slice of Y in accumulators, the hidden activation never leaves the CU -- on
-// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; twice the fp16 MFMA rate):
+// Same dataflow as ffn_fused.hip -- persistent 256-thread workgroups walk 128-row tiles, each wave keeps its 32 rows of
+// the input as MFMA B fragments and its 32 x 256 slice of Y in accumulators, the hidden activation never leaves the CU --
+// on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; twice the fp16 MFMA rate):
 //   * the (LayerNorm'ed) input rows are quantised once, in registers: xq = sat(xn / sx), sx a static per-tensor scale;
 //   * the hidden dimension is walked in chunks of 128: H^T[h][m] = W1q_c . xq^T (K = 256: two MFMAs per 16 x 16 tile),
-//     scale s1[h] * sx, + b1, ReLU, quantise with the static scale sh -- and the four results a lane holds of each of the
-//     eight 16-row tiles are exactly the 32 bytes of its B fragment for the second product (k-slot 4 t + r of lane
-//     group g = hidden unit 16 t + 4 g + r; the same permutation is baked into W2q once, on the host);
+//     then relu(acc s1 sx + b1) / sh as ONE fma and ONE median (s1 sx / sh and b1 / sh sit in LDS; the median is the ReLU
+//     and the +448 saturation at once) -- and the four results a lane holds of each of the eight 16-row tiles are
+//     exactly the 32 bytes of its B fragment for the second product (k-slot 4 t + r of lane group g = hidden unit
+//     16 t + 4 g + r; the same permutation is baked into W2q once, on the host);
 //     Y^T[n][m] += W2q_c . hq^T (K = 128: one MFMA per tile);
-//   * W1q / W2q chunks (32 KiB each, the same bytes per chunk as the fp16 kernel's 64-unit chunks) stream through a
-//     2-stage LDS ring by LDS-DMA, XOR-swizzled on the source address; per-hidden-unit scales and b1 sit in LDS;
-//   * epilogue: scale s2[n] * sh, + b2, + identity (the fp16 LayerNorm'ed input, rebuilt from X and the stored
-//     statistics), LayerNorm, whole rows out through LDS, optionally also row + pos -- as ffn_fused.hip.
-// fp32 accumulation throughout; e4m3 conversions saturate at +-448.
+//   * W1q / W2q chunks (32 KiB each) stream through two 2-stage LDS rings by LDS-DMA (inline asm, scalar base +
+//     per-thread offset), XOR-swizzled on the source address, one barrier in front of each product with a counted
+//     vmcnt wait for pieces issued half a chunk earlier; the rings keep streaming across tiles;
+//   * epilogue out of the accumulators: scale s2[n] sh, + b2 -> fp16, lanes 16 apart swap halves so that every access is
+//     16 bytes per lane, + identity (the fp16 LayerNorm'ed input, rebuilt from X and the lane's row statistics),
+//     LayerNorm, optionally also row + pos.  The next tile's rows are requested first and arrive meanwhile.
+// fp32 accumulation throughout; e4m3 conversions saturate at +-448.  Timeline / ablations: profiles/r02_ffn_stamps.txt.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -38,14 +41,6 @@ constexpr float kFp8Max = 448.0f;
 #define FFN8_ABLATE 0
 #endif
 constexpr int kAbl = FFN8_ABLATE;
-#ifndef FFN8_DMA_PLACE
-#define FFN8_DMA_PLACE 0
-#endif
-#ifndef FFN8_STAGGER
-#define FFN8_STAGGER 0
-#endif
-constexpr int kStagger = FFN8_STAGGER;      // experiment: workgroup b starts (b & 3) * kStagger * 8128 cycles late
-constexpr int kDmaPlace = FFN8_DMA_PLACE;   // experiment: 0 spread between the MFMAs, 1 a phase's 8 pieces right after its barrier, 2 at its end
 #ifdef FFN8_STAMPS   // diagnostic build only: per-workgroup cycle sums of the loop's phases (tools/micro/ffn8_ablate.hip)
 __device__ unsigned long long* g_ffn8_stamps = nullptr;
 #define FFN8_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
@@ -184,9 +179,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 
   const float inv_sx = 1.0f / sx;
   int gc = 0;  // chunks consumed so far: ring stage = gc & 1
-  if constexpr (kStagger > 0) {
-    for (int i = 0; i < (int)(blockIdx.x & 3) * kStagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 #ifdef FFN8_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
   const unsigned long long st_begin = st_last;
@@ -336,14 +328,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
           sc[p & 1][u] = *reinterpret_cast<const f32x4*>(sS1 + hu);
           bb[p & 1][u] = *reinterpret_cast<const f32x4*>(sB1 + hu);
         }
-        if constexpr (!(kAbl & 1)) {
-          if constexpr (kDmaPlace == 0) {
-            stage_w1(2 * p, cn, nW1);
-            stage_w1(2 * p + 1, cn, nW1);
-          } else if ((kDmaPlace == 1 && p == 0) || (kDmaPlace == 2 && p == 3)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) stage_w1(q, cn, nW1);
-          }
+        if constexpr (!(kAbl & 1)) {   // (spread over the phase: as one burst behind the barrier or at the end of the
+          stage_w1(2 * p, cn, nW1);     //  phase the same 8 pieces cost 200 cycles more, profiles/r02_ffn_stamps.txt)
+          stage_w1(2 * p + 1, cn, nW1);
         }
         // 4 independent accumulators, k-block 0 then k-block 1: no MFMA waits for the one before it
 #pragma unroll
@@ -388,14 +375,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
           if constexpr (kAbl & 32) a2[(nt + 3) & 3] = a2[nt & 3];
           else a2[(nt + 3) & 3] = read_w2(nt + 3);
         }
-        if constexpr (!(kAbl & 1)) {
-          if constexpr (kDmaPlace == 0) {
-            if (nt & 1) stage_w2(nt >> 1, cn, nW2);
-          } else if ((kDmaPlace == 1 && nt == 0) || (kDmaPlace == 2 && nt == 15)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) stage_w2(q, cn, nW2);
-          }
-        }
+        if constexpr (!(kAbl & 1))
+          if (nt & 1) stage_w2(nt >> 1, cn, nW2);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           if constexpr (kAbl & 4) yacc[nt][mt][0] += (float)(a2[nt & 3][0] ^ pf[mt][nt & 7]);
@@ -546,7 +527,7 @@ int codetr_ffn_fp8(void* stream, const void* x_f16_dev, const void* w1q_dev, con
   if ((ln_gamma_dev == nullptr) != (ln_beta_dev == nullptr) || (pos_dev == nullptr) != (y_plus_pos_dev == nullptr) ||
       (ln_in_gamma_dev == nullptr) != (ln_in_beta_dev == nullptr))
     return CODETR_E_BADARG;
-  if (C_in != C || hidden % BH != 0 || hidden < 2 * BH || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
+  if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
   if (M > 0x7fffffffLL - 256) return CODETR_E_TOO_LARGE;
   const int ntiles = (int)((M + 127) / 128);
   int cus = 0, dev = 0;

@@ -5,24 +5,26 @@
 // As two GEMMs the hidden activation [M, 2048] (838 MB in fp16 at M = 204 600) is written to HBM by the first and
 // read back by the second, and each GEMM re-reads its activation tile from L2 once per 128-column output tile.  Here
 // the hidden activation never leaves the CU:
-//   * a 256-thread workgroup owns 128 rows; each wave keeps its 32 rows of X as MFMA B-fragments in registers
-//     (2 m-tiles x 8 k-steps) for the whole kernel and its 32 x 256 slice of Y in accumulators;
+//   * persistent 256-thread workgroups (one per CU) walk the 128-row tiles; each wave keeps its 32 rows of X as MFMA
+//     B-fragments in registers (2 m-tiles x 8 k-steps) and its 32 x 256 slice of Y in accumulators;
 //   * the hidden dimension is walked in chunks of 64: H^T[h][m] = W1c . X^T  (K = 256), bias folded into the
 //     accumulator init, ReLU, fp16 pack -- and the packed accumulator IS the B operand of the second product
 //     (cdna_hip_programming.md section 3 "accumulator tile as the next MFMA's operand": the k-slot permutation
 //     8g+j <-> rows {4g..4g+3} of two 16-row tiles is baked into W2 once, by codetr_ffn_pack_w2_f16, so that the
 //     matching A fragment is one ds_read_b128);
 //     Y^T[n][m] += W2c . relu(H)^T  (K = 64);
-//   * W1 / W2 chunks (32 KiB each) stream through a 2-stage LDS ring by LDS-DMA, XOR-swizzled on the source address
-//     so that the ds_read_b128 fragment reads are conflict-free; one barrier per chunk (128 MFMAs per wave);
-//     with one wave per SIMD nothing else hides latency or issue cost, so the schedule is spelled out: fragments are
-//     read one step ahead of their MFMAs (behind the first two MFMAs of a group, so the wait in front of the group
-//     is for reads that landed long ago), and the 16 LDS-DMA pieces of the next chunk go out one per MFMA group
-//     instead of as a burst at the top of the chunk (~100 issue cycles per piece with the SIMD otherwise idle);
-//     ablation at M = 204 600: no DMA -13 %, no barrier -5 %; b1 sits in LDS so that no other vector-memory op
-//     (and no s_waitcnt vmcnt) lands between the DMA pieces;
-//   * the epilogue adds the residual X and streams whole rows out through LDS, like the linear kernel.
-// Algorithmic HBM traffic: X once in, Y once out (2 x M x 256 x 2 B) + 2 MB of weights re-read from L2 per workgroup.
+//   * W1 / W2 chunks (32 KiB each) stream through two 2-stage LDS rings by LDS-DMA, XOR-swizzled on the source
+//     address so that the ds_read_b128 fragment reads are conflict-free, and keep streaming across tiles.  One barrier
+//     in front of each product, with a counted wait (vmcnt(8)) for pieces issued half a chunk earlier; with one wave
+//     per SIMD nothing else hides latency or issue cost, so the schedule is spelled out: fragments are read one step
+//     ahead of their MFMAs (behind the first two MFMAs of a group), one LDS-DMA piece of the next chunk per MFMA
+//     group; the LDS-DMA is inline assembly (scalar base + per-thread offset: no vector arithmetic per piece, and the
+//     compiler keeps emitting counted lgkmcnt waits); b1 / b2 / the LayerNorm parameters sit in LDS;
+//   * the epilogue works out of the accumulators: lanes 16 apart swap halves so that every row access is 16 bytes per
+//     lane, the identity comes from the operand registers of another lane group, LayerNorm statistics are 64 in-lane
+//     values + two shuffles; no LDS staging, no barrier, no second read of X; the next tile's rows arrive meanwhile.
+// Algorithmic HBM traffic: X once in, Y once out (2 x M x 256 x 2 B) + 2 MB of weights re-read from L2 per tile.
+// History and the in-kernel timeline behind this shape: DESIGN.md section 4, profiles/r02_ffn_stamps.txt.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -160,6 +160,7 @@ def test_ffn_fp8_exact_small_integers_pin_the_lane_maps_and_the_w2_permutation()
     (4096, 2048, True, True, True),      # the encoder layer's (norm, ffn, norm) + pos
     (1000, 2048, False, True, False),    # ragged M
     (777, 1024, False, False, False),
+    (130, 128, True, False, False),      # a single chunk
     (130, 256, True, False, False),
 ])
 def test_ffn_fp8_vs_dequantised_float64(Mr, Hd, ln_in, ln_out, with_pos):
