@@ -12,7 +12,7 @@ import json
 import re
 
 GROUPS = [("linear_256_fp8", "linear_fp8"), ("linear_", "linear (f16: 128-tile / 256-tile / XS / split-K)"),
-          ("splitk_reduce", "linear (f16: 128-tile / 256-tile / XS / split-K)"), ("ffn_fused", "ffn_fused"),
+          ("splitk_reduce", "linear (f16: 128-tile / 256-tile / XS / split-K)"), ("ffn_fused", "ffn_fused"), ("ffn_fp8", "ffn_fp8"),
           ("msda_encoder", "msda_encoder"), ("msda_tiled", "msda (general fused, decoder)"), ("window_attention", "window_attention"),
           ("layernorm", "layernorm"), ("mha_attention", "mha_attention"), ("gn_", "groupnorm_tokens")]
 
