@@ -528,6 +528,12 @@ int codetr_ffn_fp8(void* stream, const void* x_f16_dev, const void* w1q_dev, con
       (ln_in_gamma_dev == nullptr) != (ln_in_beta_dev == nullptr))
     return CODETR_E_BADARG;
   if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
+  // rows, weights and LayerNorm parameters are read / written 16 bytes at a time
+  if ((reinterpret_cast<uintptr_t>(x_f16_dev) | reinterpret_cast<uintptr_t>(w1q_dev) | reinterpret_cast<uintptr_t>(w2q_packed_dev) |
+       reinterpret_cast<uintptr_t>(y_f16_dev) | reinterpret_cast<uintptr_t>(ln_in_gamma_dev) |
+       reinterpret_cast<uintptr_t>(ln_in_beta_dev) | reinterpret_cast<uintptr_t>(pos_dev) |
+       reinterpret_cast<uintptr_t>(y_plus_pos_dev)) & 15)
+    return CODETR_E_BADARG;
   if (M > 0x7fffffffLL - 256) return CODETR_E_TOO_LARGE;
   const int ntiles = (int)((M + 127) / 128);
   int cus = 0, dev = 0;

@@ -444,6 +444,13 @@ int ffn_entry(void* stream, const void* x_dev, const void* w1_dev, const void* b
     return CODETR_E_BADARG;
   if (C_in != C || hidden % BH != 0 || hidden > kMaxHidden) return CODETR_E_UNSUPPORTED;
   if (M > 0x7fffffffLL - 256 || hidden > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  // every row / weight / parameter access is a 16-byte one
+  if ((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(w1_dev) | reinterpret_cast<uintptr_t>(b1_dev) |
+       reinterpret_cast<uintptr_t>(w2_dev) | reinterpret_cast<uintptr_t>(b2_dev) | reinterpret_cast<uintptr_t>(y_dev) |
+       reinterpret_cast<uintptr_t>(ln_in_gamma_dev) | reinterpret_cast<uintptr_t>(ln_in_beta_dev) |
+       reinterpret_cast<uintptr_t>(ln_gamma_dev) | reinterpret_cast<uintptr_t>(ln_beta_dev) |
+       reinterpret_cast<uintptr_t>(pos_dev) | reinterpret_cast<uintptr_t>(y_plus_pos_dev)) & 15)
+    return CODETR_E_BADARG;
   // 128 rows per tile (2 x 16 rows per wave; 3 x 16 does not fit the register file with the interleaved DMA issue).
   // Persistent grid: one workgroup per CU.
   const int ntiles = (int)((M + 127) / 128);

@@ -567,8 +567,9 @@ int codetr_sine_pos_tokens_bf16(void *stream, const float *ycum_dev, const float
  *   w2_packed_dev [256, hidden]: the second Linear's weight passed ONCE through codetr_ffn_pack_w2_f16 (a column
  *   permutation inside every 64-block that puts the hidden units in the order the first product's accumulators
  *   hold them, so that those accumulators feed the second product without leaving registers)
- * C_in must be 256, hidden a multiple of 64.  fp32 accumulation; the hidden activation is rounded to f16 between
- * the two products and the FFN output once more before the residual add (as the two-kernel f16 path does).
+ * C_in must be 256, hidden a multiple of 64; all device pointers 16-byte aligned (CODETR_E_BADARG otherwise).  fp32
+ * accumulation; the hidden activation is rounded to f16 between the two products and the FFN output once more before
+ * the residual add (as the two-kernel f16 path does).
  * ------------------------------------------------------------------------------------------ */
 int codetr_ffn_relu_f16(void *stream, const void *x_dev, const void *w1_dev, const void *b1_dev,
                         const void *w2_packed_dev, const void *b2_dev, void *y_dev, int64_t M, int64_t C_in,
@@ -608,7 +609,8 @@ int codetr_ffn_relu_ln2_f16(void *stream, const void *x_dev, const void *w1_dev,
  * hidden unit 16 t + 4 g + r of the block (g < 4, t < 8, r < 4 -- the order in which the first product's accumulators
  * become the second product's operand).  x_scale / h_scale: static per-tensor activation scales from calibration.
  * fp32 accumulation with v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales); conversions saturate at +-448.
- * C_in must be 256, hidden a multiple of 128 and <= 2048; CODETR_E_UNSUPPORTED otherwise. */
+ * C_in must be 256, hidden a multiple of 128 and <= 2048 (CODETR_E_UNSUPPORTED otherwise); x, y, pos, the weights and
+ * the LayerNorm parameters 16-byte aligned (CODETR_E_BADARG). */
 int codetr_ffn_fp8(void *stream, const void *x_f16_dev, const void *w1q_dev, const float *w1_scale_dev,
                    const void *b1_f16_dev, const void *w2q_packed_dev, const float *w2_scale_dev,
                    const void *b2_f16_dev, void *y_f16_dev, int64_t M, int64_t C_in, int64_t hidden, float x_scale,
