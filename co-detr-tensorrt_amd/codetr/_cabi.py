@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -36,10 +36,19 @@ SIGNATURES = {
                                              _i32, _i32, _i32, _i64, _i32, _vp]),
     "codetr_msda_fused_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _i64,
                                               _i32, _i32, _i32, _i64, _i32, _vp]),
+    "codetr_msda_fused_forward_ref32_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _i64,
+                                                   _i32, _i32, _i32, _i64, _i32, _vp]),
+    "codetr_msda_fused_forward_ref32_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _i64,
+                                                    _i32, _i32, _i32, _i64, _i32, _vp]),
     "codetr_msda_encoder_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32,
                                                _i32, _i32, _vp]),
     "codetr_msda_encoder_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32,
                                                 _i32, _i32, _vp]),
+    "codetr_msda_encoder_forward_win_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
+                                                   _i32, _i32, _vp, _i32, _vp]),
+    "codetr_msda_encoder_forward_win_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
+                                                    _i32, _i32, _vp, _i32, _vp]),
+    "codetr_msda_encoder_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32]),
     "codetr_mha_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
     "codetr_mha_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
     "codetr_linear_ln_f16": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
@@ -58,14 +67,15 @@ SIGNATURES = {
     "codetr_sigmoid_f16": (_i32, [_vp, _vp, _vp, _i64]),
     "codetr_gather_rows_b16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "codetr_decode_boxes_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, ctypes.c_float, ctypes.c_float]),
-    "codetr_valid_ratios_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32]),
+    "codetr_valid_ratios_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32]),
     "codetr_linear_fp8": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i32, ctypes.c_float, _i64, _i64, _i64,
                                  _i32]),
     "codetr_cast_fp8_f16": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float]),
     "codetr_layernorm_fp8_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float, ctypes.c_float]),
     "codetr_linear_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
-    "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp]),
+    "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp,
+                                           _vp]),
     "codetr_encoder_geometry_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "codetr_row_max_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
     "codetr_preprocess_u8_f16": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -122,7 +132,8 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
 # (host data such as level shapes).  Pure host queries (plans, variants, workspace sizes) are not launches.
 RECORDER = None
 _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
-            "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes"}
+            "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
+            "codetr_msda_encoder_lds_bytes"}
 
 
 class _RecordingLib:
@@ -265,18 +276,22 @@ def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None, hm_rows=0, 
     return out2d
 
 
-def query_sine_embed(ref, valid_ratios, pos_feat, temperature=10000.0, apply_sigmoid=True):
-    """ref [B,Nq,2|4] f16 (unactivated), valid_ratios [B,L,2] f16 -> (ref_in [B,Nq,L,d] f16, embed [B,Nq,d*pos_feat] f16)"""
+def query_sine_embed(ref, valid_ratios, pos_feat, temperature=10000.0, apply_sigmoid=True, valid_ratios32=None):
+    """ref [B,Nq,2|4] f16 (unactivated), valid_ratios [B,L,2] f16 -> (ref_in [B,Nq,L,d] f16, embed [B,Nq,d*pos_feat] f16,
+    ref_in32); valid_ratios32 [B,L,2] fp32: ref_in32 [B,Nq,L,d] fp32 = the same points unrounded (else None)"""
     CALLS["query_sine_embed"] += 1
     B, Nq, d = ref.shape
     L = valid_ratios.shape[1]
     ref_in = torch.empty((B, Nq, L, d), dtype=ref.dtype, device=ref.device)
+    ref_in32 = torch.empty((B, Nq, L, d), dtype=torch.float32, device=ref.device) if valid_ratios32 is not None else None
     embed = torch.empty((B, Nq, d * pos_feat), dtype=ref.dtype, device=ref.device)
-    rc = load().codetr_query_sine_embed_f16(current_stream_ptr(ref.device), ref.data_ptr(), valid_ratios.data_ptr(), B, Nq,
+    rc = load().codetr_query_sine_embed_f16(current_stream_ptr(ref.device), ref.data_ptr(), valid_ratios.data_ptr(),
+                                            valid_ratios32.data_ptr() if valid_ratios32 is not None else None, B, Nq,
                                             d, L, pos_feat, float(temperature), 1 if apply_sigmoid else 0,
-                                            ref_in.data_ptr(), embed.data_ptr())
+                                            ref_in.data_ptr(), ref_in32.data_ptr() if ref_in32 is not None else None,
+                                            embed.data_ptr())
     check(rc, "codetr_query_sine_embed_f16")
-    return ref_in, embed
+    return ref_in, embed, ref_in32
 
 
 _MSDA_BWD = {torch.float16: "codetr_msda_backward_f16", torch.float32: "codetr_msda_backward_f32",
@@ -464,10 +479,14 @@ def msda_fused_supported(dtype, D, L, P) -> bool:
     return dtype in _MSDA_FUSED_BY_DTYPE and D in (16, 32, 64) and L * P * (256 // (D // 8)) * 32 <= 60 * 1024
 
 
+_MSDA_FUSED_REF32_BY_DTYPE = {torch.float16: "codetr_msda_fused_forward_ref32_f16",
+                              torch.bfloat16: "codetr_msda_fused_forward_ref32_bf16"}
+
+
 def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_col, ref, num_levels, num_points, out,
                head_major=False):
     """value [B,S,M,D] (or [B,M,S,D] when head_major); proj [B,Nq,Ncols] holds the sampling offsets at columns [off_col, off_col+M*L*P*2) and
-    the attention logits at [logit_col, logit_col+M*L*P); ref [B,Nq,L,2|4]; out [B,Nq,M*D]."""
+    the attention logits at [logit_col, logit_col+M*L*P); ref [B,Nq,L,2|4] in value's dtype or fp32; out [B,Nq,M*D]."""
     lib = load()
     CALLS["msda_fused"] += 1
     if head_major:
@@ -476,7 +495,8 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
         B, S, M, D = value.shape
     Nq, ncols = proj.shape[1], proj.shape[2]
     es = proj.element_size()
-    rc = getattr(lib, _MSDA_FUSED_BY_DTYPE[value.dtype])(
+    table = _MSDA_FUSED_REF32_BY_DTYPE if ref.dtype == torch.float32 else _MSDA_FUSED_BY_DTYPE
+    rc = getattr(lib, table[value.dtype])(
         current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
         proj.data_ptr() + off_col * es, ncols, proj.data_ptr() + logit_col * es, ncols,
         ref.data_ptr(), ref.shape[-1], 1 if head_major else 0, B, S, M, D, num_levels, Nq, num_points, out.data_ptr())
@@ -484,15 +504,35 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
     return out
 
 
-_MSDA_ENCODER_BY_DTYPE = {torch.float16: "codetr_msda_encoder_forward_f16",
-                          torch.bfloat16: "codetr_msda_encoder_forward_bf16"}
+_MSDA_ENCODER_BY_DTYPE = {torch.float16: "codetr_msda_encoder_forward_win_f16",
+                          torch.bfloat16: "codetr_msda_encoder_forward_win_bf16"}
 E_UNSUPPORTED = -4
 
 
-def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points, halo, out) -> bool:
+def _windows_array(windows, M, L):
+    """[M][L][4] (x lo, x hi, y lo, y hi) -> ctypes int8 array; an int h means the symmetric halo (-h, h, -h, h)"""
+    if isinstance(windows, int):
+        windows = [[(-windows, windows, -windows, windows)] * L] * M
+    flat = [int(v) for head in windows for lvl in head for v in lvl]
+    if len(flat) != M * L * 4 or any(not -128 <= v <= 127 for v in flat):
+        raise ValueError(f"msda_encoder: windows must be [M={M}][L={L}][4] int8 values")
+    return (ctypes.c_int8 * len(flat))(*flat)
+
+
+def msda_encoder_lds_bytes(level_shapes, M, num_points, windows, variant=2) -> int:
+    """LDS bytes per workgroup codetr_msda_encoder_forward_win_* needs for these windows (variant 1: generic, 2: packed
+    single pass, 3: three passes; negative: CODETR_E_* code)"""
+    L = len(level_shapes)
+    shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
+    return int(load().codetr_msda_encoder_lds_bytes(shapes, M, L, num_points, _windows_array(windows, M, L), int(variant)))
+
+
+def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points, windows, out, passes=1,
+                 valid_counts=None) -> bool:
     """Encoder self-attention form (queries = pixels of the pyramid): value [B,S,M,32]; level_shapes = host
-    list of (h, w); proj / ref as msda_fused (ref [B,S,L,2]).  Returns False when the library reports the shape
-    as unsupported (the caller then uses msda_fused), raises on any other error."""
+    list of (h, w); proj / ref as msda_fused (ref [B,S,L,2]); windows [M][L][4] or a halo; passes 1 | 3; valid_counts
+    [B,L,2] fp32 or None (see the header).  Returns False when the library reports the shape as unsupported (the caller
+    then uses msda_fused), raises on any other error."""
     lib = load()
     B, S, M, D = value.shape
     L = len(level_shapes)
@@ -500,11 +540,12 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points,
     ncols, es = proj.shape[2], proj.element_size()
     rc = getattr(lib, _MSDA_ENCODER_BY_DTYPE[value.dtype])(
         current_stream_ptr(value.device), value.data_ptr(), shapes,
-        proj.data_ptr() + off_col * es, ncols, proj.data_ptr() + logit_col * es, ncols, ref.data_ptr(), B, S, M, D, L,
-        num_points, int(halo), out.data_ptr())
+        proj.data_ptr() + off_col * es, ncols, proj.data_ptr() + logit_col * es, ncols, ref.data_ptr(),
+        valid_counts.data_ptr() if valid_counts is not None else None, B, S, M, D, L,
+        num_points, _windows_array(windows, M, L), int(passes), out.data_ptr())
     if rc == E_UNSUPPORTED:
         return False
-    check(rc, "codetr_msda_encoder_forward")
+    check(rc, "codetr_msda_encoder_forward_win")
     CALLS["msda_encoder"] += 1
     return True
 
@@ -764,9 +805,9 @@ def decode_boxes(coords_unact, idx, num_classes, img_w, img_h, boxes, labels):
           "codetr_decode_boxes_f16")
 
 
-def valid_ratios(counts, level_wh, out):
+def valid_ratios(counts, level_wh, out, out32=None):
     CALLS["small_ops"] += 1
     B, L, _ = counts.shape
     check(load().codetr_valid_ratios_f16(current_stream_ptr(counts.device), counts.data_ptr(), level_wh.data_ptr(), out.data_ptr(),
-                                         B, L), "codetr_valid_ratios_f16")
+                                         out32.data_ptr() if out32 is not None else None, B, L), "codetr_valid_ratios_f16")
     return out

@@ -25,9 +25,23 @@ import torch
 from . import _cabi
 
 MAGIC = b"CODETRPLAN\x00\x02"
-# substrings of kernel / activity names that are not this library's (ATen, rocBLAS / hipBLASLt, MIOpen, rocPRIM, copies)
-FOREIGN_KERNEL_MARKS = ("at::native", "elementwise", "Cijk", "rocprim", "miopen", "MIOpen", "CatArray", "hipblas", "rocblas",
-                        "Memcpy", "Memset")
+import re
+
+from ._kernel_names import KERNEL_NAMES
+
+# WHITELIST: a device activity of the recorded forward is replayable iff it is one of libcodetr_hip.so's own kernels
+# (their __global__ names, tools/gen_kernel_names.py; all live in an anonymous namespace).  Anything else -- ATen,
+# rocBLAS / hipBLASLt, MIOpen, rocPRIM, a Triton kernel, a device copy, whatever a future PyTorch names its kernels --
+# is foreign: the plan would skip it and replay on stale memory.
+_OWN_DEMANGLED = re.compile(r"^(?:void )?\(anonymous namespace\)::(" + "|".join(KERNEL_NAMES) + r")\s*[<(]")
+_OWN_MANGLED = re.compile(r"^_ZN12_GLOBAL__N_1(\d+)([A-Za-z_][A-Za-z0-9_]*)")
+
+
+def is_own_kernel(name: str) -> bool:
+    if _OWN_DEMANGLED.match(name):
+        return True
+    m = _OWN_MANGLED.match(name)
+    return bool(m) and m.group(2)[:int(m.group(1))] in KERNEL_NAMES
 KIND_INT, KIND_FLOAT, KIND_DEV, KIND_NULL, KIND_HOST, KIND_STREAM = 0, 1, 2, 3, 4, 5
 
 
@@ -90,7 +104,7 @@ def export_plan(model, batch_inputs, img_masks, path, warmup=2):
         finally:
             _cabi.RECORDER = None
         foreign = sorted({e.name[:100] for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA
-                          and any(t in e.name for t in FOREIGN_KERNEL_MARKS)})
+                          and not is_own_kernel(e.name)})
         if foreign:
             raise RuntimeError("this model / input shape is not exportable: the forward ran device work outside "
                                f"libcodetr_hip.so that a plan cannot replay: {foreign}")

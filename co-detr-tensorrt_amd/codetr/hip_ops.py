@@ -349,10 +349,17 @@ def query_sine_embed_supported(ref, valid_ratios, pos_feat):
 
 def query_sine_embed(ref, valid_ratios, pos_feat, temperature=10000.0):
     """Decoder layer head in one launch: (sigmoid(ref)[:, :, None] * valid_ratios (tiled to ref_dim)[:, None],
-    gen_sineembed_for_position of its level-0 row) -- see include/codetr_hip.h."""
+    gen_sineembed_for_position of its level-0 row) -- see include/codetr_hip.h.  When `valid_ratios` carries its fp32
+    twin (``_codetr_f32``, hip_ops.valid_ratios), the returned ref_in carries ``_codetr_ref32``: the same reference points
+    with sigmoid and scaling kept in fp32, which msda_fused then samples at."""
     _gpu(ref, "query_sine_embed")
+    vr32 = getattr(valid_ratios, "_codetr_f32", None) if MSDA_FP32_REF else None
     with torch.cuda.device(ref.device):
-        return _cabi.query_sine_embed(ref.contiguous(), valid_ratios.contiguous(), pos_feat, temperature)
+        ref_in, embed, ref32 = _cabi.query_sine_embed(ref.contiguous(), valid_ratios.contiguous(), pos_feat, temperature,
+                                                      valid_ratios32=vr32)
+    if ref32 is not None:
+        ref_in._codetr_ref32 = ref32
+    return ref_in, embed
 
 
 def encoder_geometry(valid_ratios, mask_flat, shapes):
@@ -492,16 +499,13 @@ def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_s
     return out
 
 
-MHA_NATIVE = os.environ.get("CODETR_MHA", "1") != "0"     # A/B switch: 0 = the SDPA library call
-
-
 def mha_self_attention(q, k, v, num_heads):
     """q,k,v [B, N, C] already projected (q / k may be column slices of one fused projection) -> [B, N, C]: dense
     softmax attention, 900 x 900 per head in the decoder (reference transformer_mmcv.py:394-428).  Native kernel for
     head_dim 32 and up to 1024 keys; the SDPA library call otherwise (fp32 parity runs, other head sizes)."""
     _gpu(q, "mha_self_attention")
     B, N, C = q.shape
-    if MHA_NATIVE and _cabi.mha_attention_supported(q, k, v, num_heads):
+    if _cabi.mha_attention_supported(q, k, v, num_heads):
         out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
         with torch.cuda.device(q.device):
             _cabi.mha_attention(q, k, v, num_heads, out)
@@ -532,21 +536,20 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
     else:
         B, S, M, D = value.shape
     out = torch.empty((B, proj.shape[1], M * D), dtype=value.dtype, device=value.device)
+    ref32 = getattr(reference_points, "_codetr_ref32", None) if MSDA_FP32_REF else None
+    ref = ref32 if ref32 is not None else reference_points.to(value.dtype).contiguous()
     if out.numel():
         with torch.cuda.device(value.device):
             _timed("msda_fused", {"B": B, "S": S, "Nq": proj.shape[1], "M": M, "D": D, "L": num_levels, "P": num_points},
                    lambda: _cabi.msda_fused(value.contiguous(), spatial_shapes, level_start_index, proj.contiguous(),
-                                            off_col, logit_col, reference_points.to(value.dtype).contiguous(),
-                                            num_levels, num_points, out, head_major=head_major), value.device)
+                                            off_col, logit_col, ref, num_levels, num_points, out,
+                                            head_major=head_major), value.device)
     return out
-
-
-PATCH_GEMM = os.environ.get("CODETR_PATCH_GEMM", "1") != "0"     # A/B switch: 0 = stem convolution through ATen / MIOpen
 
 
 def patch_embed_supported(x, weight, stride):
     kh, kw = weight.shape[-2:]
-    return (PATCH_GEMM and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype
+    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype
             and kh == kw == 4 and tuple(stride) == (4, 4) and x.shape[1] * 16 <= 64 and not torch.is_grad_enabled())
 
 
@@ -574,7 +577,7 @@ def im2col_tokens(x4d, k, stride, pad):
     _gpu(x4d, "im2col_tokens")
     B, H, W, C = x4d.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    if x4d.dtype in (torch.float16, torch.bfloat16) and C % 8 == 0 and PATCH_GEMM:
+    if x4d.dtype in (torch.float16, torch.bfloat16) and C % 8 == 0:
         out = torch.empty((B, Ho * Wo, k * k * C), dtype=x4d.dtype, device=x4d.device)
         with torch.cuda.device(x4d.device):
             _cabi.im2col_tokens(x4d.contiguous(), k, stride, pad, out)
@@ -584,9 +587,10 @@ def im2col_tokens(x4d, k, stride, pad):
                       for ky in range(k) for kx in range(k)], dim=-1).reshape(B, Ho * Wo, -1)
 
 
-# A/B switch: 0 = torch.topk.  (Long rows are cut over up to 32 workgroups, two passes; level with torch.topk's multi-
-# block rocPRIM chain at the model's sizes, 1 x 204 600 and 1 x 72 000 per image, and deterministic in its tie order.)
-TOPK_NATIVE = os.environ.get("CODETR_TOPK", "1") != "0"
+# (The library routes these three ops can also take -- SDPA, the MIOpen stem convolution, torch.topk -- were measured
+# against the native kernels in rounds 1-2 and are no longer selectable here: tools/ab_library_routes.py times them by
+# patching this module from the outside.  What remains below them is the route for shapes / dtypes the kernels do not
+# take: fp32 parity runs, other head sizes.)
 
 
 def topk(x, k, want_values=True):
@@ -595,7 +599,7 @@ def topk(x, k, want_values=True):
     k <= 1024), torch.topk otherwise (fp32 parity runs)."""
     _gpu(x, "topk")
     x2 = x.reshape(-1, x.shape[-1])
-    if TOPK_NATIVE and not torch.is_grad_enabled():
+    if not torch.is_grad_enabled():
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         if _cabi.topk_supported(x2, k):
             idx = torch.empty((x2.shape[0], k), dtype=torch.int64, device=x.device)
@@ -609,13 +613,62 @@ def topk(x, k, want_values=True):
 
 
 MSDA_ENCODER = os.environ.get("CODETR_MSDA_ENC", "1") != "0"      # A/B switch: 0 = general fused kernel in the encoder
-MSDA_HALO = int(os.environ.get("CODETR_MSDA_HALO", "4"))          # staged offset range, pixels of the sampled level
+MSDA_HALO = int(os.environ.get("CODETR_MSDA_HALO", "4"))          # staged offset range when no windows are given
+MSDA_WINDOWS = os.environ.get("CODETR_MSDA_WINDOWS", "1") != "0"  # A/B switch: 0 = symmetric halo instead of bias windows
+MSDA_PASSES = int(os.environ.get("CODETR_MSDA_PASSES", "3"))      # A/B switch: 1 = single-pass encoder kernels only
+MSDA_FP32_REF = os.environ.get("CODETR_MSDA_FP32_REF", "1") != "0"  # A/B switch: 0 = reference points read in the model dtype
+MSDA_LDS_BUDGET = {1: 80 * 1024, 3: 40 * 1024}   # bytes per workgroup: two / four workgroups per CU share 160 KiB
 
 
-def msda_encoder(value, level_shapes, proj, off_col, logit_col, reference_points, num_points):
+def msda_encoder_passes(dtype, num_levels, num_points):
+    """3 where the three-pass encoder kernel exists (fp16, 5 levels x 4 points), else 1"""
+    return 3 if (MSDA_PASSES == 3 and dtype == torch.float16 and num_levels == 5 and num_points == 4) else 1
+
+
+def msda_encoder_windows(bias, level_shapes, num_heads, num_levels, num_points, passes=1, fp16=True):
+    """Staged window per (head, level) for the encoder kernel from the offset bias [M*L*P*2] (pixels): the bounding box
+    of the head's P bias points on that level, grown on every side by the largest margin (pixels, steps of 1/2) that
+    keeps the workgroup inside MSDA_LDS_BUDGET -- per head (LDS is per (region, head) workgroup) and, with three
+    passes, per pass (each pass stages only its own levels).  A trained head's offsets scatter around its bias points;
+    the reference's initialisation is the grid of multi_scale_deformable_attention.py:90-115.  Host arithmetic on a
+    parameter copy: call once per (module, pyramid) and cache."""
+    import math
+
+    b = bias.detach().float().cpu().view(num_heads, num_levels, num_points, 2)
+    b = torch.round(b * 1024) / 1024   # (cos(pi / 2) is 6e-17, not 0: keep floor / ceil off such dust)
+    lo, hi = b.amin(2).tolist(), b.amax(2).tolist()      # [M][L][2]
+    variant = 3 if passes == 3 else (2 if fp16 and num_levels == 5 and num_points == 4 else 1)
+    groups = [[0], [1, 2], [3, 4]] if passes == 3 else [list(range(num_levels))]
+
+    def window(m, l, mg):
+        return (max(-127, math.floor(lo[m][l][0] - mg)), min(127, math.ceil(hi[m][l][0] + mg)),
+                max(-127, math.floor(lo[m][l][1] - mg)), min(127, math.ceil(hi[m][l][1] + mg)))
+
+    out = []
+    for m in range(num_heads):
+        win = [window(m, l, 0.0) for l in range(num_levels)]
+        for grp in groups:
+            for half in range(24, -1, -1):
+                trial = list(win)
+                for l in grp:
+                    trial[l] = window(m, l, 0.5 * half)
+                need = _cabi.msda_encoder_lds_bytes(level_shapes, num_heads, num_points, [trial] * num_heads, variant)
+                if 0 < need <= MSDA_LDS_BUDGET[passes] or half == 0:
+                    win = trial
+                    break
+        out.append(win)
+    return out
+
+
+def msda_encoder(value, level_shapes, proj, off_col, logit_col, reference_points, num_points, windows=None, passes=1,
+                 valid_counts=None):
     """Encoder self-attention form of msda_fused (queries = the pixels of the pyramid, 2-d reference points): the
-    gather runs out of LDS-staged neighbourhoods.  level_shapes: host sequence of (h, w).  Returns None when the
-    library does not take the shape (caller falls back to msda_fused) -- results are identical either way."""
+    gather runs out of LDS-staged neighbourhoods.  level_shapes: host sequence of (h, w); windows: [M][L][4] staged
+    offset ranges (msda_encoder_windows), default the symmetric MSDA_HALO; passes: 1 | 3; valid_counts [B,L,2] fp32
+    (hip_ops.mask_pyramid): with passes == 3 the reference points are then computed in fp32 inside the kernel instead of
+    being read in the model dtype.  Returns None when the library does not take the shape (caller falls back to
+    msda_fused); fp16 at the model's shape: within the op tolerance of msda_fused, not bit-identical (packed-half blend,
+    see include/codetr_hip.h)."""
     _gpu(value, "msda_encoder")
     B, S, M, D = value.shape
     if not (MSDA_ENCODER and D == 32 and value.dtype in (torch.float16, torch.bfloat16)
@@ -623,10 +676,17 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, reference_points
         return None
     out = torch.empty((B, S, M * D), dtype=value.dtype, device=value.device)
     ok = [True]
+    win = windows if (windows is not None and MSDA_WINDOWS) else MSDA_HALO
+    vc = valid_counts if (passes == 3 and MSDA_FP32_REF and valid_counts is not None) else None
+    if vc is not None and not (vc.dtype == torch.float32 and vc.is_contiguous() and vc.shape == (B, len(level_shapes), 2)):
+        raise ValueError("msda_encoder: valid_counts must be a contiguous fp32 [B, L, 2] tensor")
 
     def run():
         ok[0] = _cabi.msda_encoder(value.contiguous(), level_shapes, proj.contiguous(), off_col, logit_col,
-                                   reference_points.to(value.dtype).contiguous(), num_points, MSDA_HALO, out)
+                                   reference_points.to(value.dtype).contiguous(), num_points, win, out, passes, vc)
+        if not ok[0] and passes == 3:    # (regions of more queries than the three-pass kernel's waves hold)
+            ok[0] = _cabi.msda_encoder(value.contiguous(), level_shapes, proj.contiguous(), off_col, logit_col,
+                                       reference_points.to(value.dtype).contiguous(), num_points, MSDA_HALO, out, 1, None)
 
     with torch.cuda.device(value.device):
         _timed("msda_fused", {"B": B, "S": S, "Nq": S, "M": M, "D": D, "L": len(level_shapes), "P": num_points},
@@ -715,7 +775,8 @@ def linear_fp8_supported(rows, weight):
     fill the chip (smaller problems stay on the fp16 kernels)"""
     N, K = weight.shape
     return (weight.is_cuda and weight.dtype == torch.float16 and K % 128 == 0 and N % 8 == 0
-            and -(-rows // 256) * -(-N // 256) >= FP8_MIN_TILES)
+            and -(-rows // 256) * -(-N // 256) >= FP8_MIN_TILES
+            and rows * N <= 0x7fffffff)   # (the kernel's 32-bit output offsets: larger batches stay on the fp16 kernels)
 
 
 def linear_fp8(x8, x_scale, weight, bias=None, act=None, residual=None, out_scale=None):
@@ -833,7 +894,10 @@ def valid_ratios(counts, level_wh):
     _gpu(counts, "valid_ratios")
     if _native16(level_wh) and counts.dtype == torch.float32 and counts.is_contiguous() and level_wh.is_contiguous():
         out = torch.empty(counts.shape, dtype=level_wh.dtype, device=counts.device)
+        out32 = torch.empty(counts.shape, dtype=torch.float32, device=counts.device) if level_wh.dtype == torch.float16 else None
         with torch.cuda.device(counts.device):
-            _cabi.valid_ratios(counts, level_wh, out)
+            _cabi.valid_ratios(counts, level_wh, out, out32)
+        if out32 is not None:
+            out._codetr_f32 = out32   # counts / size unrounded: what the fp32 reference computes (query_sine_embed)
         return out
     return counts.to(level_wh.dtype) / level_wh

@@ -92,6 +92,15 @@ class MultiScaleDeformableAttention(nn.Module):
         return hip_ops.derived(ws, "_codetr_fused_proj", lambda: (torch.cat((ws[0], ws[2]), 0).contiguous(),
                                                                   torch.cat((ws[1], ws[3]), 0).contiguous()))
 
+    def _encoder_windows(self, host_shapes, dtype, passes):
+        """staged window per (head, level) of the LDS-staged encoder kernel, from the offset bias; rebuilt only when
+        the bias tensor or the pyramid changes (one device-to-host copy of 320 values, outside the steady state)"""
+        key = f"_codetr_enc_windows_{passes}_" + "_".join(f"{int(h)}x{int(w)}" for h, w in host_shapes) + str(dtype)
+        b = self.sampling_offsets.bias
+        return hip_ops.derived((b,), key, lambda: hip_ops.msda_encoder_windows(
+            b, [(int(h), int(w)) for h, w in host_shapes], self.num_heads, self.num_levels, self.num_points,
+            passes, dtype == torch.float16))
+
     # ------------------------------------------------------------------ batch-first core
     def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
                    level_start_index, query_plus_pos=None, value_projected=None):
@@ -143,7 +152,10 @@ class MultiScaleDeformableAttention(nn.Module):
             host_shapes = getattr(spatial_shapes, "_codetr_host", None)
             if host_shapes is not None and Nq == S and reference_points.shape[-1] == 2:
                 # encoder self-attention: queries are the pixels of the pyramid -> LDS-staged gather
-                out = hip_ops.msda_encoder(v, host_shapes, proj, 0, H * L * P * 2, reference_points, P)
+                passes = hip_ops.msda_encoder_passes(v.dtype, L, P)
+                out = hip_ops.msda_encoder(v, host_shapes, proj, 0, H * L * P * 2, reference_points, P,
+                                           self._encoder_windows(host_shapes, v.dtype, passes), passes,
+                                           getattr(reference_points, "_codetr_valid_counts", None))
             if out is None:
                 out = hip_ops.msda_fused(v, spatial_shapes, level_start_index, proj, 0, H * L * P * 2,
                                          reference_points, L, P)

@@ -385,6 +385,10 @@ class CoDinoTransformer(nn.Module):
         if native_geom:
             # reference points, per-level scaling, masked proposals and the keep / drop state of every token: one launch
             reference_points, ref_by_level, proposals, row_state = hip_ops.encoder_geometry(valid_ratios, mask, shapes)
+            if valid_counts is not None:
+                # these ARE get_reference_points x valid ratios: the encoder's MSDA kernel may recompute them in fp32
+                # from the counts instead of reading the fp16 tensor (a quarter pixel of resolution on a 480-wide level)
+                ref_by_level._codetr_valid_counts = valid_counts
         else:
             reference_points = get_reference_points([tuple(s) for s in shapes], valid_ratios, device=dev)  # [B,S,2]
             ref_by_level = reference_points[:, :, None] * valid_ratios[:, None]  # [B,S,L,2]
@@ -412,11 +416,12 @@ class CoDinoTransformer(nn.Module):
         sel = hip_ops.gather_rows(out_mem, topk)
         topk_coords = run_mlp(reg_branches[last], sel, residual=hip_ops.gather_rows(proposals, topk))
         qw = self.query_embed.weight
-        if B == 1 or not qw.is_cuda:
-            query = qw[None].expand(B, -1, -1)
+        if B == 1 or not qw.is_cuda or torch.is_grad_enabled():
+            query = qw[None].expand(B, -1, -1)   # (a view: keeps the autograd path to query_embed.weight)
         else:
-            # one materialised [B, Nq, C] copy per batch size, kept on the parameter (the decoder's first layer uses it
-            # as a GEMM residual, which needs real rows): no per-forward broadcast copy
+            # inference: one materialised [B, Nq, C] copy per batch size, kept on the parameter (the decoder's first layer
+            # uses it as a GEMM residual, which needs real rows): no per-forward broadcast copy.  Read-only by contract:
+            # every forward gets the same storage
             query = hip_ops.derived((qw,), f"_codetr_query_b{B}", lambda: qw.detach()[None].expand(B, -1, -1).contiguous())
         if capture is not None:
             # the reference's all-rows form (:555-557), for inspection only: what feeds the decoder is `topk_coords`

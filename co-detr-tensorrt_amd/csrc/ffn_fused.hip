@@ -203,6 +203,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) xf[mt][ks] = xn[mt][ks];
       }
+      // Chunk 0 of this tile takes no counted wait (see the schedule below): it relies on the tile's input rows --
+      // issued AFTER the LDS-DMA pieces of W1[0] / W2[0] -- having landed.  Without the LayerNorm nothing above
+      // consumes them, so make the dependence explicit: the compiler must wait for the last-issued row register here
+      // (vmcnt is in order, so the older pieces have landed too), whatever it does with the copies.
+      asm volatile("" ::"v"(xn[mt][7]) : "memory");
     }
     // (b2 is added in the epilogue, from LDS: as the accumulators' initial value it is loop-invariant across tiles and
     // the compiler keeps all 64 converted values alive through the whole loop -- spills)

@@ -31,6 +31,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <type_traits>
@@ -42,8 +43,12 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kRegW = 16, kRegH = 8;  // region, in level-0 pixels
 constexpr int kMaxL = 8;
-constexpr int kMetaInts = 20;  // per level: 5 x 16 B (see region_geometry)
+constexpr int kMaxM = 16;      // heads with a staged window of their own
+constexpr int kMetaInts = 28;  // per level: 7 x 16 B (see region_geometry)
 constexpr int kMaxLds = 160 * 1024;
+constexpr int kPad = 64;       // one row slot in front of and behind the staged rows (see process_v2)
+constexpr int kQueue = 4;      // v2: fix-up records per (query, head) pair and pass
+constexpr int kPre = 2;        // v2: fix-up rounds whose global loads fly under the gather loop
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -66,23 +71,32 @@ struct BF16 {
 };
 
 struct EncGeom {
-  int L, P, M, halo, RX, RY, S, rows_cap, slots_cap, band;
+  int L, P, M, RX, RY, S, rows_cap, slots_cap, band;
   int H[kMaxL], W[kMaxL], start[kMaxL];
   float invH[kMaxL], invW[kMaxL];  // 1.0f / H, 1.0f / W, correctly rounded (what the general kernel divides out)
+  // staged WINDOW per (head, level): offsets (pixels of that level, relative to the query's own location) in
+  // [x lo, x hi] x [y lo, y hi] find their four corners in LDS; the symmetric "halo" h is (-h, h, -h, h)
+  signed char win[kMaxM][kMaxL][4];
+  // v3: levels are staged in PASSES; first[l] = first level of level l's pass (all 0: one pass)
+  int first[kMaxL];
+  // v3: valid pixel counts [B][L][2] (w, h) of the level masks' first row / column, fp32, or null: when given, the
+  // reference points are computed in fp32 from the query's pixel centre and these (instead of being read from `ref`)
+  const float* vcounts;
 };
 
 // ---- region geometry along one axis (n pixels, R regions) --------------------------------------------------
 // pixel x belongs to region r iff its centre (x + 0.5) / n lies in [r / R, (r + 1) / R)
 __host__ __device__ inline int q_bound(int r, int n, int R) { return (2 * r * n + R - 1) / (2 * R); }  // ceil(r n / R - 1/2)
-// rows / columns a sample of a query of region r can touch when |offset| <= halo pixels of this level:
-// floor(r n / R - 1/2 - halo) .. ceil((r + 1) n / R - 1/2 + halo), clamped to the level
-__host__ __device__ inline int patch_lo(int r, int n, int R, int halo) {
-  const int num = 2 * r * n - R - 2 * halo * R;
-  return num <= 0 ? 0 : num / (2 * R);
+// rows / columns a sample of a query of region r can touch when lo <= offset <= hi pixels of this level:
+// floor(r n / R - 1/2 + lo) .. ceil((r + 1) n / R - 1/2 + hi), clamped to the level (and to each other)
+__host__ __device__ inline int patch_lo(int r, int n, int R, int lo) {
+  const int num = 2 * r * n - R + 2 * lo * R;
+  const int v = num <= 0 ? 0 : num / (2 * R);
+  return v > n - 1 ? n - 1 : v;
 }
-__host__ __device__ inline int patch_hi(int r, int n, int R, int halo) {
-  const int num = 2 * (r + 1) * n - R + 2 * halo * R;
-  const int v = (num + 2 * R - 1) / (2 * R);
+__host__ __device__ inline int patch_hi(int r, int n, int R, int hi) {
+  const int num = 2 * (r + 1) * n - R + 2 * hi * R;
+  const int v = num <= 0 ? 0 : (num + 2 * R - 1) / (2 * R);
   return v > n - 1 ? n - 1 : v;
 }
 
@@ -166,12 +180,14 @@ __device__ __forceinline__ int fdiv(int a, int b) {
   return q;
 }
 __device__ __forceinline__ int q_bound_d(int r, int n, int R) { return fdiv(2 * r * n + R - 1, 2 * R); }
-__device__ __forceinline__ int patch_lo_d(int r, int n, int R, int halo) {
-  const int num = 2 * r * n - R - 2 * halo * R;
-  return num <= 0 ? 0 : fdiv(num, 2 * R);
+__device__ __forceinline__ int patch_lo_d(int r, int n, int R, int lo) {
+  const int num = 2 * r * n - R + 2 * lo * R;
+  const int v = num <= 0 ? 0 : fdiv(num, 2 * R);
+  return v > n - 1 ? n - 1 : v;
 }
-__device__ __forceinline__ int patch_hi_d(int r, int n, int R, int halo) {
-  const int v = fdiv(2 * (r + 1) * n - R + 2 * halo * R + 2 * R - 1, 2 * R);
+__device__ __forceinline__ int patch_hi_d(int r, int n, int R, int hi) {
+  const int num = 2 * (r + 1) * n - R + 2 * hi * R;
+  const int v = num <= 0 ? 0 : fdiv(num + 2 * R - 1, 2 * R);
   return v > n - 1 ? n - 1 : v;
 }
 
@@ -460,8 +476,9 @@ __device__ __forceinline__ TileId decode_tile(unsigned tile, const EncGeom& g) {
 __device__ __forceinline__ void region_geometry(int* __restrict__ s_meta, const EncGeom& g, const TileId t, int tid) {
   if (tid < g.L) {
     const int W = g.W[tid], H = g.H[tid];
-    const int px0 = patch_lo_d(t.rx, W, g.RX, g.halo), px1 = patch_hi_d(t.rx, W, g.RX, g.halo);
-    const int py0 = patch_lo_d(t.ry, H, g.RY, g.halo), py1 = patch_hi_d(t.ry, H, g.RY, g.halo);
+    const signed char* wn = g.win[t.m < kMaxM ? t.m : kMaxM - 1][tid];
+    const int px0 = patch_lo_d(t.rx, W, g.RX, wn[0]), px1 = max(px0, patch_hi_d(t.rx, W, g.RX, wn[1]));
+    const int py0 = patch_lo_d(t.ry, H, g.RY, wn[2]), py1 = max(py0, patch_hi_d(t.ry, H, g.RY, wn[3]));
     const int qx0 = q_bound_d(t.rx, W, g.RX), qy0 = q_bound_d(t.ry, H, g.RY);
     int* mt = s_meta + tid * kMetaInts;
     mt[0] = H;
@@ -479,16 +496,31 @@ __device__ __forceinline__ void region_geometry(int* __restrict__ s_meta, const 
     mt[14] = py1;
     mt[16] = __float_as_int(g.invW[tid]);
     mt[17] = __float_as_int(g.invH[tid]);
+    // v2: floor coordinates (x0, y0) whose four corners are staged (or carry no weight: outside the image)
+    mt[18] = px0 == 0 ? -1 : px0;
+    mt[19] = px1 == W - 1 ? W - 1 : px1 - 1;
+    mt[20] = py0 == 0 ? -1 : py0;
+    mt[21] = py1 == H - 1 ? H - 1 : py1 - 1;
+    if (g.vcounts) {  // get_valid_ratio (reference transformer.py:384-400) in fp32
+      const float* vc = g.vcounts + ((size_t)t.b * g.L + tid) * 2;
+      mt[24] = __float_as_int(vc[0] / (float)W);
+      mt[25] = __float_as_int(vc[1] / (float)H);
+    }
   }
   __syncthreads();
   if (tid < g.L) {
     int base = 0, slot0 = 0;
     for (int l = 0; l < tid; ++l) {
-      base += s_meta[l * kMetaInts + 5] * s_meta[l * kMetaInts + 6];
+      if (l >= g.first[tid]) base += s_meta[l * kMetaInts + 5] * s_meta[l * kMetaInts + 6];
       slot0 += s_meta[l * kMetaInts + 10] * s_meta[l * kMetaInts + 11];
     }
     s_meta[tid * kMetaInts + 7] = base;
     s_meta[tid * kMetaInts + 12] = slot0;
+    {  // v2: LDS byte address of staged pixel (x, y) = y * [22] + x * 64 + [23]
+      const int* mt = s_meta + tid * kMetaInts;
+      s_meta[tid * kMetaInts + 22] = mt[5] * 64;
+      s_meta[tid * kMetaInts + 23] = (base - mt[4] * mt[5] - mt[3]) * 64;
+    }
     if (tid == g.L - 1)  // queries in the region
       s_meta[kMaxL * kMetaInts] = slot0 + s_meta[tid * kMetaInts + 10] * s_meta[tid * kMetaInts + 11];
   }
@@ -511,8 +543,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   using S = typename TR::storage;
   constexpr unsigned kRow = 32 * sizeof(S);  // 64 B: one pixel of one head
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* patch = smem;
-  int* s_meta = reinterpret_cast<int*>(smem + (size_t)g.rows_cap * kRow);
+  unsigned char* patch = smem + kPad;
+  int* s_meta = reinterpret_cast<int*>(smem + 2 * kPad + (size_t)g.rows_cap * kRow);
 
   const int tid = threadIdx.x;
   const int L = g.L, P = g.P, M = g.M;
@@ -580,28 +612,688 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
-template <class TR>
-int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, const void* offs, int64_t off_stride,
-                   const void* logits, int64_t logit_stride, const void* ref, int64_t B, int64_t S, int M, int D,
-                   int L, int P, int halo, void* out) {
-  using ST = typename TR::storage;
-  if (!value || !shapes || !offs || !logits || !ref || !out) return CODETR_E_BADARG;
-  if (B <= 0 || S <= 0 || M <= 0 || L <= 0 || P <= 0 || halo < 0) return CODETR_E_BADARG;
-  if (D != 32 || L > kMaxL || L * P > 32) return CODETR_E_UNSUPPORTED;
-  if (off_stride < (int64_t)M * L * P * 2 || logit_stride < (int64_t)M * L * P || off_stride > 0x7fffffff ||
-      logit_stride > 0x7fffffff || (off_stride & 1) || (reinterpret_cast<uintptr_t>(offs) & 3) ||
-      (reinterpret_cast<uintptr_t>(ref) & 3))
-    return CODETR_E_BADARG;
-  EncGeom g{};
+// =====================================================================================================================
+// v2 (fp16, num_levels == 5, num_points == 4: the model's shape).  Same staging, different gather:
+//   * the blend runs on packed halves: per step (2 points = 8 corner rows) a lane multiplies its 8 channels of each
+//     row by the corner's weight with v_pk_fma_f16 (2 MACs per instruction; the fp32 v_fma_mix_f32 blend issues at
+//     the same ~4.4 cycles per instruction per SIMD for ONE MAC: tools/micro/valu_rates.hip) into an 8-term fp16
+//     chain, and adds the chain to its fp32 accumulators -- fp16 weights (bilinear x attention, <= 1), fp32 across
+//     the 10 chains of a (query, head) pair.  The reference's own half instantiation accumulates all 80 terms in
+//     half (ms_deform_attn.cu:250-252 with scalar_t = c10::Half); error against the fp64 oracle: tests/test_msda_
+//     encoder_gpu.py (relative L2 ~5e-4, the final fp16 rounding alone is 2e-4);
+//   * corner weights travel as packed half pairs and the two row addresses as such (x1 = x0 + 1 is the next 64-byte
+//     slot: an immediate offset): 4 quad broadcasts per point instead of 8;
+//   * a sample that leaves the staged window no longer drags its wave through a checked loop: its weights are zeroed
+//     for the gather loop, the owner lane appends a 16-byte record (floor coordinates, level, weights) to the pair's
+//     queue in LDS, and the four lanes of the pair add it from global memory afterwards -- the loads of the first
+//     kPre records are in flight while the gather loop runs.  Pairs with more than kQueue such samples take further
+//     passes over the queue, so the result never depends on the windows, only the speed does;
+//   * the window is per (head, level) (EncGeom::win): a head whose samples lean one way (the reference's
+//     initialisation points head m along angle 2 pi m / M) stages that side.
+// =====================================================================================================================
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ h2 as_h2(unsigned u) { return __builtin_bit_cast(h2, u); }
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+  const h2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// quad broadcast of `v` from lane `owner` of the quad, plus this lane's `add`: ONE v_add_u32_dpp (the compiler splits the
+// builtin form into v_mov_b32_dpp + v_add_u32)
+__device__ __forceinline__ unsigned quad_bcast_add(unsigned v, int owner, unsigned add) {
+  unsigned d;
+  switch (owner) {
+    case 0: asm("v_add_u32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "v"(add)); break;
+    case 1: asm("v_add_u32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "v"(add)); break;
+    case 2: asm("v_add_u32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "v"(add)); break;
+    default: asm("v_add_u32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "v"(add)); break;
+  }
+  return d;
+}
+// acc += (float)h.lo / (float)h.hi in one instruction each (v_cvt_f32_f16 + v_add_f32 otherwise)
+__device__ __forceinline__ void acc_h2(float& lo, float& hi, h2 h) {
+  const unsigned u = __builtin_bit_cast(unsigned, h);
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(u));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi) : "v"(u));
+}
+__device__ __forceinline__ int med3_i(int a, int b, int c) {
+  int d;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+template <class TR, int DEPTH, int KPRE, bool SCHED, int ABL = 0>
+__device__ __forceinline__ void process_v2(const Raw<TR, 5>& raw, const int q, const bool valid,
+                                           const int* __restrict__ s_meta, const unsigned char* __restrict__ patch,
+                                           u32x4* __restrict__ queue, const unsigned char* __restrict__ vimg,
+                                           const unsigned pix_bytes, typename TR::storage* __restrict__ out,
+                                           const size_t out_row, const EncGeom& g, const int sub) {
+  using V = typename TR::vec;
+  constexpr int K = 5;
+  constexpr unsigned kRow = 64;
+  const unsigned lane_byte = (unsigned)sub * 16;
+  const int M = g.M;
+  // -- softmax over the pair's 20 logits (quad reductions) --
+  float pw_[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) pw_[k] = TR::to_f32(raw.w[k]);
+  float mx = pw_[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) mx = fmaxf(mx, pw_[k]);
+  mx = fmaxf(mx, dpp_f<kXor2>(mx));
+  mx = fmaxf(mx, dpp_f<kXor1>(mx));
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    pw_[k] = __expf(pw_[k] - mx);
+    sum += pw_[k];
+  }
+  sum += dpp_f<kXor2>(sum);
+  sum += dpp_f<kXor1>(sum);
+  const float inv = __builtin_amdgcn_rcpf(sum);   // (1 ulp; the weights are rounded to fp16 next)
+
+  // -- own points (point `sub` of every level) -> LDS row addresses, packed weights, out-of-window flags --
+  unsigned ad0[K], ad1[K], mw01[K], mw23[K], rw01[K], rw23[K], hw[K];
+  unsigned bad = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (ABL & 4) {   // timing experiment: no sample preparation
+      ad0[k] = ad1[k] = (unsigned)((q + k) & 255) * 64u;
+      mw01[k] = mw23[k] = rw01[k] = rw23[k] = 0x2c002c00u;
+      hw[k] = 0;
+      continue;
+    }
+    const int* mt = s_meta + k * kMetaInts;
+    const i32x4_t mA = *reinterpret_cast<const i32x4_t*>(mt + 16);  // 1/W, 1/H (float bits), x lo, x hi
+    const i32x4_t mB = *reinterpret_cast<const i32x4_t*>(mt + 20);  // y lo, y hi, row pitch, address constant
+    const int H = g.H[k], W = g.W[k];
+    const float Hf = (float)H, Wf = (float)W;
+    const float x = fmaf(TR::to_f32(raw.o[k].a), __int_as_float(mA[0]), TR::to_f32(raw.r[k].a));
+    const float y = fmaf(TR::to_f32(raw.o[k].b), __int_as_float(mA[1]), TR::to_f32(raw.r[k].b));
+    const float h_im = fmaf(y, Hf, -0.5f);
+    const float w_im = fmaf(x, Wf, -0.5f);
+    const bool gate = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;  // cu:249
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const float lh = h_im - hf, lw = w_im - wf;
+    const int h0 = gate ? (int)hf : 0, w0 = gate ? (int)wf : 0;
+    const float aw = gate ? pw_[k] * inv : 0.f;
+    // corners outside the image carry no weight (cu:52-71)
+    const float wy0 = hf >= 0.f ? (1.f - lh) * aw : 0.f, wy1 = hf + 1.f < Hf ? lh * aw : 0.f;
+    const float wx0 = wf >= 0.f ? 1.f - lw : 0.f, wx1 = wf + 1.f < Wf ? lw : 0.f;
+    rw01[k] = pack_h2(wy0 * wx0, wy0 * wx1);
+    rw23[k] = pack_h2(wy1 * wx0, wy1 * wx1);
+    const int tx = med3_i(w0, mA[2], mA[3]), ty = med3_i(h0, mB[0], mB[1]);
+    const bool isbad = gate && !(tx == w0 && ty == h0);
+    mw01[k] = isbad ? 0u : rw01[k];
+    mw23[k] = isbad ? 0u : rw23[k];
+    hw[k] = ((unsigned)h0 << 16) | ((unsigned)w0 & 0xffffu);
+    const int xo = tx * (int)kRow + mB[3];
+    ad0[k] = (unsigned)(max(ty, 0) * mB[2] + xo);
+    ad1[k] = (unsigned)(min(ty + 1, H - 1) * mB[2] + xo);
+    bad |= isbad ? 1u << (sub + 4 * k) : 0u;
+  }
+  bad |= dpp_u<kXor2>(bad);
+  bad |= dpp_u<kXor1>(bad);
+  const int cnt = __builtin_popcount(bad);
+
+  // the owner lanes append their out-of-window points [base, base + kQueue) of the pair to its queue
+  auto push = [&](int base) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int pt = sub + 4 * k;
+      if ((bad >> pt) & 1u) {
+        const int pos = __builtin_popcount(bad & ((1u << pt) - 1u)) - base;
+        if ((unsigned)pos < (unsigned)kQueue) queue[pos] = u32x4{hw[k], (unsigned)k, rw01[k], rw23[k]};
+      }
+    }
+  };
+  struct Fix {
+    V rows[4];
+    u32x4 rec;
+  };
+  auto fix_issue = [&](Fix& f, int j, bool act) {
+    if (act) {
+      f.rec = queue[j];
+      const int* mt = s_meta + (int)f.rec[1] * kMetaInts;
+      const int H = mt[0], W = mt[1];
+      const unsigned st = (unsigned)mt[2];
+      const int h0 = (int)(short)(f.rec[0] >> 16), w0 = (int)(short)(f.rec[0] & 0xffffu);
+      const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
+      const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
+      const unsigned char* vb = vimg + lane_byte;
+      f.rows[0] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h0c * W + w0c)) * pix_bytes));
+      f.rows[1] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h0c * W + w1c)) * pix_bytes));
+      f.rows[2] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h1c * W + w0c)) * pix_bytes));
+      f.rows[3] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h1c * W + w1c)) * pix_bytes));
+    }
+  };
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  auto fix_apply = [&](const Fix& f, bool act) {
+    if (act) {
+      const h2 a = as_h2(f.rec[2]), b = as_h2(f.rec[3]);
+      const float w[4] = {(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(w[c], TR::to_f32(f.rows[c][j]), acc[j]);
+    }
+  };
+
+  push(0);
+  Fix pre[KPRE > 0 ? KPRE : 1];
+#pragma unroll
+  for (int j = 0; j < KPRE; ++j) fix_issue(pre[j], j, j < cnt);
+
+  // -- gather loop: 10 steps of 2 points; the rows of step s + 1 are requested before the arithmetic of step s --
+  {
+    constexpr int NS = 2 * K, NB = DEPTH + 1;
+    V rows[NB][2][4];
+    unsigned wA[NB][2], wB[NB][2];
+    auto fetch = [&](int s_, int buf) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pt = 2 * s_ + u, o = pt & 3, k = pt >> 2;
+        const unsigned a0 = quad_bcast_add(ad0[k], o, lane_byte), a1 = quad_bcast_add(ad1[k], o, lane_byte);
+        wA[buf][u] = quad_bcast_u(mw01[k], o);
+        wB[buf][u] = quad_bcast_u(mw23[k], o);
+        if (ABL & 1) {   // timing experiment: no LDS reads
+          const _Float16 c0 = (_Float16)(int)(a0 >> 6), c1 = (_Float16)(int)(a1 >> 6);
+          rows[buf][u][0] = rows[buf][u][1] = V{c0, c0, c0, c0, c0, c0, c0, c0};
+          rows[buf][u][2] = rows[buf][u][3] = V{c1, c1, c1, c1, c1, c1, c1, c1};
+          continue;
+        }
+        rows[buf][u][0] = *reinterpret_cast<const V*>(patch + a0);
+        rows[buf][u][1] = *reinterpret_cast<const V*>(patch + a0 + kRow);
+        rows[buf][u][2] = *reinterpret_cast<const V*>(patch + a1);
+        rows[buf][u][3] = *reinterpret_cast<const V*>(patch + a1 + kRow);
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(d, d);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int b = s_ % NB;
+      if (s_ + DEPTH < NS) fetch(s_ + DEPTH, (s_ + DEPTH) % NB);
+      h2 h[4];
+      if (ABL & 2) {   // timing experiment: no blend (one add per row keeps the reads alive)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int cr = 0; cr < 4; ++cr) acc[cr + 4 * u] += (float)rows[b][u][cr][0] * __uint_as_float(wA[b][u] ^ wB[b][u]);
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const h2 a = as_h2(wA[b][u]), c = as_h2(wB[b][u]);
+        const h2 w4[4] = {h2{a[0], a[0]}, h2{a[1], a[1]}, h2{c[0], c[0]}, h2{c[1], c[1]}};
+#pragma unroll
+        for (int cr = 0; cr < 4; ++cr) {
+          const V r = rows[b][u][cr];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const h2 v = {r[2 * j], r[2 * j + 1]};
+            h[j] = (u == 0 && cr == 0) ? v * w4[cr] : __builtin_elementwise_fma(v, w4[cr], h[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc_h2(acc[2 * j], acc[2 * j + 1], h[j]);
+      if (SCHED) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < KPRE; ++j) fix_apply(pre[j], j < cnt);
+  if (__builtin_amdgcn_ballot_w64(cnt > KPRE) != 0) {  // rare: more out-of-window points than prefetched rounds
+    for (int base = 0; __builtin_amdgcn_ballot_w64(cnt > base) != 0; base += kQueue) {
+      if (base > 0) push(base);
+      for (int j = base == 0 ? KPRE : 0; j < kQueue; ++j) {
+        const bool act = base + j < cnt;
+        if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+        Fix f;
+        fix_issue(f, j, act);
+        fix_apply(f, act);
+      }
+    }
+  }
+
+  if (valid) {
+    V packed;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) packed[j] = TR::from_f32(acc[j]);
+    *reinterpret_cast<V*>(reinterpret_cast<unsigned char*>(out) + (out_row + (size_t)q * M) * kRow + lane_byte) = packed;
+  }
+}
+
+// LDS: [pad 64 B | staged rows | pad 64 B | fix-up queues 4 KB | geometry table]
+template <class TR, int DEPTH, int KPRE, bool SCHED, int ABL>
+__device__ __forceinline__ void encoder_v2_body(
+    const typename TR::storage* __restrict__ value, const typename TR::storage* __restrict__ offs,
+    const typename TR::storage* __restrict__ logits, const typename TR::storage* __restrict__ ref,
+    typename TR::storage* __restrict__ out, const EncGeom& g, const int off_stride, const int logit_stride) {
+  using S = typename TR::storage;
+  constexpr unsigned kRow = 64;
+  constexpr int KMAX = 5;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* patch = smem + kPad;
+  u32x4* queues = reinterpret_cast<u32x4*>(smem + 2 * kPad + (size_t)g.rows_cap * kRow);
+  int* s_meta = reinterpret_cast<int*>(queues + (kThreads / 4) * kQueue);
+
+  const int tid = threadIdx.x;
+  const int L = KMAX, P = 4, M = g.M;
+  const int wave = tid >> 6, lane = tid & 63, sub = lane & 3, pl = lane >> 2;
+  const unsigned pix_bytes = (unsigned)M * kRow;
+
+  const TileId t = decode_tile(xcd_tile(blockIdx.x, gridDim.x), g);
+  region_geometry(s_meta, g, t, tid);
+  const int total = s_meta[kMaxL * kMetaInts];
+  const int n_it = total > wave * 16 ? (total - wave * 16 + 63) >> 6 : 0;
+
+  const size_t row0 = (size_t)t.b * g.S;
+  Raw<TR, KMAX> raws[kAhead];
+  int qs[kAhead];
+#pragma unroll
+  for (int a = 0; a < kAhead; ++a) {
+    qs[a] = 0;
+    if (a < n_it) {
+      const int sl = (a * 4 + wave) * 16 + pl;
+      qs[a] = slot_query(s_meta, L, sl < total ? sl : total - 1);
+      load_raw<TR, KMAX, true>(raws[a], offs, logits, ref, row0 + qs[a], t.m, sub, L, P, off_stride, logit_stride);
+    }
+  }
+
+  const unsigned char* vimg = reinterpret_cast<const unsigned char*>(value) + (size_t)t.b * g.S * M * kRow + t.m * kRow;
+  for (int l = 0; l < ((ABL & 8) ? 0 : L); ++l) {
+    const int* mt = s_meta + l * kMetaInts;
+    const int W = mt[1], pw = mt[5];
+    const int n = pw * mt[6] * 4;  // 16-byte pieces
+    const float inv = __frcp_rn((float)pw);
+    const unsigned src0 = (unsigned)(mt[2] + mt[4] * W + mt[3]) * pix_bytes + (unsigned)(lane & 3) * 16;
+    unsigned char* dst0 = patch + (size_t)mt[7] * kRow;
+    for (int e0 = wave * 64; e0 < n; e0 += kThreads) {
+      const int row = (e0 + lane) >> 2;
+      if (e0 + lane < n) {
+        const int y = (int)(((float)row + 0.5f) * inv);
+        const unsigned char* gp = vimg + (src0 + (unsigned)(y * (W - pw) + row) * pix_bytes);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)(dst0 + (size_t)e0 * 16), 16, 0, 0);
+      }
+    }
+  }
+  // the slots in front of the first and behind the last staged row are read with zero weight (x0 = -1, x1 = W):
+  // they must hold finite values
+  if (tid < 8) {
+    const int* mt = s_meta + (L - 1) * kMetaInts;
+    const unsigned end = (unsigned)(mt[7] + mt[5] * mt[6]) * kRow;
+    *reinterpret_cast<u32x4*>(tid < 4 ? smem + tid * 16 : patch + end + (tid - 4) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  u32x4* queue = queues + (size_t)(wave * 16 + pl) * kQueue;
+  const size_t out_row = row0 * M + t.m;
+  for (int it = 0; it < n_it; ++it) {
+    const bool valid = (it * 4 + wave) * 16 + pl < total;
+    const Raw<TR, KMAX> raw = raws[0];
+    const int q = qs[0];
+#pragma unroll
+    for (int a = 0; a + 1 < kAhead; ++a) {
+      raws[a] = raws[a + 1];
+      qs[a] = qs[a + 1];
+    }
+    if (it + kAhead < n_it) {
+      const int sl = ((it + kAhead) * 4 + wave) * 16 + pl;
+      qs[kAhead - 1] = slot_query(s_meta, L, sl < total ? sl : total - 1);
+      load_raw<TR, KMAX, true>(raws[kAhead - 1], offs, logits, ref, row0 + qs[kAhead - 1], t.m, sub, L, P, off_stride,
+                               logit_stride);
+    }
+    process_v2<TR, DEPTH, KPRE, SCHED, ABL>(raw, q, valid, s_meta, patch, queue, vimg, pix_bytes, out, out_row, g, sub);
+  }
+}
+
+template <class TR, int DEPTH = 1, int KPRE = kPre, bool SCHED = true, int ABL = 0>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void msda_encoder_v2_kernel(
+    const typename TR::storage* __restrict__ value, const typename TR::storage* __restrict__ offs,
+    const typename TR::storage* __restrict__ logits, const typename TR::storage* __restrict__ ref,
+    typename TR::storage* __restrict__ out, const EncGeom g, const int off_stride, const int logit_stride) {
+  encoder_v2_body<TR, DEPTH, KPRE, SCHED, ABL>(value, offs, logits, ref, out, g, off_stride, logit_stride);
+}
+// three workgroups per CU (<= 53 KB of LDS each, <= 168 registers)
+template <class TR, int DEPTH = 1, int KPRE = 0>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void msda_encoder_v2_occ3_kernel(
+    const typename TR::storage* __restrict__ value, const typename TR::storage* __restrict__ offs,
+    const typename TR::storage* __restrict__ logits, const typename TR::storage* __restrict__ ref,
+    typename TR::storage* __restrict__ out, const EncGeom g, const int off_stride, const int logit_stride) {
+  encoder_v2_body<TR, DEPTH, KPRE, true, 0>(value, offs, logits, ref, out, g, off_stride, logit_stride);
+}
+
+// =====================================================================================================================
+// v3 (fp16, 5 levels x 4 points): v2's packed-half gather, restructured for OCCUPANCY.
+// Measured on v2 (profiles/r03_msda_encoder_ablation.txt): the gather loop itself is 18 % of the kernel; sample
+// preparation 34 %, per-tile fixed work 27 %, staging 20 % -- and a wave issues at most one vector instruction per
+// ~5 cycles (~9 for the packed-math / DPP forms) however idle its SIMD is (tools/micro/valu_rates.hip), so with two
+// waves per SIMD (73 KB of LDS per workgroup) the vector pipes idle half the time.  Here a workgroup walks its tile in
+// three PASSES over the levels -- {0}, {1, 2}, {3, 4} -- staging only the pass's neighbourhoods: <= 40 KB of LDS and
+// <= 128 registers, FOUR workgroups per CU, and the staged windows grow to +-5-6 pixels per level (a sample outside
+// them is rare: the fix-up queue is the cold path).  A wave keeps the fp32 accumulators and the softmax weights of its
+// (up to kMaxIt) iterations in registers across the passes.
+// =====================================================================================================================
+constexpr int kMaxIt = 3;    // iterations (16 queries each) per wave: regions of up to 192 queries
+constexpr int kQ3 = 2;       // fix-up records per (query, head) pair and queue pass
+
+template <class TR, int LV0, int NLV, bool CREF>
+__device__ __forceinline__ void pass_v3(float (&acc)[8], const float (&aw)[5], const typename Raw<TR, 5>::S2 (&ro)[NLV],
+                                        const typename Raw<TR, 5>::S2 (&rr)[NLV], const float bx, const float by,
+                                        const int* __restrict__ s_meta,
+                                        const unsigned char* __restrict__ patch, u32x4* __restrict__ queue,
+                                        const unsigned char* __restrict__ vimg, const unsigned pix_bytes,
+                                        const EncGeom& g, const int sub) {
+  using V = typename TR::vec;
+  constexpr unsigned kRow = 64;
+  const unsigned lane_byte = (unsigned)sub * 16;
+  unsigned ad0[NLV], ad1[NLV], mw01[NLV], mw23[NLV], rw01[NLV], rw23[NLV], hw[NLV];
+  unsigned bad = 0;
+#pragma unroll
+  for (int i = 0; i < NLV; ++i) {
+    constexpr int kDummy = 0;
+    (void)kDummy;
+    const int k = LV0 + i;
+    const int* mt = s_meta + k * kMetaInts;
+    const i32x4_t mA = *reinterpret_cast<const i32x4_t*>(mt + 16);  // 1/W, 1/H (float bits), x lo, x hi
+    const i32x4_t mB = *reinterpret_cast<const i32x4_t*>(mt + 20);  // y lo, y hi, row pitch, address constant
+    const int H = g.H[k], W = g.W[k];
+    const float Hf = (float)H, Wf = (float)W;
+    // reference point on level k: read (model dtype), or the query's pixel centre scaled by the valid ratios in fp32
+    const float rx = CREF ? bx * __int_as_float(mt[24]) : TR::to_f32(rr[i].a);
+    const float ry = CREF ? by * __int_as_float(mt[25]) : TR::to_f32(rr[i].b);
+    const float x = fmaf(TR::to_f32(ro[i].a), __int_as_float(mA[0]), rx);
+    const float y = fmaf(TR::to_f32(ro[i].b), __int_as_float(mA[1]), ry);
+    const float h_im = fmaf(y, Hf, -0.5f);
+    const float w_im = fmaf(x, Wf, -0.5f);
+    const bool gate = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;  // cu:249
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const float lh = h_im - hf, lw = w_im - wf;
+    const int h0 = gate ? (int)hf : 0, w0 = gate ? (int)wf : 0;
+    const float a = gate ? aw[k] : 0.f;
+    const float wy0 = hf >= 0.f ? (1.f - lh) * a : 0.f, wy1 = hf + 1.f < Hf ? lh * a : 0.f;   // cu:52-71
+    const float wx0 = wf >= 0.f ? 1.f - lw : 0.f, wx1 = wf + 1.f < Wf ? lw : 0.f;
+    rw01[i] = pack_h2(wy0 * wx0, wy0 * wx1);
+    rw23[i] = pack_h2(wy1 * wx0, wy1 * wx1);
+    const int tx = med3_i(w0, mA[2], mA[3]), ty = med3_i(h0, mB[0], mB[1]);
+    const bool isbad = gate && !(tx == w0 && ty == h0);
+    mw01[i] = isbad ? 0u : rw01[i];
+    mw23[i] = isbad ? 0u : rw23[i];
+    hw[i] = ((unsigned)h0 << 16) | ((unsigned)w0 & 0xffffu);
+    const int xo = tx * (int)kRow + mB[3];
+    ad0[i] = (unsigned)(max(ty, 0) * mB[2] + xo);
+    ad1[i] = (unsigned)(min(ty + 1, H - 1) * mB[2] + xo);
+    bad |= isbad ? 1u << (sub + 4 * i) : 0u;
+  }
+  bad |= dpp_u<kXor2>(bad);
+  bad |= dpp_u<kXor1>(bad);
+
+  // -- gather: 4 * NLV points, one per step; an 8-term fp16 chain per point pair --
+  {
+    constexpr int NS = 4 * NLV;
+    V rows[2][4];
+    unsigned wA[2], wB[2];
+    auto fetch = [&](int s_, int buf) {
+      const int o = s_ & 3, i = s_ >> 2;
+      const unsigned a0 = quad_bcast_add(ad0[i], o, lane_byte), a1 = quad_bcast_add(ad1[i], o, lane_byte);
+      wA[buf] = quad_bcast_u(mw01[i], o);
+      wB[buf] = quad_bcast_u(mw23[i], o);
+      rows[buf][0] = *reinterpret_cast<const V*>(patch + a0);
+      rows[buf][1] = *reinterpret_cast<const V*>(patch + a0 + kRow);
+      rows[buf][2] = *reinterpret_cast<const V*>(patch + a1);
+      rows[buf][3] = *reinterpret_cast<const V*>(patch + a1 + kRow);
+    };
+    fetch(0, 0);
+    h2 h[4];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int b = s_ & 1;
+      if (s_ + 1 < NS) fetch(s_ + 1, (s_ + 1) & 1);
+      const h2 a = as_h2(wA[b]), c = as_h2(wB[b]);
+      const h2 w4[4] = {h2{a[0], a[0]}, h2{a[1], a[1]}, h2{c[0], c[0]}, h2{c[1], c[1]}};
+#pragma unroll
+      for (int cr = 0; cr < 4; ++cr) {
+        const V r = rows[b][cr];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const h2 v = {r[2 * j], r[2 * j + 1]};
+          h[j] = ((s_ & 1) == 0 && cr == 0) ? v * w4[cr] : __builtin_elementwise_fma(v, w4[cr], h[j]);
+        }
+      }
+      if (s_ & 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_h2(acc[2 * j], acc[2 * j + 1], h[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // -- samples outside the staged windows (rare): queue passes of kQ3 records per pair, read from global memory --
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+    const int cnt = __builtin_popcount(bad);
+    for (int base = 0; __builtin_amdgcn_ballot_w64(cnt > base) != 0; base += kQ3) {
+#pragma unroll
+      for (int i = 0; i < NLV; ++i) {
+        const int pt = sub + 4 * i;
+        if ((bad >> pt) & 1u) {
+          const int pos = __builtin_popcount(bad & ((1u << pt) - 1u)) - base;
+          if ((unsigned)pos < (unsigned)kQ3) queue[pos] = u32x4{hw[i], (unsigned)(LV0 + i), rw01[i], rw23[i]};
+        }
+      }
+      for (int j = 0; j < kQ3; ++j) {
+        const bool act = base + j < cnt;
+        if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+        if (act) {
+          const u32x4 rec = queue[j];
+          const int* mt = s_meta + (int)rec[1] * kMetaInts;
+          const int H = mt[0], W = mt[1];
+          const unsigned st = (unsigned)mt[2];
+          const int h0 = (int)(short)(rec[0] >> 16), w0 = (int)(short)(rec[0] & 0xffffu);
+          const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
+          const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
+          const unsigned char* vb = vimg + lane_byte;
+          V r4[4];
+          r4[0] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h0c * W + w0c)) * pix_bytes));
+          r4[1] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h0c * W + w1c)) * pix_bytes));
+          r4[2] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h1c * W + w0c)) * pix_bytes));
+          r4[3] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h1c * W + w1c)) * pix_bytes));
+          const h2 a = as_h2(rec[2]), b = as_h2(rec[3]);
+          const float w[4] = {(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) acc[jj] = __builtin_fmaf(w[c], TR::to_f32(r4[c][jj]), acc[jj]);
+        }
+      }
+    }
+  }
+}
+
+// slot -> flattened query index, and the query's level / pixel
+__device__ __forceinline__ int slot_query3(const int* __restrict__ s_meta, int L, int slot, int& lv, int& x, int& y) {
+  lv = 0;
+  for (int l = 1; l < L; ++l) lv = slot >= s_meta[l * kMetaInts + 12] ? l : lv;
+  const int* mt = s_meta + lv * kMetaInts;
+  const int t = slot - mt[12], qw = mt[10];
+  const int yy = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)qw));
+  y = mt[9] + yy;
+  x = mt[8] + (t - yy * qw);
+  return mt[2] + y * mt[1] + x;
+}
+
+// LDS: [pad 64 B | staged rows of ONE pass | pad 64 B | fix-up queues 2 KB | geometry table]
+template <class TR, bool CREF>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_encoder_v3_kernel(
+    const typename TR::storage* __restrict__ value, const typename TR::storage* __restrict__ offs,
+    const typename TR::storage* __restrict__ logits, const typename TR::storage* __restrict__ ref,
+    typename TR::storage* __restrict__ out, const EncGeom g, const int off_stride, const int logit_stride) {
+  using S = typename TR::storage;
+  using S2 = typename Raw<TR, 5>::S2;
+  using V = typename TR::vec;
+  constexpr unsigned kRow = 64;
+  constexpr int L = 5, LP = 20;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* patch = smem + kPad;
+  u32x4* queues = reinterpret_cast<u32x4*>(smem + 2 * kPad + (size_t)g.rows_cap * kRow);
+  int* s_meta = reinterpret_cast<int*>(queues + (kThreads / 4) * kQ3);
+
+  const int tid = threadIdx.x;
+  const int M = g.M;
+  const int wave = tid >> 6, lane = tid & 63, sub = lane & 3, pl = lane >> 2;
+  const unsigned pix_bytes = (unsigned)M * kRow;
+
+  const TileId t = decode_tile(xcd_tile(blockIdx.x, gridDim.x), g);
+  region_geometry(s_meta, g, t, tid);
+  const int total = s_meta[kMaxL * kMetaInts];
+  const int n_it = total > wave * 16 ? (total - wave * 16 + 63) >> 6 : 0;   // <= kMaxIt (host-checked)
+
+  // per-image bases (uniform) + 32-bit in-image element offsets
+  const S* offs_b = offs + (size_t)t.b * g.S * off_stride + 2 * (t.m * LP + sub);
+  const S* logit_b = logits + (size_t)t.b * g.S * logit_stride + (t.m * LP + sub);
+  const S* ref_b = ref + (size_t)t.b * g.S * (L * 2);
+  const unsigned char* vimg = reinterpret_cast<const unsigned char*>(value) + (size_t)t.b * g.S * M * kRow + t.m * kRow;
+
+  int qs[kMaxIt];
+  float aw[kMaxIt][5], acc[kMaxIt][8], bx[kMaxIt], by[kMaxIt];
+#pragma unroll
+  for (int it = 0; it < kMaxIt; ++it) {
+    qs[it] = 0;
+    bx[it] = by[it] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[it][j] = 0.f;
+    if (it < n_it) {
+      const int sl = (it * 4 + wave) * 16 + pl;
+      int lv, x, y;
+      qs[it] = slot_query3(s_meta, L, sl < total ? sl : total - 1, lv, x, y);
+      if (CREF) {  // get_reference_points (reference transformer.py:280-305): centre / (valid ratio * size), fp32
+        const int* mt = s_meta + lv * kMetaInts;
+        bx[it] = ((float)x + 0.5f) / (__int_as_float(mt[24]) * (float)mt[1]);
+        by[it] = ((float)y + 0.5f) / (__int_as_float(mt[25]) * (float)mt[0]);
+      }
+    }
+  }
+  // softmax of every iteration's 20 logits (5 per lane; quad reductions): the attention weights live in registers
+  {
+    S lg[kMaxIt][5];
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) lg[it][k] = it < n_it ? logit_b[(unsigned)qs[it] * (unsigned)logit_stride + 4 * k] : S(0);
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+      float mx = TR::to_f32(lg[it][0]);
+#pragma unroll
+      for (int k = 1; k < 5; ++k) mx = fmaxf(mx, TR::to_f32(lg[it][k]));
+      mx = fmaxf(mx, dpp_f<kXor2>(mx));
+      mx = fmaxf(mx, dpp_f<kXor1>(mx));
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        aw[it][k] = __expf(TR::to_f32(lg[it][k]) - mx);
+        sum += aw[it][k];
+      }
+      sum += dpp_f<kXor2>(sum);
+      sum += dpp_f<kXor1>(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) aw[it][k] *= inv;
+    }
+  }
+
+  u32x4* queue = queues + (size_t)(wave * 16 + pl) * kQ3;
+  auto run_pass = [&](auto lv0_c, auto nlv_c) {
+    constexpr int LV0 = decltype(lv0_c)::value, NLV = decltype(nlv_c)::value;
+    // raw offsets / reference points of the pass's levels for all iterations: in flight while the rows are staged
+    S2 ro[kMaxIt][NLV], rr[kMaxIt][NLV];
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it)
+#pragma unroll
+      for (int i = 0; i < NLV; ++i) {
+        ro[it][i] = S2{S(0), S(0)};
+        rr[it][i] = S2{S(0), S(0)};
+        if (it < n_it) {
+          ro[it][i] = *reinterpret_cast<const S2*>(offs_b + (unsigned)qs[it] * (unsigned)off_stride + 8 * (LV0 + i));
+          if (!CREF) rr[it][i] = *reinterpret_cast<const S2*>(ref_b + (unsigned)qs[it] * (unsigned)(L * 2) + 2 * (LV0 + i));
+        }
+      }
+    if (LV0 > 0) __syncthreads();   // every wave is done reading the previous pass's rows
+#pragma unroll
+    for (int i = 0; i < NLV; ++i) {
+      const int* mt = s_meta + (LV0 + i) * kMetaInts;
+      const int W = mt[1], pw = mt[5];
+      const int n = pw * mt[6] * 4;  // 16-byte pieces
+      const float inv = __builtin_amdgcn_rcpf((float)pw);
+      const unsigned src0 = (unsigned)(mt[2] + mt[4] * W + mt[3]) * pix_bytes + (unsigned)(lane & 3) * 16;
+      unsigned char* dst0 = patch + (size_t)mt[7] * kRow;
+      for (int e0 = wave * 64; e0 < n; e0 += kThreads) {
+        const int row = (e0 + lane) >> 2;
+        if (e0 + lane < n) {
+          const int y = (int)(((float)row + 0.5f) * inv);
+          const unsigned char* gp = vimg + (src0 + (unsigned)(y * (W - pw) + row) * pix_bytes);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                           (__attribute__((address_space(3))) void*)(dst0 + (size_t)e0 * 16), 16, 0, 0);
+        }
+      }
+    }
+    if (tid < 8) {   // the slots in front of / behind the staged rows are read with zero weight: finite values
+      const int* mt = s_meta + (LV0 + NLV - 1) * kMetaInts;
+      const unsigned end = (unsigned)(mt[7] + mt[5] * mt[6]) * kRow;
+      *reinterpret_cast<u32x4*>(tid < 4 ? smem + tid * 16 : patch + end + (tid - 4) * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it)
+      if (it < n_it)
+        pass_v3<TR, LV0, NLV, CREF>(acc[it], aw[it], ro[it], rr[it], bx[it], by[it], s_meta, patch, queue, vimg, pix_bytes, g, sub);
+  };
+  run_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  run_pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+  run_pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+
+  const size_t out_row = ((size_t)t.b * g.S) * M + t.m;
+#pragma unroll
+  for (int it = 0; it < kMaxIt; ++it)
+    if (it < n_it && (it * 4 + wave) * 16 + pl < total) {
+      V packed;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) packed[j] = TR::from_f32(acc[it][j]);
+      *reinterpret_cast<V*>(reinterpret_cast<unsigned char*>(out) + (out_row + (size_t)qs[it] * M) * kRow + sub * 16) = packed;
+    }
+}
+
+// LDS bytes the kernels need for these windows (0: not representable), and the geometry for the launch
+struct EncPlan {
+  EncGeom g;
+  size_t lds_v1, lds_v2, lds_v3;   // bytes per workgroup of the generic / packed single-pass / three-pass kernels
+  int rows_cap3;                    // v3: the largest pass
+  int rc;
+};
+constexpr int kPassFirst5[5] = {0, 1, 1, 3, 3};   // v3 (5 levels): passes {0}, {1, 2}, {3, 4}
+
+inline EncPlan plan_encoder(const int64_t* shapes, int64_t S, int M, int L, int P, const signed char* win /* [M][L][4] */) {
+  EncPlan pl{};
+  EncGeom& g = pl.g;
+  pl.rc = CODETR_E_BADARG;
+  if (!shapes || !win || M <= 0 || L <= 0 || P <= 0) return pl;
+  pl.rc = CODETR_E_UNSUPPORTED;
+  if (L > kMaxL || L * P > 32) return pl;
   g.L = L;
   g.P = P;
   g.M = M;
-  g.halo = halo;
   g.S = (int)S;
   int64_t sum = 0;
   for (int l = 0; l < L; ++l) {
     const int64_t h = shapes[2 * l], w = shapes[2 * l + 1];
-    if (h <= 0 || w <= 0 || h > 32767 || w > 32767) return CODETR_E_BADARG;  // (h0, w0) travel as 16-bit halves
+    if (h <= 0 || w <= 0 || h > 32767 || w > 32767) return pl.rc = CODETR_E_BADARG, pl;  // (h0, w0) travel as 16-bit halves
     g.H[l] = (int)h;
     g.W[l] = (int)w;
     g.start[l] = (int)sum;
@@ -609,8 +1301,18 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
     g.invW[l] = 1.0f / (float)w;
     sum += h * w;
   }
-  if (sum != S) return CODETR_E_BADARG;
-  if (S * M * (int64_t)(D * sizeof(ST)) > 0xffffffffLL) return CODETR_E_TOO_LARGE;  // 32-bit in-image offsets
+  if (sum != S) return pl.rc = CODETR_E_BADARG, pl;
+  int wmax = 0;
+  for (int m = 0; m < M; ++m)
+    for (int l = 0; l < L; ++l) {
+      const signed char* wn = win + ((size_t)m * L + l) * 4;
+      if (wn[0] > wn[1] || wn[2] > wn[3]) return pl.rc = CODETR_E_BADARG, pl;
+      for (int c = 0; c < 4; ++c) {
+        g.win[m < kMaxM ? m : kMaxM - 1][l][c] = wn[c];
+        wmax = abs(wn[c]) > wmax ? abs(wn[c]) : wmax;
+      }
+      if (m >= kMaxM && memcmp(wn, win + ((size_t)(kMaxM - 1) * L + l) * 4, 4) != 0) return pl;  // heads beyond kMaxM share one window
+    }
   // regions follow the finest level
   int fine = 0;
   for (int l = 1; l < L; ++l)
@@ -619,33 +1321,68 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
   g.RY = (g.H[fine] + kRegH - 1) / kRegH;
   // the kernel's reciprocal-based floor division is exact below 2^22
   for (int l = 0; l < L; ++l) {
-    const int64_t nx = 2 * (int64_t)(g.RX + 1) * g.W[l] + (2 * (int64_t)halo + 3) * g.RX;
-    const int64_t ny = 2 * (int64_t)(g.RY + 1) * g.H[l] + (2 * (int64_t)halo + 3) * g.RY;
-    if (nx >= (1 << 22) || ny >= (1 << 22)) return CODETR_E_UNSUPPORTED;
+    const int64_t nx = 2 * (int64_t)(g.RX + 1) * g.W[l] + (2 * (int64_t)wmax + 3) * g.RX;
+    const int64_t ny = 2 * (int64_t)(g.RY + 1) * g.H[l] + (2 * (int64_t)wmax + 3) * g.RY;
+    if (nx >= (1 << 22) || ny >= (1 << 22)) return pl;
   }
-  // LDS capacity: the largest neighbourhood / query count any region has, per level
-  int rows = 0, slots = 0;
-  for (int l = 0; l < L; ++l) {
-    int pw = 0, ph = 0, qw = 0, qh = 0;
-    for (int r = 0; r < g.RX; ++r) {
-      const int w = patch_hi(r, g.W[l], g.RX, halo) - patch_lo(r, g.W[l], g.RX, halo) + 1;
-      const int q = q_bound(r + 1, g.W[l], g.RX) - q_bound(r, g.W[l], g.RX);
-      pw = w > pw ? w : pw;
-      qw = q > qw ? q : qw;
+  // LDS capacity: the largest neighbourhood / query count any (region, head) has, per level
+  int rows_cap = 0, rows_cap3 = 0, slots = 0;
+  for (int m = 0; m < (M < kMaxM ? M : kMaxM); ++m) {
+    int rows = 0, rows_pass = 0;
+    slots = 0;
+    for (int l = 0; l < L; ++l) {
+      const signed char* wn = g.win[m][l];
+      int pw = 0, ph = 0, qw = 0, qh = 0;
+      for (int r = 0; r < g.RX; ++r) {
+        const int lo = patch_lo(r, g.W[l], g.RX, wn[0]), hi = patch_hi(r, g.W[l], g.RX, wn[1]);
+        const int w = (hi > lo ? hi : lo) - lo + 1;
+        const int q = q_bound(r + 1, g.W[l], g.RX) - q_bound(r, g.W[l], g.RX);
+        pw = w > pw ? w : pw;
+        qw = q > qw ? q : qw;
+      }
+      for (int r = 0; r < g.RY; ++r) {
+        const int lo = patch_lo(r, g.H[l], g.RY, wn[2]), hi = patch_hi(r, g.H[l], g.RY, wn[3]);
+        const int h = (hi > lo ? hi : lo) - lo + 1;
+        const int q = q_bound(r + 1, g.H[l], g.RY) - q_bound(r, g.H[l], g.RY);
+        ph = h > ph ? h : ph;
+        qh = q > qh ? q : qh;
+      }
+      rows += pw * ph;
+      slots += qw * qh;
+      if (L == 5) {
+        rows_pass = (kPassFirst5[l] == l ? 0 : rows_pass) + pw * ph;
+        rows_cap3 = rows_pass > rows_cap3 ? rows_pass : rows_cap3;
+      }
     }
-    for (int r = 0; r < g.RY; ++r) {
-      const int h = patch_hi(r, g.H[l], g.RY, halo) - patch_lo(r, g.H[l], g.RY, halo) + 1;
-      const int q = q_bound(r + 1, g.H[l], g.RY) - q_bound(r, g.H[l], g.RY);
-      ph = h > ph ? h : ph;
-      qh = q > qh ? q : qh;
-    }
-    rows += pw * ph;
-    slots += qw * qh;
+    rows_cap = rows > rows_cap ? rows : rows_cap;
   }
-  g.rows_cap = rows;
+  g.rows_cap = rows_cap;
   g.slots_cap = slots;
-  const size_t lds = (size_t)rows * D * sizeof(ST) + kMetaStride * sizeof(int);
-  if (lds > (size_t)kMaxLds) return CODETR_E_UNSUPPORTED;
+  pl.rows_cap3 = rows_cap3;
+  pl.lds_v1 = 2 * kPad + (size_t)rows_cap * 64 + kMetaStride * sizeof(int);
+  pl.lds_v2 = pl.lds_v1 + (size_t)(kThreads / 4) * kQueue * 16;
+  pl.lds_v3 = 2 * kPad + (size_t)rows_cap3 * 64 + kMetaStride * sizeof(int) + (size_t)(kThreads / 4) * kQ3 * 16;
+  pl.rc = 0;
+  return pl;
+}
+
+template <class TR>
+int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, const void* offs, int64_t off_stride,
+                   const void* logits, int64_t logit_stride, const void* ref, const float* vcounts, int64_t B, int64_t S,
+                   int M, int D, int L, int P, const signed char* win, int passes, void* out) {
+  using ST = typename TR::storage;
+  if (!value || !shapes || !offs || !logits || !out || !win || (!ref && !(vcounts && passes == 3))) return CODETR_E_BADARG;
+  if (passes != 1 && passes != 3) return CODETR_E_BADARG;
+  if (B <= 0 || S <= 0 || M <= 0 || L <= 0 || P <= 0) return CODETR_E_BADARG;
+  if (D != 32) return CODETR_E_UNSUPPORTED;
+  if (off_stride < (int64_t)M * L * P * 2 || logit_stride < (int64_t)M * L * P || off_stride > 0x7fffffff ||
+      logit_stride > 0x7fffffff || (off_stride & 1) || (reinterpret_cast<uintptr_t>(offs) & 3) ||
+      (reinterpret_cast<uintptr_t>(ref) & 3))
+    return CODETR_E_BADARG;
+  EncPlan pl = plan_encoder(shapes, S, M, L, P, win);
+  if (pl.rc != 0) return pl.rc;
+  EncGeom& g = pl.g;
+  if (S * M * (int64_t)(D * sizeof(ST)) > 0xffffffffLL) return CODETR_E_TOO_LARGE;  // 32-bit in-image offsets
   const int64_t blocks = B * g.RX * g.RY * M;
   if (blocks >= (1 << 22)) return CODETR_E_UNSUPPORTED;  // (the kernel's cheap tile decode)
 #ifdef MSDA_ENC_ABLATE
@@ -657,30 +1394,114 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
 #endif
   static const int band_env = [] { const char* e = getenv("CODETR_MSDA_BAND"); return e ? atoi(e) : kBand; }();
   static const bool static_env = [] { const char* e = getenv("CODETR_MSDA_STATIC"); return e ? atoi(e) != 0 : true; }();
+  static const bool v2_env = [] { const char* e = getenv("CODETR_MSDA_V2"); return e ? atoi(e) != 0 : true; }();
   g.band = band_env < 1 ? 1 : (band_env > 64 ? 64 : band_env);
+  if (passes == 3) {   // three-pass kernel: fp16, 5 levels x 4 points, regions of <= 64 * kMaxIt queries
+    if (!std::is_same<TR, F16>::value || P != 4 || L != 5 || g.slots_cap > 64 * kMaxIt || pl.lds_v3 > (size_t)kMaxLds ||
+        S * (off_stride > logit_stride ? off_stride : logit_stride) > 0x7fffffffLL)
+      return CODETR_E_UNSUPPORTED;
+    for (int l = 0; l < L; ++l) g.first[l] = kPassFirst5[l];
+    g.rows_cap = pl.rows_cap3;
+    g.vcounts = vcounts;
+    auto k3 = vcounts ? msda_encoder_v3_kernel<F16, true> : msda_encoder_v3_kernel<F16, false>;
+    static std::atomic<uint32_t> done3[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done3[0].store(0);
+    const uint32_t bit = vcounts ? 2u : 1u;
+    if (!(done3[dev].load(std::memory_order_acquire) & bit)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+      if (e != hipSuccess) return (int)e;
+      done3[dev].fetch_or(bit, std::memory_order_release);
+    }
+    // diagnostic (occupancy experiments): a floor on the LDS request limits the workgroups per CU; results unchanged
+    static const size_t lds_floor = [] { const char* e = getenv("CODETR_MSDA_LDS_FLOOR"); return e ? (size_t)atol(e) : (size_t)0; }();
+    const size_t lds3 = pl.lds_v3 > lds_floor ? pl.lds_v3 : (lds_floor > (size_t)kMaxLds ? (size_t)kMaxLds : lds_floor);
+    hipLaunchKernelGGL(k3, dim3((unsigned)blocks), dim3(kThreads), lds3, st, static_cast<const _Float16*>(value),
+                       static_cast<const _Float16*>(offs), static_cast<const _Float16*>(logits),
+                       static_cast<const _Float16*>(ref), static_cast<_Float16*>(out), g, (int)off_stride, (int)logit_stride);
+    const hipError_t err3 = hipGetLastError();
+    return err3 == hipSuccess ? 0 : (int)err3;
+  }
+  const bool v2 = std::is_same<TR, F16>::value && P == 4 && L == 5 && v2_env;
+  const size_t lds = v2 ? pl.lds_v2 : pl.lds_v1;
+  if (lds > (size_t)kMaxLds) return CODETR_E_UNSUPPORTED;
   const int kmax5 = L * P <= 20;
   auto kern = P == 4 ? (kmax5 ? (L == 5 && static_env ? msda_encoder_kernel<TR, 5, true, true> : msda_encoder_kernel<TR, 5, true>)
                               : msda_encoder_kernel<TR, 8, true>)
                      : (kmax5 ? msda_encoder_kernel<TR, 5, false> : msda_encoder_kernel<TR, 8, false>);
+  static const int v2_cfg = [] { const char* e = getenv("CODETR_MSDA_V2_CFG"); return e ? atoi(e) : 0; }();
+  typedef void (*V2Fn)(const _Float16*, const _Float16*, const _Float16*, const _Float16*, _Float16*, const EncGeom, const int, const int);
+  V2Fn v2fn = msda_encoder_v2_kernel<F16>;
+  switch (v2_cfg) {
+    case 1: v2fn = msda_encoder_v2_kernel<F16, 2, kPre, true>; break;
+    case 2: v2fn = msda_encoder_v2_kernel<F16, 1, 0, true>; break;
+    case 3: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, false>; break;
+    case 4: v2fn = msda_encoder_v2_kernel<F16, 2, 0, true>; break;
+    case 5: v2fn = msda_encoder_v2_kernel<F16, 2, 1, true>; break;
+    case 6: v2fn = msda_encoder_v2_occ3_kernel<F16, 1, 0>; break;
+    case 7: v2fn = msda_encoder_v2_occ3_kernel<F16, 1, 1>; break;
+#ifdef MSDA_ENC_ABLATE   // timing experiments only: WRONG results
+    case 101: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 1>; break;
+    case 102: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 2>; break;
+    case 103: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 3>; break;
+    case 104: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 4>; break;
+    case 108: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 8>; break;
+    case 107: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 7>; break;
+    case 115: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 15>; break;
+#endif
+    default: break;
+  }
+  const void* kfn = v2 ? reinterpret_cast<const void*>(v2fn) : reinterpret_cast<const void*>(kern);
   // > 64 KB of dynamic LDS needs the attribute on the CURRENT device's function object: remembered per (device, kernel)
   // -- a process-wide "already set" flag would skip it when the process moves to a second GPU
   {
     static std::atomic<uint32_t> done[64];  // bit = kernel instantiation, index = device ordinal
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done[0].store(0);
-    const uint32_t bit = 1u << (kmax5 + 2 * (P == 4) + 4 * (P == 4 && L == 5 && static_env) + 8 * std::is_same<TR, BF16>::value);
+    const uint32_t bit = v2 ? 1u << (16 + v2_cfg % 8)
+                            : 1u << (kmax5 + 2 * (P == 4) + 4 * (P == 4 && L == 5 && static_env) + 8 * std::is_same<TR, BF16>::value);
     if (!(done[dev].load(std::memory_order_acquire) & bit)) {
-      const hipError_t e =
-          hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+      const hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
       if (e != hipSuccess) return (int)e;
       done[dev].fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, st, static_cast<const ST*>(value),
-                     static_cast<const ST*>(offs), static_cast<const ST*>(logits), static_cast<const ST*>(ref),
-                     static_cast<ST*>(out), g, (int)off_stride, (int)logit_stride, ablate);
+  if (v2)
+    hipLaunchKernelGGL(v2fn, dim3((unsigned)blocks), dim3(kThreads), lds, st,
+                       static_cast<const _Float16*>(value), static_cast<const _Float16*>(offs),
+                       static_cast<const _Float16*>(logits), static_cast<const _Float16*>(ref),
+                       static_cast<_Float16*>(out), g, (int)off_stride, (int)logit_stride);
+  else
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, st, static_cast<const ST*>(value),
+                       static_cast<const ST*>(offs), static_cast<const ST*>(logits), static_cast<const ST*>(ref),
+                       static_cast<ST*>(out), g, (int)off_stride, (int)logit_stride, ablate);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+// symmetric windows of the `halo` entry points
+struct HaloWin {
+  signed char w[kMaxM > 64 ? kMaxM : 64][kMaxL][4];
+};
+inline int halo_windows(int M, int L, int halo, signed char* buf /* [M][L][4] */) {
+  if (halo < 0 || halo > 127) return CODETR_E_BADARG;
+  for (int i = 0; i < M * L; ++i) {
+    buf[4 * i + 0] = buf[4 * i + 2] = (signed char)-halo;
+    buf[4 * i + 1] = buf[4 * i + 3] = (signed char)halo;
+  }
+  return 0;
+}
+
+template <class TR>
+int launch_encoder_halo(void* stream, const void* value, const int64_t* shapes, const void* offs, int64_t off_stride,
+                        const void* logits, int64_t logit_stride, const void* ref, int64_t B, int64_t S, int M, int D,
+                        int L, int P, int halo, void* out) {
+  if (M <= 0 || L <= 0 || M > 64 || L > kMaxL) return M <= 0 || L <= 0 ? CODETR_E_BADARG : CODETR_E_UNSUPPORTED;
+  signed char win[64 * kMaxL * 4];
+  const int rc = halo_windows(M, L, halo, win);
+  if (rc != 0) return rc;
+  return launch_encoder<TR>(static_cast<hipStream_t>(stream), value, shapes, offs, off_stride, logits, logit_stride,
+                            ref, nullptr, B, S, M, D, L, P, win, 1, out);
 }
 
 }  // namespace
@@ -691,18 +1512,47 @@ int codetr_msda_encoder_forward_f16(void* stream, const void* value_dev, const i
                                     const void* offsets_dev, int64_t offsets_row_stride, const void* logits_dev,
                                     int64_t logits_row_stride, const void* ref_dev, int64_t B, int64_t S, int M, int D,
                                     int L, int P, int halo, void* out_dev) {
-  return launch_encoder<F16>(static_cast<hipStream_t>(stream), value_dev, level_shapes_host, offsets_dev,
-                             offsets_row_stride, logits_dev, logits_row_stride, ref_dev, B, S, M, D, L, P, halo,
-                             out_dev);
+  return launch_encoder_halo<F16>(stream, value_dev, level_shapes_host, offsets_dev, offsets_row_stride, logits_dev,
+                                  logits_row_stride, ref_dev, B, S, M, D, L, P, halo, out_dev);
 }
 
 int codetr_msda_encoder_forward_bf16(void* stream, const void* value_dev, const int64_t* level_shapes_host,
                                      const void* offsets_dev, int64_t offsets_row_stride, const void* logits_dev,
                                      int64_t logits_row_stride, const void* ref_dev, int64_t B, int64_t S, int M,
                                      int D, int L, int P, int halo, void* out_dev) {
+  return launch_encoder_halo<BF16>(stream, value_dev, level_shapes_host, offsets_dev, offsets_row_stride, logits_dev,
+                                   logits_row_stride, ref_dev, B, S, M, D, L, P, halo, out_dev);
+}
+
+int codetr_msda_encoder_forward_win_f16(void* stream, const void* value_dev, const int64_t* level_shapes_host,
+                                        const void* offsets_dev, int64_t offsets_row_stride, const void* logits_dev,
+                                        int64_t logits_row_stride, const void* ref_dev, const float* valid_counts_dev,
+                                        int64_t B, int64_t S, int M, int D, int L, int P, const int8_t* windows_host,
+                                        int passes, void* out_dev) {
+  return launch_encoder<F16>(static_cast<hipStream_t>(stream), value_dev, level_shapes_host, offsets_dev,
+                             offsets_row_stride, logits_dev, logits_row_stride, ref_dev, valid_counts_dev, B, S, M, D, L,
+                             P, reinterpret_cast<const signed char*>(windows_host), passes, out_dev);
+}
+
+int codetr_msda_encoder_forward_win_bf16(void* stream, const void* value_dev, const int64_t* level_shapes_host,
+                                         const void* offsets_dev, int64_t offsets_row_stride, const void* logits_dev,
+                                         int64_t logits_row_stride, const void* ref_dev, const float* valid_counts_dev,
+                                         int64_t B, int64_t S, int M, int D, int L, int P, const int8_t* windows_host,
+                                         int passes, void* out_dev) {
   return launch_encoder<BF16>(static_cast<hipStream_t>(stream), value_dev, level_shapes_host, offsets_dev,
-                              offsets_row_stride, logits_dev, logits_row_stride, ref_dev, B, S, M, D, L, P, halo,
-                              out_dev);
+                              offsets_row_stride, logits_dev, logits_row_stride, ref_dev, valid_counts_dev, B, S, M, D, L,
+                              P, reinterpret_cast<const signed char*>(windows_host), passes, out_dev);
+}
+
+int64_t codetr_msda_encoder_lds_bytes(const int64_t* level_shapes_host, int M, int L, int P, const int8_t* windows_host,
+                                      int variant) {
+  int64_t S = 0;
+  if (!level_shapes_host || L <= 0 || L > kMaxL) return CODETR_E_BADARG;
+  for (int l = 0; l < L; ++l) S += level_shapes_host[2 * l] * level_shapes_host[2 * l + 1];
+  const EncPlan pl = plan_encoder(level_shapes_host, S, M, L, P, reinterpret_cast<const signed char*>(windows_host));
+  if (pl.rc != 0) return pl.rc;
+  if (variant == 3) return L == 5 && P == 4 && pl.g.slots_cap <= 64 * kMaxIt ? (int64_t)pl.lds_v3 : (int64_t)CODETR_E_UNSUPPORTED;
+  return (int64_t)(variant == 2 && P == 4 && L == 5 ? pl.lds_v2 : pl.lds_v1);
 }
 
 }  // extern "C"

@@ -110,10 +110,12 @@ struct __attribute__((aligned(16))) Entry {
 // `loc` then points at the offsets and `weight` at the logits; both are addressed as rows of one
 // (possibly wider, fused-projection) matrix with the strides below.
 struct FusedArgs {
-  const void* ref;      // [B*Nq, L, ref_dim]
+  const void* ref;      // [B*Nq, L, ref_dim]: the tensors' 16-bit type, or fp32 (ref_f32)
   int ref_dim;          // 2 or 4
   int off_stride;       // elements between consecutive (b, q) rows of the offsets matrix
   int logit_stride;     // same for the logits matrix
+  int ref_f32;          // reference points are fp32 (a coordinate in [0.5, 1) resolves to 1/2048 in fp16: a quarter
+                        // pixel on a 480-wide level)
 };
 
 constexpr int kMaxLevels = 16;  // level table kept in LDS
@@ -152,17 +154,29 @@ __device__ __forceinline__ void build_entries(Entry* __restrict__ entries, int P
       if (FUSED) {
         const int col = (int)m * LP + pt;
         const S2 o2 = *reinterpret_cast<const S2*>(loc + (size_t)row * fa.off_stride + 2 * col);
-        const S* rp = static_cast<const S*>(fa.ref) + ((size_t)row * L + l) * fa.ref_dim;
-        const S2 r2 = *reinterpret_cast<const S2*>(rp);
         px[k] = TR::to_f32(o2.a);
         py[k] = TR::to_f32(o2.b);
-        rw[k] = TR::to_f32(r2.a);
-        rh[k] = TR::to_f32(r2.b);
         pw[k] = TR::to_f32(weight[(size_t)row * fa.logit_stride + col]);
-        if (fa.ref_dim == 4) {  // fold (w, h) into the offsets now: off / P * wh * 0.5
-          const S2 wh = *reinterpret_cast<const S2*>(rp + 2);
-          px[k] *= TR::to_f32(wh.a) * (0.5f / (float)P);
-          py[k] *= TR::to_f32(wh.b) * (0.5f / (float)P);
+        if (fa.ref_f32) {
+          const float* rp = static_cast<const float*>(fa.ref) + ((size_t)row * L + l) * fa.ref_dim;
+          const float2 r2 = *reinterpret_cast<const float2*>(rp);
+          rw[k] = r2.x;
+          rh[k] = r2.y;
+          if (fa.ref_dim == 4) {
+            const float2 wh = *reinterpret_cast<const float2*>(rp + 2);
+            px[k] *= wh.x * (0.5f / (float)P);
+            py[k] *= wh.y * (0.5f / (float)P);
+          }
+        } else {
+          const S* rp = static_cast<const S*>(fa.ref) + ((size_t)row * L + l) * fa.ref_dim;
+          const S2 r2 = *reinterpret_cast<const S2*>(rp);
+          rw[k] = TR::to_f32(r2.a);
+          rh[k] = TR::to_f32(r2.b);
+          if (fa.ref_dim == 4) {  // fold (w, h) into the offsets now: off / P * wh * 0.5
+            const S2 wh = *reinterpret_cast<const S2*>(rp + 2);
+            px[k] *= TR::to_f32(wh.a) * (0.5f / (float)P);
+            py[k] *= TR::to_f32(wh.b) * (0.5f / (float)P);
+          }
         }
       } else {
         const size_t e = (size_t)g * LP + pt;
@@ -468,7 +482,8 @@ int launch_headmajor(hipStream_t st, const void* value, const int64_t* ss, const
     const unsigned n_pairs = (unsigned)(nb * pairs_per_image);
     const unsigned grid = (n_pairs + PAIRS - 1) / PAIRS;
     FusedArgs fb = fa;
-    fb.ref = static_cast<const ST*>(fa.ref) + b0 * Nq * L * fa.ref_dim;
+    fb.ref = fa.ref_f32 ? static_cast<const void*>(static_cast<const float*>(fa.ref) + b0 * Nq * L * fa.ref_dim)
+                        : static_cast<const void*>(static_cast<const ST*>(fa.ref) + b0 * Nq * L * fa.ref_dim);
     hipLaunchKernelGGL((msda_fused_headmajor_kernel<TR, LANES>), dim3(grid), dim3(kThreads), lds, st,
                        static_cast<const ST*>(value) + b0 * image_elems, ss, ls,
                        static_cast<const ST*>(off) + b0 * Nq * (int64_t)fa.off_stride,
@@ -583,7 +598,9 @@ int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int
     const unsigned n_pairs = (unsigned)(nb * pairs_per_image);
     const unsigned grid = (n_pairs + PAIRS - 1) / PAIRS;
     FusedArgs fb = fa;
-    if (FUSED) fb.ref = static_cast<const ST*>(fa.ref) + b0 * Nq * L * fa.ref_dim;
+    if (FUSED)
+      fb.ref = fa.ref_f32 ? static_cast<const void*>(static_cast<const float*>(fa.ref) + b0 * Nq * L * fa.ref_dim)
+                          : static_cast<const void*>(static_cast<const ST*>(fa.ref) + b0 * Nq * L * fa.ref_dim);
     hipLaunchKernelGGL((msda_tiled_kernel<TR, LANES, FUSED>), dim3(grid), dim3(kThreads), lds, st,
                        static_cast<const ST*>(value) + b0 * image_elems, ss, ls,
                        static_cast<const ST*>(loc) + b0 * loc_per_image, static_cast<const ST*>(w) + b0 * w_per_image,
@@ -686,7 +703,7 @@ CODETR_MSDA_ENTRY(codetr_msda_forward_f16, F16, _Float16, float, CvF16, 2)
 CODETR_MSDA_ENTRY(codetr_msda_forward_bf16, BF16, unsigned short, float, CvBF16, 2)
 CODETR_MSDA_ENTRY(codetr_msda_forward_f32, F32, float, float, CvF32, 4)
 
-#define CODETR_MSDA_FUSED_ENTRY(NAME, TR)                                                                        \
+#define CODETR_MSDA_FUSED_ENTRY(NAME, TR, REF32)                                                                 \
   int NAME(void* stream, const void* value_dev, const int64_t* spatial_shapes_dev, const int64_t* level_start_dev, \
            const void* offsets_dev, int64_t offsets_row_stride, const void* logits_dev, int64_t logits_row_stride, \
            const void* ref_dev, int ref_dim, int value_head_major, int64_t B, int64_t S, int M, int D, int L,    \
@@ -701,9 +718,9 @@ CODETR_MSDA_ENTRY(codetr_msda_forward_f32, F32, float, float, CvF32, 4)
     const int lanes = tiled_lanes(2, D, L, P);                                                                   \
     if (!lanes || L * P > 8 * lanes) return CODETR_E_UNSUPPORTED;                                                \
     if ((offsets_row_stride & 1) || (reinterpret_cast<uintptr_t>(offsets_dev) & 3) ||                            \
-        (reinterpret_cast<uintptr_t>(ref_dev) & 3))                                                              \
-      return CODETR_E_BADARG; /* (x, y) pairs are read with 32-bit loads */                                      \
-    const FusedArgs fa{ref_dev, ref_dim, (int)offsets_row_stride, (int)logits_row_stride};                       \
+        (reinterpret_cast<uintptr_t>(ref_dev) & (REF32 ? 7 : 3)))                                                \
+      return CODETR_E_BADARG; /* (x, y) pairs are read with 32-bit (fp32: 64-bit) loads */                       \
+    const FusedArgs fa{ref_dev, ref_dim, (int)offsets_row_stride, (int)logits_row_stride, REF32};                \
     if (value_head_major) {                                                                                      \
       hipStream_t hst = static_cast<hipStream_t>(stream);                                                        \
       if (lanes == 4)                                                                                            \
@@ -718,8 +735,10 @@ CODETR_MSDA_ENTRY(codetr_msda_forward_f32, F32, float, float, CvF32, 4)
                               level_start_dev, offsets_dev, logits_dev, out_dev, B, S, M, L, Nq, P, fa);         \
   }
 
-CODETR_MSDA_FUSED_ENTRY(codetr_msda_fused_forward_f16, F16)
-CODETR_MSDA_FUSED_ENTRY(codetr_msda_fused_forward_bf16, BF16)
+CODETR_MSDA_FUSED_ENTRY(codetr_msda_fused_forward_f16, F16, 0)
+CODETR_MSDA_FUSED_ENTRY(codetr_msda_fused_forward_bf16, BF16, 0)
+CODETR_MSDA_FUSED_ENTRY(codetr_msda_fused_forward_ref32_f16, F16, 1)
+CODETR_MSDA_FUSED_ENTRY(codetr_msda_fused_forward_ref32_bf16, BF16, 1)
 
 int codetr_msda_forward_f64(void* stream, const void* value_dev, const int64_t* spatial_shapes_dev,
                             const int64_t* level_start_dev, const void* loc_dev, const void* weight_dev, int64_t B,

@@ -10,6 +10,10 @@
 //   embed[b, q, j*F + i] = sin | cos (ref_in[b, q, 0, order[j]] * 2 pi / T^(2 (i/2) / F)),  i even -> sin, odd -> cos
 //                          order = (y, x, w, h) = coordinate (1, 0, 2, 3)                       [B, Nq, ref_dim*F]
 // The trigonometry runs in fp32 on the fp16-rounded ref_in (the values the reference feeds it); one lane = 8 channels.
+// With fp32 valid ratios and an fp32 output given (ref_in32), the layer's MSDA reference points are ALSO written
+// unrounded -- sigmoid and the scaling in fp32 -- and the embedding is taken from those: a coordinate in [0.5, 1)
+// resolves to 1/2048 in fp16, a quarter pixel on a 480-wide level, which is what separates an fp16 model's decoder from
+// the fp32 reference at 1920x1280.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,7 +25,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void query_sine_embed_kernel(const _Float16* __restrict__ ref,
                                                                const _Float16* __restrict__ valid_ratios,
-                                                               _Float16* __restrict__ ref_in, _Float16* __restrict__ embed,
+                                                               const float* __restrict__ valid_ratios32,
+                                                               _Float16* __restrict__ ref_in, float* __restrict__ ref_in32,
+                                                               _Float16* __restrict__ embed,
                                                                int64_t rows, int Nq, int ref_dim, int L, int F,
                                                                float log2_temperature, int apply_sigmoid) {
   const int chunks = ref_dim * F / 8;
@@ -30,20 +36,25 @@ __global__ __launch_bounds__(256) void query_sine_embed_kernel(const _Float16* _
   const int c = (int)(i % chunks);
   const int64_t row = i / chunks;  // b*Nq + q
   const int b = (int)(row / Nq);
-  float s[4];
+  float s[4], s32[4];
   for (int k = 0; k < ref_dim; ++k) {
     float v = (float)ref[row * ref_dim + k];
+    s32[k] = apply_sigmoid ? 1.0f / (1.0f + expf(-v)) : v;
     if (apply_sigmoid) v = (float)(_Float16)(1.0f / (1.0f + __expf(-v)));
     s[k] = v;
   }
   const _Float16* vr = valid_ratios + (size_t)b * L * 2;
+  const float* vr32 = valid_ratios32 ? valid_ratios32 + (size_t)b * L * 2 : nullptr;
   // level rows of ref_in: lanes c = 0..L-1 of this query write one level each
   if (c < L)
-    for (int k = 0; k < ref_dim; ++k)
+    for (int k = 0; k < ref_dim; ++k) {
       ref_in[(row * L + c) * ref_dim + k] = (_Float16)(s[k] * (float)vr[c * 2 + (k & 1)]);
+      if (ref_in32) ref_in32[(row * L + c) * ref_dim + k] = s32[k] * vr32[c * 2 + (k & 1)];
+    }
   const int j = (c * 8) / F;                          // coordinate block of this chunk
   const int coord = j == 0 ? 1 : (j == 1 ? 0 : j);    // (y, x, w, h)
-  const float v0 = (float)(_Float16)(s[coord] * (float)vr[coord & 1]);  // ref_in[b, q, 0, coord]
+  const float v0 = ref_in32 ? s32[coord] * vr32[coord & 1]
+                            : (float)(_Float16)(s[coord] * (float)vr[coord & 1]);  // ref_in[b, q, 0, coord]
   const float e = v0 * 6.283185307179586f;
   const int ch0 = c * 8 - j * F;
   f16x8 o;
@@ -61,11 +72,12 @@ __global__ __launch_bounds__(256) void query_sine_embed_kernel(const _Float16* _
 
 extern "C" {
 
-int codetr_query_sine_embed_f16(void* stream, const void* ref_dev, const void* valid_ratios_dev, int64_t B, int64_t Nq,
-                                int ref_dim, int num_levels, int pos_feat, float temperature, int apply_sigmoid,
-                                void* ref_in_dev, void* embed_dev) {
+int codetr_query_sine_embed_f16(void* stream, const void* ref_dev, const void* valid_ratios_dev,
+                                const float* valid_ratios32_dev, int64_t B, int64_t Nq, int ref_dim, int num_levels,
+                                int pos_feat, float temperature, int apply_sigmoid, void* ref_in_dev, float* ref_in32_dev,
+                                void* embed_dev) {
   if (!ref_dev || !valid_ratios_dev || !ref_in_dev || !embed_dev || B <= 0 || Nq <= 0 || num_levels <= 0 ||
-      temperature <= 0.f)
+      temperature <= 0.f || (ref_in32_dev && !valid_ratios32_dev))
     return CODETR_E_BADARG;
   if ((ref_dim != 2 && ref_dim != 4) || pos_feat <= 0 || pos_feat % 8 != 0 || num_levels > ref_dim * pos_feat / 8)
     return CODETR_E_UNSUPPORTED;
@@ -73,8 +85,8 @@ int codetr_query_sine_embed_f16(void* stream, const void* ref_dev, const void* v
   const int64_t threads = B * Nq * (ref_dim * pos_feat / 8);
   hipLaunchKernelGGL(query_sine_embed_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const _Float16*>(ref_dev),
-                     static_cast<const _Float16*>(valid_ratios_dev), static_cast<_Float16*>(ref_in_dev),
-                     static_cast<_Float16*>(embed_dev), B * Nq, (int)Nq, ref_dim, num_levels, pos_feat, log2f(temperature),
+                     static_cast<const _Float16*>(valid_ratios_dev), valid_ratios32_dev, static_cast<_Float16*>(ref_in_dev),
+                     ref_in32_dev, static_cast<_Float16*>(embed_dev), B * Nq, (int)Nq, ref_dim, num_levels, pos_feat, log2f(temperature),
                      apply_sigmoid);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;

@@ -101,11 +101,14 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const unsigned short*
 }
 
 // valid_ratios[b, l, j] = fp16(counts[b, l, j]) / wh[l, j]   (get_valid_ratio: sum(~mask row/col) / W or H, in fp16)
+// out32 (optional): the same ratio in fp32, counts / size unrounded (what the fp32 reference computes)
 __global__ __launch_bounds__(256) void valid_ratios_kernel(const float* __restrict__ counts, const unsigned short* __restrict__ wh,
-                                                           unsigned short* __restrict__ out, int n, int L2) {
+                                                           unsigned short* __restrict__ out, float* __restrict__ out32, int n,
+                                                           int L2) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   out[i] = f2h(rh(counts[i]) / h2f(wh[i % L2]));
+  if (out32) out32[i] = counts[i] / h2f(wh[i % L2]);
 }
 
 }  // namespace
@@ -172,15 +175,15 @@ int codetr_decode_boxes_f16(void* stream, const void* coords_unact_dev, const in
   return err == hipSuccess ? 0 : (int)err;
 }
 
-int codetr_valid_ratios_f16(void* stream, const float* counts_dev, const void* level_wh_f16_dev, void* out_dev, int64_t B,
-                            int L) {
+int codetr_valid_ratios_f16(void* stream, const float* counts_dev, const void* level_wh_f16_dev, void* out_dev,
+                            float* out32_dev, int64_t B, int L) {
   if (!counts_dev || !level_wh_f16_dev || !out_dev || B < 0 || L <= 0) return CODETR_E_BADARG;
   if (B == 0) return 0;
   const int64_t n = B * L * 2;
   if (n > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   hipLaunchKernelGGL(valid_ratios_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      counts_dev, static_cast<const unsigned short*>(level_wh_f16_dev), static_cast<unsigned short*>(out_dev),
-                     (int)n, 2 * L);
+                     out32_dev, (int)n, 2 * L);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }

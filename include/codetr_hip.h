@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 37
+#define CODETR_HIP_ABI_VERSION 38
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -114,6 +114,19 @@ int codetr_msda_fused_forward_bf16(void *stream, const void *value_dev, const in
                                    const void *logits_dev, int64_t logits_row_stride, const void *ref_dev, int ref_dim,
                                    int value_head_major, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P,
                                    void *out_dev);
+/* The same with ref_dev in fp32 ([B, Nq, L, ref_dim] float, 8-byte aligned) while value / offsets / logits / output keep
+ * their 16-bit type: a 16-bit model's reference points (sigmoid outputs in [0, 1]) resolve a coordinate to 1/2048,
+ * a quarter pixel on a 480-wide level; codetr_query_sine_embed_f16 writes them unrounded for the decoder's layers. */
+int codetr_msda_fused_forward_ref32_f16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                                        const int64_t *level_start_dev, const void *offsets_dev,
+                                        int64_t offsets_row_stride, const void *logits_dev, int64_t logits_row_stride,
+                                        const void *ref_dev, int ref_dim, int value_head_major, int64_t B, int64_t S,
+                                        int M, int D, int L, int64_t Nq, int P, void *out_dev);
+int codetr_msda_fused_forward_ref32_bf16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                                         const int64_t *level_start_dev, const void *offsets_dev,
+                                         int64_t offsets_row_stride, const void *logits_dev, int64_t logits_row_stride,
+                                         const void *ref_dev, int ref_dim, int value_head_major, int64_t B, int64_t S,
+                                         int M, int D, int L, int64_t Nq, int P, void *out_dev);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder self-attention form of the fused op (same arithmetic, bit-identical results; LDS-staged gather).
@@ -140,6 +153,43 @@ int codetr_msda_encoder_forward_bf16(void *stream, const void *value_dev, const 
                                      const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
                                      int64_t logits_row_stride, const void *ref_dev, int64_t B, int64_t S, int M,
                                      int D, int L, int P, int halo, void *out_dev);
+
+/* The same with a staged WINDOW per (head, level) instead of one symmetric halo, fp32 reference points, and the
+ * three-pass form:
+ *   windows_host      [M][L][4] int8 (x lo, x hi, y lo, y hi): sampling offsets, in pixels of the sampled level relative
+ *                     to the query's own location, inside [x lo, x hi] x [y lo, y hi] are served from LDS; halo h is
+ *                     (-h, h, -h, h).  A trained head's offsets lean one way (the reference initialises head m along
+ *                     the angle 2 pi m / M, multi_scale_deformable_attention.py:90-115): the host derives the windows
+ *                     from sampling_offsets.bias so that the same LDS covers more of what the head actually samples.
+ *   passes            1: all levels staged at once (<= 80 KiB per workgroup keeps two per CU);
+ *                     3: fp16, L == 5, P == 4 only (CODETR_E_UNSUPPORTED otherwise): levels {0}, {1, 2}, {3, 4} staged
+ *                     one pass after the other, accumulators kept in registers -- <= 40 KiB and <= 128 registers per
+ *                     workgroup, four per CU, wider windows in the same LDS.
+ *   valid_counts_dev  NULL, or (passes == 3) [B][L][2] fp32: valid pixels of every level mask's first row (w) and first
+ *                     column (h), as codetr_mask_pyramid writes them.  When given, ref_dev is ignored (may be NULL) and the
+ *                     reference point of query pixel (x, y) of level q on level l is computed in fp32 as
+ *                     ((x + 0.5) / (vr_q W_q)) vr_l with vr = count / size -- get_reference_points and the per-level
+ *                     scaling of the reference (transformer.py:280-305, 384-400, 530) without the model dtype's rounding
+ *                     (fp16 resolves a coordinate in [0.5, 1) to 1/2048: a quarter pixel on a 480-wide level).
+ * Windows change speed, never results beyond the rounding of the packed blend: for fp16 with L == 5, P == 4 the blend
+ * runs on packed halves (fp16 corner weights, 8-term fp16 partial sums added in fp32; samples outside the windows
+ * are added in fp32): within rtol 1e-2 / atol 2e-3 of the fp64 oracle (the reference's own half test allows rtol 1e-2 /
+ * atol 1e-3 for a kernel that accumulates in half: tests/test_multi_scale_deformable_attention.py:62, 363-364), not
+ * bit-identical to codetr_msda_fused_forward_f16.
+ * codetr_msda_encoder_lds_bytes: LDS bytes per workgroup a launch would need (variant 1: generic single pass, 2: packed
+ * single pass, 3: three passes), or a negative CODETR_E_* code. */
+int codetr_msda_encoder_forward_win_f16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
+                                        const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
+                                        int64_t logits_row_stride, const void *ref_dev, const float *valid_counts_dev,
+                                        int64_t B, int64_t S, int M, int D, int L, int P, const int8_t *windows_host,
+                                        int passes, void *out_dev);
+int codetr_msda_encoder_forward_win_bf16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
+                                         const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
+                                         int64_t logits_row_stride, const void *ref_dev, const float *valid_counts_dev,
+                                         int64_t B, int64_t S, int M, int D, int L, int P, const int8_t *windows_host,
+                                         int passes, void *out_dev);
+int64_t codetr_msda_encoder_lds_bytes(const int64_t *level_shapes_host, int M, int L, int P,
+                                      const int8_t *windows_host, int variant);
 
 /* ------------------------------------------------------------------------------------------
  * Patch gather of the Swin stem (mmdet PatchEmbed: Conv2d(C, E, k, stride k) with "corner" zero padding, reference
@@ -291,7 +341,8 @@ int codetr_layernorm_fp8_f16(void *stream, const void *x_f16_dev, const void *ga
  *   codetr_decode_boxes_f16  q = idx / C, label = idx % C, sigmoid -> cxcywh -> xyxy -> x (W,H,W,H) -> clamp
  *                            (co_dino_head.py:177-209 + mmdet bbox_cxcywh_to_xyxy); coords_unact [B,Nq,4] = box branch
  *                            output + reference (before the sigmoid); boxes [B,K,4] fp16, labels [B,K] int64
- *   codetr_valid_ratios_f16  out[b,l,j] = fp16(counts[b,l,j]) / level_wh[l,j]   (transformer.py:384-400)
+ *   codetr_valid_ratios_f16  out[b,l,j] = fp16(counts[b,l,j]) / level_wh[l,j]   (transformer.py:384-400);
+ *                            out32 (may be NULL): counts / level_wh in fp32, unrounded
  * ------------------------------------------------------------------------------------------ */
 int codetr_add_f16(void *stream, const void *a_dev, const void *b_dev, void *out_dev, int64_t n, int64_t a_period);
 int codetr_sigmoid_f16(void *stream, const void *x_dev, void *out_dev, int64_t n);
@@ -300,8 +351,8 @@ int codetr_gather_rows_b16(void *stream, const void *src_dev, const int64_t *idx
 int codetr_decode_boxes_f16(void *stream, const void *coords_unact_dev, const int64_t *idx_dev, void *boxes_dev,
                             int64_t *labels_dev, int64_t B, int64_t Nq, int64_t K, int num_classes, float img_w,
                             float img_h);
-int codetr_valid_ratios_f16(void *stream, const float *counts_dev, const void *level_wh_f16_dev, void *out_dev, int64_t B,
-                            int L);
+int codetr_valid_ratios_f16(void *stream, const float *counts_dev, const void *level_wh_f16_dev, void *out_dev,
+                            float *out32_dev, int64_t B, int L);
 
 /* Split-K form of the same layer for problems with few output tiles and a long K -- the neck's extra
  * 3x3 / stride-2 level (codetr/codetr.py neck, mmdet ChannelMapper extra_convs) run as a GEMM over unfolded
@@ -359,10 +410,14 @@ int codetr_mask_pyramid(void *stream, const void *img_mask_dev, int64_t B, int64
  *   embed_dev         out [B, Nq, ref_dim * pos_feat] f16: blocks ordered (y, x[, w, h]); within a block channel
  *                     2k = sin, 2k+1 = cos of  v * 2 pi / temperature^(2k / pos_feat),  v = ref_in[b, q, 0, coord]
  * fp32 trigonometry on the f16-rounded ref_in; pos_feat % 8 == 0.
+ *   valid_ratios32_dev / ref_in32_dev  NULL, or fp32 valid ratios [B, num_levels, 2] and an fp32 output
+ *                     [B, Nq, num_levels, ref_dim]: the same reference points with the sigmoid and the scaling kept in
+ *                     fp32 (for codetr_msda_fused_forward_ref32_*); the embedding is then taken from these.
  * ------------------------------------------------------------------------------------------ */
-int codetr_query_sine_embed_f16(void *stream, const void *ref_dev, const void *valid_ratios_dev, int64_t B,
-                                int64_t Nq, int ref_dim, int num_levels, int pos_feat, float temperature,
-                                int apply_sigmoid, void *ref_in_dev, void *embed_dev);
+int codetr_query_sine_embed_f16(void *stream, const void *ref_dev, const void *valid_ratios_dev,
+                                const float *valid_ratios32_dev, int64_t B, int64_t Nq, int ref_dim, int num_levels,
+                                int pos_feat, float temperature, int apply_sigmoid, void *ref_in_dev,
+                                float *ref_in32_dev, void *embed_dev);
 
 /* ------------------------------------------------------------------------------------------
  * Token geometry of the deformable encoder / two-stage proposal head, one launch (f16 path).

@@ -80,9 +80,16 @@ struct Reader {
     }
     return v;
   }
+  void bytes(void* dst, size_t n) {   // bulk read, checked like get()
+    f.read(reinterpret_cast<char*>(dst), (std::streamsize)n);
+    if (!f) {
+      fprintf(stderr, "codetr_runner: truncated plan\n");
+      exit(2);
+    }
+  }
   std::string str(size_t n) {
     std::string s(n, '\0');
-    f.read(&s[0], (std::streamsize)n);
+    if (n) bytes(&s[0], n);
     return s;
   }
 };
@@ -184,12 +191,12 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < nblob; ++i) {
       const uint32_t seg = r.get<uint32_t>();
       const uint64_t off = r.get<uint64_t>(), n = r.get<uint64_t>();
-      buf.resize(n);
-      r.f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)n);
-      if (seg >= nseg || !seg_base[seg] || off + n > seg_size[seg]) {
+      if (seg >= nseg || !seg_base[seg] || off > seg_size[seg] || n > seg_size[seg] - off) {   // (before sizing the buffer)
         fprintf(stderr, "codetr_runner: blob %u outside its segment\n", i);
         return 2;
       }
+      buf.resize(n);
+      if (n) r.bytes(buf.data(), n);
       HIP_OK(hipMemcpy(seg_base[seg] + off, buf.data(), n, hipMemcpyHostToDevice));
       uploaded += n;
     }
@@ -230,8 +237,12 @@ int main(int argc, char** argv) {
           break;
         case kHost: {
           const uint32_t n = r.get<uint32_t>();
+          if (n > (1u << 20)) {   // host arguments are level shapes / window tables: a few hundred bytes
+            fprintf(stderr, "codetr_runner: call %u (%s) carries a %u-byte host argument\n", c, name.c_str(), n);
+            return 2;
+          }
           a.host.resize(n);
-          r.f.read(reinterpret_cast<char*>(a.host.data()), n);
+          if (n) r.bytes(a.host.data(), n);
           break;
         }
         case kNull:
@@ -250,6 +261,10 @@ int main(int argc, char** argv) {
     io.nbytes = r.get<uint64_t>();
     io.shape.resize(r.get<uint8_t>());
     for (auto& d : io.shape) d = r.get<int64_t>();
+    if (io.seg >= nseg || !seg_base[io.seg] || io.off > seg_size[io.seg] || io.nbytes > seg_size[io.seg] - io.off) {
+      fprintf(stderr, "codetr_runner: tensor %s lies outside its segment\n", io.name.c_str());
+      return 2;
+    }
   }
 
   // ---- inputs given on the command line replace the recorded ones ----

@@ -28,6 +28,16 @@ CASES = {
     # BASELINE config 1: Co-DINO R50 608x608 (the reference's CPU-runnable case; here also run in fp32 on the GPU)
     "r50_608": dict(cfg="co_dino_5scale_r50_8xb2_1x_coco.py", backbone="r50", H=608, W=608, B=1, pad=(0.9, 0.9),
                     weight_seed=13, input_seed=7),
+    # BASELINE configs 4 / 5, the size the headline metric is quoted on: Co-DINO Swin-L 1920x1280, one image with
+    # right / bottom padding.  `msda_grid_bias`: the MSDA offset biases carry the reference's directional grid
+    # (multi_scale_deformable_attention.py:90-115) under the seeded weights' ~1.6 px of query-dependent spread, so the
+    # samples straddle the LDS-staged encoder kernel's neighbourhood like trained offsets do.  `boundary_rows`: the
+    # encoder-side samples also hold the first / last row of every level and rows next to multiples of 128 / 256
+    # (GEMM / FFN tile edges) -- what a tile-edge bug would corrupt.
+    "swinl_1920x1280": dict(cfg="co_dino_5scale_swin_l_16xb1_16e_o365tococo.py", backbone="swin", H=1280, W=1920, B=1,
+                            pad=(0.9, 0.9), weight_seed=14, input_seed=8, msda_grid_bias=True, boundary_rows=True,
+                            rows={"backbone": 64, "neck": 64, "memory": 640, "enc_outputs_class": 640,
+                                  "final_state": 128, "outputs_classes": 128}),
 }
 
 # rows kept per stage (all channels of a row are kept)
@@ -50,14 +60,29 @@ def build_case(name):
             full[k] = torch.rand(full[k].shape, generator=g) + 0.5
         elif k.endswith("running_mean"):
             full[k] = torch.randn(full[k].shape, generator=g) * 0.1
+    if c.get("msda_grid_bias"):
+        from codetr.multi_scale_deformable_attention import MultiScaleDeformableAttention
+
+        for mod_name, mod in model.named_modules():
+            if isinstance(mod, MultiScaleDeformableAttention):
+                scratch = MultiScaleDeformableAttention(mod.embed_dims, mod.num_heads, mod.num_levels, mod.num_points)
+                full[mod_name + ".sampling_offsets.bias"] = scratch.sampling_offsets.bias.detach().clone()
     model.load_state_dict(full)
-    g = torch.Generator().manual_seed(c["input_seed"])
+    img, mask = case_input(name)
+    return model.eval(), full, img, mask
+
+
+def case_input(name, image_seed=None, pad="case"):
+    """the case's seeded input (or another image of the same size: `image_seed`, `pad` = None / (fx, fy))"""
+    c = CASES[name]
+    g = torch.Generator().manual_seed(c["input_seed"] if image_seed is None else image_seed)
     img = torch.randn(c["B"], 3, c["H"], c["W"], generator=g)
     mask = torch.zeros(c["B"], c["H"], c["W"])
-    if c["pad"] is not None:
-        mask[-1, :, int(c["W"] * c["pad"][0]):] = 1
-        mask[-1, int(c["H"] * c["pad"][1]):, :] = 1
-    return model.eval(), full, img, mask
+    pad = c["pad"] if pad == "case" else pad
+    if pad is not None:
+        mask[-1, :, int(c["W"] * pad[0]):] = 1
+        mask[-1, int(c["H"] * pad[1]):, :] = 1
+    return img, mask
 
 
 def spec_digest(state_dict):
@@ -75,9 +100,38 @@ def row_indices(tag, n_rows, keep):
     return torch.sort(perm[:min(keep, n_rows)])[0]
 
 
-def sample_capture(name, cap):
+def boundary_rows(level_shapes, n_rows):
+    """rows of the flattened multi-level map [S] a tile-edge bug would hit: first / last row of every level, and the
+    rows either side of every multiple of 128 / 256 nearest to 16 evenly spread positions"""
+    idx, start = set(), 0
+    for h, w in level_shapes:
+        idx.update((start, start + 1, start + w - 1, start + h * w - 1, start + h * w - w))
+        start += h * w
+    for step in (128, 256):
+        for j in range(16):
+            m = (int((j + 0.5) * n_rows / 16) // step) * step
+            idx.update((m - 1, m, m + 1, m + step - 1))
+    return torch.tensor(sorted(i for i in idx if 0 <= i < n_rows))
+
+
+def stage_row_indices(name, key, n_rows, cap=None, image=0, images=1):
+    """row indices (into the [images * rows_per_image] flattening) sampled for stage `key` of case `name`;
+    image > 0 / images > 1: the same per-image rows, taken from image `image` of a larger batch"""
+    c = CASES[name]
+    rows = dict(ROWS, **c.get("rows", {}))
+    per_image = n_rows // images
+    short = key.rstrip("0123456789")
+    idx = row_indices(f"{name}/{key}", per_image, rows[short])
+    if c.get("boundary_rows") and key in ("memory", "enc_outputs_class") and cap is not None:
+        shapes = [tuple(int(v) for v in r) for r in torch.as_tensor(cap["spatial_shapes"]).tolist()]
+        idx = torch.unique(torch.cat((idx, boundary_rows(shapes, per_image // c["B"]))))
+    return idx + image * per_image
+
+
+def sample_capture(name, cap, image=0, images=1):
     """capture dict (oracle's or product's; tensors on any device / dtype) -> dict of float32 numpy row samples.
-    backbone_feats / neck_feats are lists of [B,C,H,W]; rows are (image, pixel) pairs of the flattened map."""
+    backbone_feats / neck_feats are lists of [B,C,H,W]; rows are (image, pixel) pairs of the flattened map.
+    image / images: sample image `image` of a product batch of `images` case-sized images with the fixture's rows."""
     out = {}
 
     def rows2d(t):   # [B, N, C] -> [B*N, C]
@@ -86,13 +140,14 @@ def sample_capture(name, cap):
     for key, short in (("backbone_feats", "backbone"), ("neck_feats", "neck")):
         for i, f in enumerate(cap[key]):
             t = rows2d(f.flatten(2).transpose(1, 2))
-            idx = row_indices(f"{name}/{short}{i}", t.shape[0], ROWS[short])
+            idx = stage_row_indices(name, f"{short}{i}", t.shape[0], cap, image, images)
             out[f"{short}{i}"] = t[idx.to(t.device)].float().cpu().numpy()
     for key in ("memory", "enc_outputs_class", "final_state", "outputs_classes"):
         t = rows2d(cap[key])
-        idx = row_indices(f"{name}/{key}", t.shape[0], ROWS[key])
+        idx = stage_row_indices(name, key, t.shape[0], cap, image, images)
         out[key] = t[idx.to(t.device)].float().cpu().numpy()
-    out["outputs_coords"] = cap["outputs_coords"].float().cpu().numpy()
+    per = cap["outputs_coords"].shape[0] // images
+    out["outputs_coords"] = cap["outputs_coords"][image * per:(image + 1) * per].float().cpu().numpy()
     return out
 
 

@@ -69,6 +69,37 @@ def assert_close_lowp(actual, ref, rel_l2=1e-2, max_abs=None, what=""):
     return err
 
 
+def row_error_stats(actual, ref, rel_l2):
+    """Per-row companions of the whole-tensor relative L2 error, for [rows, C] samples of a stage (a tile-edge bug that
+    corrupts a handful of rows moves the whole-tensor number by nothing):
+      row_ratio  = max over rows of ||a_row - r_row|| / (rel_l2 * max(||r_row||, rms row norm of the tensor)),
+      elem_frac  = max over rows of the fraction of the row's elements with |a - r| > 4 rel_l2 (|r| + rms element).
+    Non-finite elements must agree in position (checked by assert_close_lowp) and are left out."""
+    a = np.asarray(actual, dtype=np.float64).reshape(-1, np.asarray(actual).shape[-1])
+    r = np.asarray(ref, dtype=np.float64).reshape(a.shape)
+    fin = np.isfinite(r) & np.isfinite(a)
+    d = np.where(fin, a - r, 0.0)
+    rz = np.where(fin, r, 0.0)
+    row_norm = np.sqrt((rz * rz).sum(-1))
+    rms_row = np.sqrt((row_norm ** 2).mean())
+    rms_el = np.sqrt((rz * rz).sum() / max(fin.sum(), 1))
+    ratio = np.sqrt((d * d).sum(-1)) / (rel_l2 * np.maximum(row_norm, max(rms_row, 1e-30)))
+    out = np.abs(d) > 4.0 * rel_l2 * (np.abs(rz) + rms_el)
+    frac = out.sum(-1) / np.maximum(fin.sum(-1), 1)
+    return float(ratio.max()), float(frac.max()), int(ratio.argmax())
+
+
+def assert_rows_close(actual, ref, rel_l2, what="", row_factor=5.0, elem_frac=0.01):
+    """assert_close_lowp plus the per-row bound: no row's error above row_factor x the tensor's bound (relative to
+    the larger of its own norm and the tensor's rms row norm), no row with more than elem_frac of its elements beyond
+    4 rel_l2 (|ref| + rms).  Returns (tensor rel-L2, worst row ratio / row_factor, worst element fraction)."""
+    err = assert_close_lowp(actual, ref, rel_l2, None, what)
+    ratio, frac, worst = row_error_stats(actual, ref, rel_l2)
+    assert ratio <= row_factor, f"{what}: row {worst} is {ratio:.2f} x the tensor bound {rel_l2:.1e} (limit {row_factor})"
+    assert frac <= elem_frac, f"{what}: a row has {100 * frac:.1f} % of its elements beyond 4 x {rel_l2:.1e} (|ref| + rms)"
+    return err, ratio / row_factor, frac
+
+
 def valid_topk(enc_cls, enc_coord, k, bound=None):
     """Proposal selection for parity runs on random weights: the reference's rule (top-k of the max class
     logit, reference transformer.py:560) restricted to positions whose proposal is finite.  With

@@ -109,3 +109,25 @@ def test_runner_dispatch_table_is_in_sync_with_the_signature_table():
     assert gen == open(os.path.join(root, "runner", "dispatch_gen.inc")).read(), \
         "regenerate: python tools/gen_runner_dispatch.py > runner/dispatch_gen.inc"
     assert os.access(os.path.join(root, "runner", "codetr_runner"), os.X_OK)   # built by __graft_entry__.build()
+
+
+def test_kernel_name_whitelist_matches_sources():
+    """codetr/_kernel_names.py (the plan exporter's whitelist of replayable device activity) lists exactly the
+    __global__ functions of csrc/*.hip: regenerate with tools/gen_kernel_names.py after adding a kernel"""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_kernel_names", os.path.join(root, "tools", "gen_kernel_names.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    from codetr._kernel_names import KERNEL_NAMES
+    from codetr.export import is_own_kernel
+
+    assert list(KERNEL_NAMES) == gen.kernel_names()
+    assert is_own_kernel("(anonymous namespace)::add_kernel(unsigned short const*, ...)")
+    assert is_own_kernel("void (anonymous namespace)::linear_256_kernel<(anonymous namespace)::HalfT, 0, true, false, true>(")
+    assert is_own_kernel("_ZN12_GLOBAL__N_114row_max_kernelEPKDF16_PDF16_li")
+    for foreign in ("void (anonymous namespace)::elementwise_kernel_with_index<int, ...>", "void at::native::vectorized_elementwise_kernel<4",
+                    "Cijk_Alik_Bljk_HHS_BH", "Memcpy DtoD (Device -> Device)", "__amd_rocclr_copyBuffer", "triton_poi_fused_add_0"):
+        assert not is_own_kernel(foreign), foreign

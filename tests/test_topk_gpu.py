@@ -19,12 +19,8 @@ def _check(x, k):
     from codetr import _cabi, hip_ops
 
     before = _cabi.CALLS["topk"]
-    hip_ops.TOPK_NATIVE, saved = True, hip_ops.TOPK_NATIVE      # (opt-in on the model path: CODETR_TOPK=1)
-    try:
-        with torch.no_grad():
-            v, i = hip_ops.topk(x, k)
-    finally:
-        hip_ops.TOPK_NATIVE = saved
+    with torch.no_grad():
+        v, i = hip_ops.topk(x, k)
     torch.cuda.synchronize()
     assert _cabi.CALLS["topk"] == before + 1
     # stable descending order of the whole row fixes the indices; every NaN counts as the largest value (torch's
@@ -79,10 +75,6 @@ def test_unsupported_falls_back_to_torch():
     assert _cabi.CALLS["topk"] == before
     tv, ti = torch.topk(x, 10, dim=-1)
     assert torch.equal(v, tv) and torch.equal(i, ti)
-    hip_ops.TOPK_NATIVE, saved = True, hip_ops.TOPK_NATIVE
-    try:
-        with torch.no_grad():
-            v, i = hip_ops.topk(x.half(), 2000)         # k > 1024: library path
-    finally:
-        hip_ops.TOPK_NATIVE = saved
+    with torch.no_grad():
+        v, i = hip_ops.topk(x.half(), 2000)         # k > 1024: library path
     assert _cabi.CALLS["topk"] == before and v.shape == (2, 2000)

@@ -18,8 +18,14 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--noise", type=float, default=0.5)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=1, help="1: windows from the bias grid, 0: symmetric halo")
+    ap.add_argument("--passes", type=int, default=3, help="3: three-pass kernel, 1: single pass")
+    ap.add_argument("--counts", type=int, default=0, help="1: reference points computed in fp32 from valid counts")
     a = ap.parse_args()
-    from codetr import hip_ops
+    from codetr import _cabi, hip_ops
+
+    if os.environ.get("CODETR_LIB"):   # timing experiments: a diagnostic build of the library (e.g. -DMSDA_ENC_ABLATE)
+        _cabi.LIB_PATH = os.environ["CODETR_LIB"]
 
     dev = "cuda:0"
     shapes = [(320, 480), (160, 240), (80, 120), (40, 60), (20, 30)]
@@ -53,15 +59,23 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / a.iters * 1e3
 
-    enc = lambda: hip_ops.msda_encoder(value, shapes, proj, 0, M * L * P * 2, ref, P)  # noqa: E731
+    bias = off_bias = (grid[:, None, None, :] * (torch.arange(P, device=dev) + 1)[None, None, :, None]).expand(M, L, P, 2)
+    win = hip_ops.msda_encoder_windows(bias.reshape(-1), shapes, M, L, P, a.passes) if a.windows else None
+    counts = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=dev)[None].expand(B, L, 2).contiguous()
+    enc = lambda: hip_ops.msda_encoder(value, shapes, proj, 0, M * L * P * 2, ref, P, win, a.passes,  # noqa: E731
+                                       counts if a.counts else None)
+    if win is not None:
+        print("windows head 0/1:", win[0], win[1], "lds", _cabi.msda_encoder_lds_bytes(shapes, M, P, win, 3 if a.passes == 3 else 2))
     gen = lambda: hip_ops.msda_fused(value, ss, ls, proj, 0, M * L * P * 2, ref, L, P)  # noqa: E731
     o1, o2 = enc(), gen()
     assert o1 is not None
     same = torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+    rel = ((o1.double() - o2.double()).norm() / o2.double().norm()).item()
     t_enc, t_gen = timed(enc), timed(gen)
     alg = 2 * (B * S * M * D + 3 * B * S * M * L * P + B * S * M * D)
     print(f"batch {B} noise {a.noise} halo {hip_ops.MSDA_HALO}: encoder kernel {t_enc:8.1f} us "
-          f"({alg / t_enc / 1e6:6.2f} TB/s algorithmic)   general fused {t_gen:8.1f} us   identical: {same}")
+          f"({alg / t_enc / 1e6:6.2f} TB/s algorithmic)   general fused {t_gen:8.1f} us   identical: {same} "
+          f"rel L2 vs general {rel:.2e}  windows {'bias' if a.windows else 'halo'} passes {a.passes} counts {a.counts}")
 
 
 if __name__ == "__main__":

@@ -31,10 +31,13 @@ for (H, W) in [(608, 608), (800, 1333), (750, 1000), (1280, 1920)]:
         assert (used > 0) == enc, (enc, used)
     hip_ops.MSDA_ENCODER = True
     same = all(torch.equal(torch.nan_to_num(a.float(), 0), torch.nan_to_num(b.float(), 0)) for a, b in zip(outs[True], outs[False]))
-    hip_ops.PATCH_GEMM = False
-    with torch.no_grad():
-        ref = model(img, mask)
-    hip_ops.PATCH_GEMM = True
+    saved = hip_ops.patch_embed_supported
+    hip_ops.patch_embed_supported = lambda *a, **k: False    # the stem through the library convolution
+    try:
+        with torch.no_grad():
+            ref = model(img, mask)
+    finally:
+        hip_ops.patch_embed_supported = saved
     s_new, s_ref = torch.nan_to_num(outs[True][1].float(), 0), torch.nan_to_num(ref[1].float(), 0)
     prof = (s_new[:, :100] - s_ref[:, :100]).abs().max().item() / max(s_ref.abs().max().item(), 1e-6)
     print(f"{W}x{H}: encoder kernel == general kernel: {same};  gather+GEMM stem / neck vs ATen: top-100 score profile "
