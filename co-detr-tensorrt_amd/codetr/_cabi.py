@@ -49,6 +49,11 @@ SIGNATURES = {
     "codetr_msda_encoder_forward_win_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
                                                     _i32, _i32, _vp, _i32, _vp]),
     "codetr_msda_encoder_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32]),
+    "codetr_mx_scale_bytes": (_i64, [_i64, _i64]),
+    "codetr_linear_fp8mx": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
+    "codetr_cast_fp8mx_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64]),
+    "codetr_layernorm_fp8mx_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
+    "codetr_window_attention_fp8mx_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
     "codetr_mha_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
     "codetr_mha_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i64, _i64, _i64]),
     "codetr_linear_ln_f16": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
@@ -133,7 +138,7 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
 RECORDER = None
 _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
-            "codetr_msda_encoder_lds_bytes"}
+            "codetr_msda_encoder_lds_bytes", "codetr_mx_scale_bytes"}
 
 
 class _RecordingLib:
@@ -455,10 +460,18 @@ def window_attention_supported(dtype, embed_dims, num_heads, window_size) -> boo
     return dtype in (torch.float16, torch.bfloat16) and embed_dims == num_heads * 32 and window_size in (4, 7, 8, 12)
 
 
-def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_size, shift, out_scale=None):
-    """out: 16-bit like qkv, or (with out_scale, f16 qkv) torch.float8_e4m3fn = sat(f16(o) / out_scale)"""
+def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_size, shift, out_scale=None,
+                     out_scales=None):
+    """out: 16-bit like qkv, or (with out_scale, f16 qkv) torch.float8_e4m3fn = sat(f16(o) / out_scale), or (with
+    out_scales, a uint8 MX scale tensor) block-scaled e4m3"""
     CALLS["window_attention"] += 1
     lib = load()
+    if out_scales is not None:
+        rc = lib.codetr_window_attention_fp8mx_f16(current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(),
+                                                   rel_bias.data_ptr(), out.data_ptr(), out_scales.data_ptr(), B, H, W,
+                                                   num_heads, 32, window_size, shift)
+        check(rc, "codetr_window_attention_fp8mx_f16")
+        return out
     if out_scale is not None:
         rc = lib.codetr_window_attention_fp8out_f16(current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(),
                                                     rel_bias.data_ptr(), out.data_ptr(), float(out_scale), B, H, W,
@@ -737,6 +750,43 @@ def linear_fp8(x8, w8, w_scale, x_scale, bias, residual2d, act, out2d, out_scale
                                residual2d.data_ptr() if residual2d is not None else None, out2d.data_ptr(),
                                1 if out8 else 0, float(out_scale), M, N, K, _ACT[act])
     check(rc, "codetr_linear_fp8")
+    return out2d
+
+
+def mx_scale_bytes(M, K) -> int:
+    n = int(load().codetr_mx_scale_bytes(M, K))
+    if n < 0:
+        raise ValueError(f"no MX scale layout for [{M}, {K}]")
+    return n
+
+
+def linear_fp8mx(x8, x_scales, w8, w_scale, bias, residual2d, act, out2d, out_scales=None):
+    """x8 [M,K] e4m3 + x_scales (uint8, mx_scale_bytes(M, K)); out2d fp16 [M,N], or e4m3 + out_scales (mx_scale_bytes(M, N))"""
+    CALLS["linear_fp8"] += 1
+    M, K = x8.shape
+    N = w8.shape[0]
+    rc = load().codetr_linear_fp8mx(current_stream_ptr(x8.device), x8.data_ptr(), x_scales.data_ptr(), w8.data_ptr(),
+                                    w_scale.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    residual2d.data_ptr() if residual2d is not None else None, out2d.data_ptr(),
+                                    out_scales.data_ptr() if out_scales is not None else None, M, N, K, _ACT[act])
+    check(rc, "codetr_linear_fp8mx")
+    return out2d
+
+
+def cast_fp8mx(x2d, out2d, out_scales):
+    CALLS["cast_fp8"] += 1
+    rows, C = x2d.shape
+    check(load().codetr_cast_fp8mx_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), out2d.data_ptr(), out_scales.data_ptr(),
+                                       rows, C), "codetr_cast_fp8mx_f16")
+    return out2d
+
+
+def layernorm_fp8mx(x2d, weight, bias, eps, out2d, out_scales):
+    CALLS["layernorm_fp8"] += 1
+    rows, C = x2d.shape
+    check(load().codetr_layernorm_fp8mx_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                            out2d.data_ptr(), out_scales.data_ptr(), rows, C, float(eps)),
+          "codetr_layernorm_fp8mx_f16")
     return out2d
 
 

@@ -22,7 +22,12 @@ from . import hip_ops
 from .swin import SwinBlock
 from .transformer_layers import FFN
 
-MARGIN = 1.0   # scale = absmax * MARGIN / 448 (calibration and evaluation inputs are drawn alike in bench / tests)
+MARGIN = 1.0   # static mode: scale = absmax * MARGIN / 448 (calibration and evaluation inputs are drawn alike in bench / tests)
+# "mx" (default): MX block scales on the Swin activations -- one e8m0 exponent per 32 channels, chosen by the producer
+# kernel from the block's own maximum and applied by the scaled MFMA in hardware: no calibration, no saturation on unseen
+# inputs.  "static": the round-2 scheme (one calibrated scale per tensor), kept for A/B.  The encoder's fused FFN uses
+# static scales in both modes (its calibration is the only thing `calibrate` still has to do in "mx" mode).
+MODE = "mx"
 
 
 def _blocks(model):
@@ -64,19 +69,30 @@ def calibrate(model, batch_inputs, img_masks):
     return n
 
 
-def enable(model, on=True):
-    """switch the calibrated blocks to the fp8 path (blocks without scales, or whose shapes the fp8 GEMM does not
-    take at run time, keep running fp16)"""
-    for b in _blocks(model) + _ffns(model):
-        b.fp8_mode = "run" if (on and hasattr(b, "_fp8_scales")) else None
+def enable(model, on=True, mode=None):
+    """switch the blocks to the fp8 path: Swin blocks to MX block scales (mode "mx", no calibration needed) or to their
+    calibrated static scales (mode "static"); calibrated FFNs to the fused e4m3 kernel.  Blocks whose shapes the fp8
+    GEMM does not take at run time keep running fp16."""
+    mode = mode or MODE
+    for b in _blocks(model):
+        if not on:
+            b.fp8_mode = None
+        elif mode == "mx":
+            b.fp8_mode = "mx"
+        else:
+            b.fp8_mode = "run" if hasattr(b, "_fp8_scales") else None
+    for f in _ffns(model):
+        f.fp8_mode = "run" if (on and hasattr(f, "_fp8_scales")) else None
 
 
 def report(model):
     blocks = _blocks(model)
-    ready = [b for b in blocks if getattr(b, "fp8_mode", None) == "run"]
+    ready = [b for b in blocks if getattr(b, "fp8_mode", None) in ("run", "mx")]
     k_ok = [b for b in ready if all(w.shape[1] % 128 == 0 for w in b._fp8_weights())]
     ffns = _ffns(model)
     return {"swin_blocks": len(blocks), "swin_blocks_fp8": len(k_ok),
+            "activation_scales": "MX blocks (e8m0 per 32 channels, dynamic)" if any(getattr(b, "fp8_mode", None) == "mx" for b in blocks)
+            else "static per tensor (calibrated)",
             "ffns": len(ffns), "ffns_fp8": sum(1 for f in ffns if f.fp8_mode == "run"),
             "fp8_layers": f"qkv / proj / fc1 / fc2 of Swin blocks with K a multiple of 128 (stages 1-3) when the GEMM has "
                           f">= {hip_ops.FP8_MIN_TILES} 256x256 tiles; both products of the encoder's fused FFN "

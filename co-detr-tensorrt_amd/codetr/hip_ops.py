@@ -476,12 +476,13 @@ def swin_window_attention_supported(x, embed_dims, num_heads, window_size):
     return x.is_cuda and _cabi.window_attention_supported(x.dtype, embed_dims, num_heads, window_size)
 
 
-def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_size, shift, out_scale=None):
+def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_size, shift, out_scale=None, out_mx=False):
     """Fused (shifted-)window attention on the UNPADDED spatial token map.
     qkv [B, H*W, 3C] (output of the qkv Linear on real tokens only), qkv_bias [3C] or None,
     rel_bias [nH, N, N] -> [B, H*W, C].  Pad / roll / partition / softmax / reverse are all inside
     the kernel (reference codetr/swin.py:191-252, 92-112).
-    out_scale (fp16 qkv only): the result is e4m3 = sat(f16(o) / out_scale), the operand of the fp8 proj GEMM."""
+    out_scale (fp16 qkv only): the result is e4m3 = sat(f16(o) / out_scale), the operand of the fp8 proj GEMM;
+    out_mx (fp16 qkv only): the result is (e4m3, MX block scales) -- one block per (token, head)."""
     _gpu(qkv, "swin_window_attention")
     B, L, C3 = qkv.shape
     H, W = hw_shape
@@ -491,12 +492,14 @@ def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_s
         qkv = qkv.contiguous()
     if qkv_bias is None:
         qkv_bias = torch.zeros(C3, dtype=qkv.dtype, device=qkv.device)
-    if out_scale is not None and qkv.dtype != torch.float16:
-        raise ValueError("the e4m3 output form takes fp16 qkv")
-    out = torch.empty((B, L, C3 // 3), dtype=qkv.dtype if out_scale is None else FP8, device=qkv.device)
+    if (out_scale is not None or out_mx) and qkv.dtype != torch.float16:
+        raise ValueError("the e4m3 output forms take fp16 qkv")
+    out = torch.empty((B, L, C3 // 3), dtype=FP8 if (out_scale is not None or out_mx) else qkv.dtype, device=qkv.device)
+    scales = torch.empty(_cabi.mx_scale_bytes(B * L, C3 // 3), dtype=torch.uint8, device=qkv.device) if out_mx else None
     with torch.cuda.device(qkv.device):
-        _cabi.window_attention(qkv, qkv_bias, rel_bias.contiguous(), out, B, H, W, num_heads, window_size, shift, out_scale)
-    return out
+        _cabi.window_attention(qkv, qkv_bias, rel_bias.contiguous(), out, B, H, W, num_heads, window_size, shift, out_scale,
+                               scales)
+    return (out, scales) if out_mx else out
 
 
 def mha_self_attention(q, k, v, num_heads):
@@ -800,6 +803,68 @@ def linear_fp8(x8, x_scale, weight, bias=None, act=None, residual=None, out_scal
             e1.record(st)
             LINEAR_PROFILE.append((e0, e1, 2.0 * x2.shape[0] * N * K, x2.shape[0], N, K, "fp8"))
     return out.view(*x8.shape[:-1], N)
+
+
+def linear_fp8mx(x8, x_scales, weight, bias=None, act=None, residual=None, out_mx=False):
+    """act((x8 (*) block scales) @ weight.T + bias) (+ residual): x8 e4m3 [..., K] with its MX scale tensor, the fp16
+    `weight` quantised per output channel (cached).  Returns fp16, or (e4m3, scales) with block scales along N."""
+    _gpu(x8, "linear_fp8mx")
+    w8, ws = fp8_weight(weight)
+    K, N = x8.shape[-1], weight.shape[0]
+    x2 = x8.reshape(-1, K)
+    r2 = None if residual is None else residual.reshape(-1, N).contiguous()
+    out = torch.empty((x2.shape[0], N), dtype=FP8 if out_mx else torch.float16, device=x8.device)
+    sy = torch.empty(_cabi.mx_scale_bytes(x2.shape[0], N), dtype=torch.uint8, device=x8.device) if out_mx else None
+    with torch.cuda.device(x8.device):
+        launch = lambda: _cabi.linear_fp8mx(x2, x_scales, w8, ws, bias, r2, act, out, sy)  # noqa: E731
+        if LINEAR_PROFILE is None:
+            launch()
+        else:
+            st = torch.cuda.current_stream(x8.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            launch()
+            e1.record(st)
+            LINEAR_PROFILE.append((e0, e1, 2.0 * x2.shape[0] * N * K, x2.shape[0], N, K, "fp8"))
+    out = out.view(*x8.shape[:-1], N)
+    return (out, sy) if out_mx else out
+
+
+def cast_fp8mx(x):
+    """fp16 [..., C] -> (e4m3, MX block scales), C % 128 == 0"""
+    _gpu(x, "cast_fp8mx")
+    x2 = x.reshape(-1, x.shape[-1])
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    out = torch.empty(x2.shape, dtype=FP8, device=x.device)
+    sy = torch.empty(_cabi.mx_scale_bytes(*x2.shape), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _cabi.cast_fp8mx(x2, out, sy)
+    return out.view(x.shape), sy
+
+
+def layer_norm_fp8mx(x, weight, bias, eps):
+    """LayerNorm(x) -> (e4m3, MX block scales) in one kernel (fp16 input; the norm's fp16 output is never written)"""
+    _gpu(x, "layer_norm_fp8mx")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    out = torch.empty(x2.shape, dtype=FP8, device=x.device)
+    sy = torch.empty(_cabi.mx_scale_bytes(x2.shape[0], C), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _cabi.layernorm_fp8mx(x2, weight, bias, eps, out, sy)
+    return out.view(x.shape), sy
+
+
+def mx_dequant(x8, scales):
+    """(tests / diagnostics) the fp32 values an (e4m3, MX scales) pair stands for"""
+    x2 = x8.reshape(-1, x8.shape[-1])
+    M, K = x2.shape
+    m = torch.arange(M, device=x8.device)[:, None]
+    kb = torch.arange(K // 32, device=x8.device)[None, :]
+    MB = -(-M // 128)
+    idx = ((((kb >> 2) * MB + (m >> 7)) * 64 + (kb & 3) * 16 + (m & 15)) * 8 + ((m >> 4) & 7)).long()
+    e = scales.long()[idx].float() - 127.0                       # [M, K / 32]
+    return (x2.float().view(M, K // 32, 32) * torch.exp2(e)[:, :, None]).view(x8.shape)
 
 
 def cast_fp8(x, scale):

@@ -245,6 +245,8 @@ class SwinBlock(nn.Module):
                 return self._forward_fp8_calibrate(x, hw_shape)
             if mode == "run" and all(hip_ops.linear_fp8_supported(rows, w) for w in self._fp8_weights()):
                 return self._forward_fp8(x, hw_shape)
+            if mode == "mx" and all(hip_ops.linear_fp8_supported(rows, w) for w in self._fp8_weights()):
+                return self._forward_fp8mx(x, hw_shape)
         if (isinstance(n1, nn.LayerNorm) and self.attn.takes_norm(x, hw_shape)
                 and hip_ops.linear_ln_supported(x, n1.weight, self.attn.w_msa.qkv.weight)):
             # norm1 folded into the qkv GEMM's operand load (only that GEMM reads the normalised rows)
@@ -304,6 +306,21 @@ class SwinBlock(nn.Module):
         h8 = hip_ops.layer_norm_fp8(x, n2.weight, n2.bias, n2.eps, sc["ln2"])
         g8 = hip_ops.linear_fp8(h8, sc["ln2"], fc1.weight, fc1.bias, act=self.ffn.act, out_scale=sc["act"])
         return hip_ops.linear_fp8(g8, sc["act"], fc2.weight, fc2.bias, residual=x)
+
+
+    def _forward_fp8mx(self, x, hw_shape):
+        """the same chain with MX block scales on every activation (one e8m0 exponent per 32 channels, chosen by the
+        producer from the block's own maximum; applied by the scaled MFMA in hardware): no calibration, no static scale"""
+        n1, n2, m = self.norm1, self.norm2, self.attn.w_msa
+        fc1, fc2 = self.ffn.layers[0][0], self.ffn.layers[1]
+        h8, hs = hip_ops.layer_norm_fp8mx(x, n1.weight, n1.bias, n1.eps)
+        qkv = hip_ops.linear_fp8mx(h8, hs, m.qkv.weight, m.qkv.bias)
+        o8, os_ = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads,
+                                                self.attn.window_size, self.attn.shift_size, out_mx=True)
+        x = hip_ops.linear_fp8mx(o8, os_, m.proj.weight, m.proj.bias, residual=x)
+        h8, hs = hip_ops.layer_norm_fp8mx(x, n2.weight, n2.bias, n2.eps)
+        g8, gs = hip_ops.linear_fp8mx(h8, hs, fc1.weight, fc1.bias, act=self.ffn.act, out_mx=True)
+        return hip_ops.linear_fp8mx(g8, gs, fc2.weight, fc2.bias, residual=x)
 
 
 class SwinBlockSequence(nn.Module):

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "codetr_hip.h"
+#include "mx_scale.h"
 
 namespace {
 
@@ -71,6 +72,17 @@ __device__ __forceinline__ i32x8 read_frag(const unsigned char* tile, int row, i
   return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// MX form: the hardware's k order.  Lane group g = lane >> 4 holds k [16 g, 16 g + 16) in registers 0-3 and
+// k [64 + 16 g, 64 + 16 g + 16) in registers 4-7 -- 16-byte chunks g and g + 4 -- and the scale byte of lane row + 16 b covers
+// MX block b = k [32 b, 32 b + 32) = chunks 2 b, 2 b + 1 (probed: tools/micro/mx_scale_probe2.hip).  With unit scales any
+// consistent k permutation works (read_frag above); with block scales the operands must sit where the instruction
+// expects them.  Bank check as for read_frag: a ds_read_b128 service group then reads chunks {c, c ^ 1} of 16 different
+// rows whose swizzled images are distinct (tests/test_lds_bank_model.py).
+__device__ __forceinline__ i32x8 read_frag_mx(const unsigned char* tile, int row, int g) {
+  const i32x4 lo = read_piece(tile, row, g), hi = read_piece(tile, row, g + 4);
+  return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 __device__ __forceinline__ float h2f(unsigned short bits) {
   _Float16 h;
   __builtin_memcpy(&h, &bits, 2);
@@ -89,15 +101,36 @@ __device__ __forceinline__ unsigned pk_fp8(float a, float b) {
   return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
 }
 
+// one lane's 8 scale bytes of a k-tile (mx_scale.h layout): an ORDINARY load, waited for by the compiler.  hipcc drains
+// the whole vector-memory queue (vmcnt(0)) at the first use of such a load while LDS-DMA pieces are in flight, i.e. at the
+// top of the next k-tile -- so in the MX form X(t+2)'s pieces have to land one tile early and the three-slot X ring
+// degenerates to a two-slot one in time (measured cost: profiles/r03_fp8_mx_gemm.txt).  The alternative -- a raw
+// inline-assembly load hidden from the compiler's bookkeeping, covered by the loop's own counted wait -- was built and
+// REMOVED: the compiler is free to copy / recycle the asm's destination register before the data lands (it placed the
+// loop-carried copy ahead of the wait and reused the register for address arithmetic: wrong scales now and then, and a
+// memory fault when the late write hit a recycled address register; tools/micro notes in DESIGN.md section 4).
+__device__ __forceinline__ unsigned long long ld_scales(const unsigned char* tile_base, unsigned lane_off) {
+  return *reinterpret_cast<const unsigned long long*>(tile_base + lane_off);
+}
+template <int OPSEL>
+__device__ __forceinline__ f32x4 mfma_mx(const i32x8& a, const i32x8& b, const f32x4& c, int scale_b) {
+  // A = the weight rows at unit block scales (their real scale is per output channel, applied in the epilogue),
+  // B = the activation rows with their block scales
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, OPSEL, scale_b);
+}
+
 // ACT: 0 none, 1 relu, 2 gelu(erf).  OUT8: Y is e4m3 (y / out_scale), else fp16.
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool OUT8>
+// MX: X carries block scales (sx, mx_scale.h) instead of one static scale; with OUT8 the output gets block scales of its
+// own along N (sy), laid out for a consumer GEMM whose K is this N.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool OUT8, bool MX = false>
 __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char* __restrict__ X,
                                                              const unsigned char* __restrict__ W,
                                                              const float* __restrict__ w_scale, const float x_scale,
                                                              const unsigned short* __restrict__ bias,
                                                              const unsigned short* __restrict__ R, void* __restrict__ Yv,
                                                              const float out_inv_scale, int M, int N, int K,
-                                                             int tiles_n) {
+                                                             int tiles_n, const unsigned char* __restrict__ sx,
+                                                             unsigned char* __restrict__ sy) {
   constexpr int NT = 512;
   constexpr int kTileBytes = 256 * 128;        // 32 KiB: one operand tile (256 rows x 128 bytes of K)
   // LDS = [X0 X1 X2][W0 W1], 160 KiB (all of the CU's): X is prefetched two k-tiles ahead, W one (the XDEEP form of
@@ -134,6 +167,10 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
   };
   const int nk = K / 128;
+  const int64_t MB = mx_blocks128(M);
+  const unsigned char* sx_blk = MX ? sx + (size_t)(tm * 2 + wm < MB ? tm * 2 + wm : MB - 1) * 512 : nullptr;
+  unsigned long long sxc = 0, sxn = 0;   // scale bytes of the current / next k-tile
+  if (MX) sxn = ld_scales(sx_blk, (unsigned)lane * 8);
   // issue order W(0), X(0), X(1): the youngest four pieces may stay in flight at the first wait
 #pragma unroll
   for (int q = 0; q < 4; ++q) dma(gw[q], lds + 3 * kTileBytes + (q * NT + wave * 64) * 16);
@@ -145,8 +182,10 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
     for (int q = 0; q < 4; ++q) dma(gx[q] + k1, lds + kTileBytes + (q * NT + wave * 64) * 16);
   }
   int xs = 0;  // ring slot of X(t)
-  for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // W(t), X(t) landed; the four pieces of X(t+1) may be in flight
+  // one k-tile.  MX: `s_use` = the tile's scale bytes, `s_load` receives the next tile's
+  auto k_tile = [&](const int t, unsigned long long& s_use, unsigned long long& s_load) {
+    // W(t), X(t) (and the scales of tile t) landed; the four pieces of X(t+1) may be in flight
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t is in LDS for everyone; everyone is done reading tile t-1
     const unsigned char* bufW = lds + (3 + (t & 1)) * kTileBytes;
     const unsigned char* bufX = lds + xs * kTileBytes;
@@ -157,23 +196,43 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
     unsigned char* nbufW = lds + (3 + ((t + 1) & 1)) * kTileBytes;
     unsigned char* nbufX = lds + (xs >= 1 ? xs - 1 : 2) * kTileBytes;
     xs = xs == 2 ? 0 : xs + 1;
+    if (MX) s_load = ld_scales(sx_blk + (size_t)(t + 1 < nk ? t + 1 : nk - 1) * (size_t)MB * 512, (unsigned)lane * 8);
     i32x8 a[4], b[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = read_frag(bufW, wn * 64 + i * 16 + frow, fg);
-    b[0] = read_frag(bufX, wm * 128 + frow, fg);
+    for (int i = 0; i < 4; ++i)
+      a[i] = MX ? read_frag_mx(bufW, wn * 64 + i * 16 + frow, fg) : read_frag(bufW, wn * 64 + i * 16 + frow, fg);
+    b[0] = MX ? read_frag_mx(bufX, wm * 128 + frow, fg) : read_frag(bufX, wm * 128 + frow, fg);
     __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (j < 7) b[(j + 1) & 1] = read_frag(bufX, wm * 128 + (j + 1) * 16 + frow, fg);
+      if (j < 7)
+        b[(j + 1) & 1] = MX ? read_frag_mx(bufX, wm * 128 + (j + 1) * 16 + frow, fg)
+                            : read_frag(bufX, wm * 128 + (j + 1) * 16 + frow, fg);
       if (j < 4) dma(gw[j] + koffw, nbufW + (j * NT + wave * 64) * 16);
       else dma(gx[j - 4] + koffx, nbufX + ((j - 4) * NT + wave * 64) * 16);
+      const int sb = (int)(j < 4 ? (unsigned)s_use : (unsigned)(s_use >> 32));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j & 1], acc[i][j], 0, 0, 0, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        if (!MX) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j & 1], acc[i][j], 0, 0, 0, 0, 0, 0);
+        else if ((j & 3) == 0) acc[i][j] = mfma_mx<0>(a[i], b[j & 1], acc[i][j], sb);
+        else if ((j & 3) == 1) acc[i][j] = mfma_mx<1>(a[i], b[j & 1], acc[i][j], sb);
+        else if ((j & 3) == 2) acc[i][j] = mfma_mx<2>(a[i], b[j & 1], acc[i][j], sb);
+        else acc[i][j] = mfma_mx<3>(a[i], b[j & 1], acc[i][j], sb);
+      }
       if (j < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
+  };
+  if (MX) {
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      k_tile(t, sxn, sxc);
+      k_tile(t + 1, sxc, sxn);
+    }
+    if (t < nk) k_tile(t, sxn, sxc);
+  } else {
+    for (int t = 0; t < nk; ++t) k_tile(t, sxc, sxn);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all fragment reads done, no DMA in flight: LDS is free for the epilogue
@@ -186,7 +245,7 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = n + r < N;
-      sc[i][r] = ok ? w_scale[n + r] * x_scale : 0.f;
+      sc[i][r] = ok ? w_scale[n + r] * (MX ? 1.0f : x_scale) : 0.f;
       bs[i][r] = (HAS_BIAS && ok) ? h2f(bias[n + r]) : 0.f;
     }
   }
@@ -238,7 +297,23 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
           for (int e = 0; e < 8; ++e) v[e] = (short)f2h(h2f((unsigned short)v[e]) + h2f((unsigned short)rr[e]));
         }
         const unsigned eoff = (unsigned)(wm * 128 + h * 64 + ml) * (unsigned)N + (unsigned)(wn * 64 + schunk * 8);
-        if (OUT8) {
+        if (OUT8 && MX) {
+          // block scales along N: the 32 columns of a block are the 8 values of 4 neighbouring lanes
+          float y[8], amax = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            y[e] = h2f((unsigned short)v[e]);
+            amax = fmaxf(amax, fabsf(y[e]));
+          }
+          amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+          amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+          const unsigned sbyte = mx_e8m0(amax);
+          const float inv = mx_inv_scale(sbyte);
+          const unsigned lo = pk_fp8(y[0] * inv, y[1] * inv) | (pk_fp8(y[2] * inv, y[3] * inv) << 16);
+          const unsigned hi = pk_fp8(y[4] * inv, y[5] * inv) | (pk_fp8(y[6] * inv, y[7] * inv) << 16);
+          *reinterpret_cast<uint2*>(ytile + eoff) = uint2{lo, hi};
+          if ((schunk & 3) == 0) sy[mx_index(m, n >> 5, MB)] = (unsigned char)sbyte;
+        } else if (OUT8) {
           unsigned lo = 0, hi = 0;
           lo = pk_fp8(h2f((unsigned short)v[0]) * out_inv_scale, h2f((unsigned short)v[1]) * out_inv_scale) |
                (pk_fp8(h2f((unsigned short)v[2]) * out_inv_scale, h2f((unsigned short)v[3]) * out_inv_scale) << 16);
@@ -254,9 +329,10 @@ __global__ __launch_bounds__(512) void linear_256_fp8_kernel(const unsigned char
   }
 }
 
-template <int ACT, bool OUT8>
+template <int ACT, bool OUT8, bool MX = false>
 int launch_bias_res(hipStream_t st, const void* X, const void* W, const float* ws, float xs, const void* bias,
-                    const void* R, void* Y, float out_inv, int M, int N, int K) {
+                    const void* R, void* Y, float out_inv, int M, int N, int K, const unsigned char* sx = nullptr,
+                    unsigned char* sy = nullptr) {
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
   auto x = static_cast<const unsigned char*>(X);
@@ -264,7 +340,7 @@ int launch_bias_res(hipStream_t st, const void* X, const void* W, const float* w
   auto b = static_cast<const unsigned short*>(bias);
   auto r = static_cast<const unsigned short*>(R);
 #define CODETR_FP8_LAUNCH(HB, HR) \
-  hipLaunchKernelGGL((linear_256_fp8_kernel<ACT, HB, HR, OUT8>), grid, block, 0, st, x, w, ws, xs, b, r, Y, out_inv, M, N, K, tiles_n)
+  hipLaunchKernelGGL((linear_256_fp8_kernel<ACT, HB, HR, OUT8, MX>), grid, block, 0, st, x, w, ws, xs, b, r, Y, out_inv, M, N, K, tiles_n, sx, sy)
   if (bias && R) CODETR_FP8_LAUNCH(true, true);
   else if (bias) CODETR_FP8_LAUNCH(true, false);
   else if (R) CODETR_FP8_LAUNCH(false, true);
@@ -347,9 +423,163 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const unsigned short
   }
 }
 
+// ---- MX producers: e4m3 + one e8m0 byte per (row, 32 channels), mx_scale.h layout for a consumer GEMM over these rows ----
+
+// plain cast of a 16-bit [rows, C] tensor (C % 32 == 0): a lane owns 8 consecutive channels, 4 neighbouring lanes a block
+__global__ __launch_bounds__(256) void cast_fp8mx_kernel(const s16x8* __restrict__ x, uint2* __restrict__ y,
+                                                         unsigned char* __restrict__ sy, int64_t n16, int chunks_per_row,
+                                                         int64_t MB) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = i < n16;
+  const s16x8 v = ok ? x[i] : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  float f[8], amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    f[e] = h2f((unsigned short)v[e]);
+    amax = fmaxf(amax, fabsf(f[e]));
+  }
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  if (!ok) return;
+  const unsigned sb = mx_e8m0(amax);
+  const float inv = mx_inv_scale(sb);
+  y[i] = uint2{pk_fp8(f[0] * inv, f[1] * inv) | (pk_fp8(f[2] * inv, f[3] * inv) << 16),
+               pk_fp8(f[4] * inv, f[5] * inv) | (pk_fp8(f[6] * inv, f[7] * inv) << 16)};
+  if ((i & 3) == 0) {
+    const int64_t row = i / chunks_per_row;
+    const int ch = (int)(i - row * chunks_per_row);
+    sy[mx_index(row, ch >> 2, MB)] = (unsigned char)sb;
+  }
+}
+
+// layernorm_fp8_kernel with block scales: the fp16 LayerNorm output the fp16 model would have produced, then MX-quantised
+__global__ __launch_bounds__(256) void layernorm_fp8mx_kernel(const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ gamma,
+                                                              const unsigned short* __restrict__ beta,
+                                                              unsigned char* __restrict__ y, unsigned char* __restrict__ sy,
+                                                              int64_t rows, int C, float eps, int64_t MB) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;   // (whole wave)
+  const int nch = C >> 3;  // 16-byte chunks per row (a multiple of 4: C % 32 == 0)
+  float v[8][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nch) {
+      const s16x8 r = *reinterpret_cast<const s16x8*>(x + row * C + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[c][e] = h2f((unsigned short)r[e]);
+        sum += v[c][e];
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c * 64 + lane < nch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[c][e] - mean;
+        var += d * d;
+      }
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+  const float rstd = rsqrtf(var / (float)C + eps);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int ch = c * 64 + lane;
+    const bool ok = ch < nch;   // uniform over a 4-lane block group (nch % 4 == 0)
+    float o[8], amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    if (ok) {
+      const s16x8 g = *reinterpret_cast<const s16x8*>(gamma + ch * 8);
+      const s16x8 b = *reinterpret_cast<const s16x8*>(beta + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = h2f(f2h((v[c][e] - mean) * rstd * h2f((unsigned short)g[e]) + h2f((unsigned short)b[e])));
+        amax = fmaxf(amax, fabsf(o[e]));
+      }
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    if (ok) {
+      const unsigned sb = mx_e8m0(amax);
+      const float inv = mx_inv_scale(sb);
+      const unsigned lo = pk_fp8(o[0] * inv, o[1] * inv) | (pk_fp8(o[2] * inv, o[3] * inv) << 16);
+      const unsigned hi = pk_fp8(o[4] * inv, o[5] * inv) | (pk_fp8(o[6] * inv, o[7] * inv) << 16);
+      *reinterpret_cast<uint2*>(y + row * C + ch * 8) = uint2{lo, hi};
+      if ((lane & 3) == 0) sy[mx_index(row, ch >> 2, MB)] = (unsigned char)sb;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t codetr_mx_scale_bytes(int64_t M, int64_t K) { return M > 0 && K > 0 && K % 128 == 0 ? (int64_t)mx_bytes(M, K) : CODETR_E_BADARG; }
+
+int codetr_linear_fp8mx(void* stream, const void* x8_dev, const void* x_scales_dev, const void* w8_dev,
+                        const float* w_scale_dev, const void* bias_f16_dev, const void* residual_f16_dev, void* y_dev,
+                        void* y_scales_dev, int64_t M, int64_t N, int64_t K, int act) {
+  if (!x8_dev || !x_scales_dev || !w8_dev || !w_scale_dev || !y_dev || M <= 0 || N <= 0 || K <= 0) return CODETR_E_BADARG;
+  if (K % 128 != 0 || N % 8 != 0 || act < 0 || act > 2) return CODETR_E_UNSUPPORTED;
+  const bool out8 = y_scales_dev != nullptr;
+  if (out8 && (residual_f16_dev || N % 128 != 0)) return CODETR_E_BADARG;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL || K > 0x7fffffffLL || M * N > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if ((reinterpret_cast<uintptr_t>(x8_dev) | reinterpret_cast<uintptr_t>(w8_dev) | reinterpret_cast<uintptr_t>(y_dev) |
+       reinterpret_cast<uintptr_t>(residual_f16_dev)) & 15 || (reinterpret_cast<uintptr_t>(x_scales_dev) & 7))
+    return CODETR_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto sx = static_cast<const unsigned char*>(x_scales_dev);
+  auto sy = static_cast<unsigned char*>(y_scales_dev);
+#define CODETR_FP8MX_ACT(A)                                                                                               \
+  return out8 ? launch_bias_res<A, true, true>(st, x8_dev, w8_dev, w_scale_dev, 1.0f, bias_f16_dev, residual_f16_dev,     \
+                                               y_dev, 1.0f, (int)M, (int)N, (int)K, sx, sy)                               \
+              : launch_bias_res<A, false, true>(st, x8_dev, w8_dev, w_scale_dev, 1.0f, bias_f16_dev, residual_f16_dev,    \
+                                                y_dev, 1.0f, (int)M, (int)N, (int)K, sx, sy)
+  if (act == 0) CODETR_FP8MX_ACT(0);
+  if (act == 1) CODETR_FP8MX_ACT(1);
+  CODETR_FP8MX_ACT(2);
+#undef CODETR_FP8MX_ACT
+}
+
+int codetr_cast_fp8mx_f16(void* stream, const void* x_f16_dev, void* y8_dev, void* y_scales_dev, int64_t rows, int64_t C) {
+  if (!x_f16_dev || !y8_dev || !y_scales_dev || rows < 0 || C <= 0) return CODETR_E_BADARG;
+  if (rows == 0) return 0;
+  if (C % 128 != 0 || (reinterpret_cast<uintptr_t>(x_f16_dev) & 15) || (reinterpret_cast<uintptr_t>(y8_dev) & 7))
+    return CODETR_E_UNSUPPORTED;
+  const int64_t n16 = rows * C / 8, blocks = (n16 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  hipLaunchKernelGGL(cast_fp8mx_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const s16x8*>(x_f16_dev), static_cast<uint2*>(y8_dev),
+                     static_cast<unsigned char*>(y_scales_dev), n16, (int)(C / 8), mx_blocks128(rows));
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+int codetr_layernorm_fp8mx_f16(void* stream, const void* x_f16_dev, const void* gamma_f16_dev, const void* beta_f16_dev,
+                               void* y8_dev, void* y_scales_dev, int64_t rows, int64_t C, float eps) {
+  if (!x_f16_dev || !gamma_f16_dev || !beta_f16_dev || !y8_dev || !y_scales_dev || rows < 0 || C <= 0) return CODETR_E_BADARG;
+  if (rows == 0) return 0;
+  if (C % 128 != 0 || C > 4096) return CODETR_E_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x_f16_dev) | reinterpret_cast<uintptr_t>(gamma_f16_dev) |
+       reinterpret_cast<uintptr_t>(beta_f16_dev)) & 15 || (reinterpret_cast<uintptr_t>(y8_dev) & 7))
+    return CODETR_E_BADARG;
+  const int64_t blocks = (rows + 3) / 4;
+  if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  hipLaunchKernelGGL(layernorm_fp8mx_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(x_f16_dev), static_cast<const unsigned short*>(gamma_f16_dev),
+                     static_cast<const unsigned short*>(beta_f16_dev), static_cast<unsigned char*>(y8_dev),
+                     static_cast<unsigned char*>(y_scales_dev), rows, (int)C, eps, mx_blocks128(rows));
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
 
 int codetr_linear_fp8(void* stream, const void* x8_dev, const void* w8_dev, const float* w_scale_dev, float x_scale,
                       const void* bias_f16_dev, const void* residual_f16_dev, void* y_dev, int out_is_fp8, float out_scale,

@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "codetr_hip.h"
+#include "mx_scale.h"
 
 namespace {
 
@@ -99,13 +100,15 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 
 // OUT8: the output is e4m3 = sat(f16(o) * out_inv_scale) (the operand of the fp8 proj GEMM, BASELINE config 5) instead of
 // 16-bit -- what codetr_cast_fp8_f16 would make of the 16-bit output, without that tensor's round trip
-template <class ET, int WS, bool OUT8 = false>
+// OUTMX (with OUT8): block-scaled e4m3 instead -- one e8m0 byte per (token, head) = per 32 channels, written to `out_scales`
+// in the consumer GEMM's layout (mx_scale.h); out_inv_scale is unused
+template <class ET, int WS, bool OUT8 = false, bool OUTMX = false>
 __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     const typename ET::e* __restrict__ qkv,       // [B, H*W, 3C]
     const typename ET::e* __restrict__ qkv_bias,  // [3C] (zeros if the layer has no bias)
     const typename ET::e* __restrict__ rel_bias,  // [nH, N, N]
     void* __restrict__ out_v,                     // [B, H*W, C] 16-bit, or e4m3 bytes (OUT8)
-    Geometry g, int n_problems, float out_inv_scale) {
+    Geometry g, int n_problems, float out_inv_scale, unsigned char* __restrict__ out_scales) {
   using E = typename ET::e;
   using V8 = typename ET::v8;
   using V4 = typename ET::v4;
@@ -296,7 +299,37 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
       }
     }
     // ---- normalise and store: lane holds channels 16*dt + 4*grp + r of query l15 ----
-    if (q_in && tq.valid) {
+    if constexpr (OUT8 && OUTMX) {
+      // the 32 channels of (token, head) sit in the four lanes l15 + 16 grp: block maximum by two xor-shuffles (every
+      // lane takes part; the shuffles stay outside the validity branch)
+      const float inv = 1.0f / sum;
+      float f[2][4], amax = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[dt][r] = (float)(E)(o[dt][r] * inv);
+          amax = fmaxf(amax, fabsf(f[dt][r]));
+        }
+      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      if (q_in && tq.valid) {
+        const unsigned sb = mx_e8m0(amax);
+        const float qs = mx_inv_scale(sb);
+        const size_t trow = (size_t)b * g.H * g.W + tq.token;
+        const size_t doff = trow * C + hoff + grp * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          float q4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q4[r] = __builtin_amdgcn_fmed3f(f[dt][r] * qs, -448.0f, 448.0f);
+          int w = __builtin_amdgcn_cvt_pk_fp8_f32(q4[0], q4[1], 0, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(q4[2], q4[3], w, true);
+          *reinterpret_cast<int*>(static_cast<unsigned char*>(out_v) + doff + dt * 16) = w;
+        }
+        if (grp == 0) out_scales[mx_index((int64_t)trow, head, mx_blocks128((int64_t)g.B * g.H * g.W))] = (unsigned char)sb;
+      }
+    } else if (q_in && tq.valid) {
       const float inv = 1.0f / sum;
       const size_t doff = ((size_t)b * g.H * g.W + tq.token) * C + hoff + grp * 4;
 #pragma unroll
@@ -319,23 +352,24 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   }
 }
 
-template <class ET, int WS, bool OUT8>
+template <class ET, int WS, bool OUT8, bool OUTMX = false>
 int launch_ws(hipStream_t st, const void* qkv, const void* qkv_bias, const void* rel_bias, void* out, Geometry g,
-              float out_inv_scale) {
+              float out_inv_scale, unsigned char* out_scales = nullptr) {
   const int64_t n = (int64_t)g.B * g.nWin * g.nH;
   if (n > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
-  hipLaunchKernelGGL((window_attention_kernel<ET, WS, OUT8>), dim3(blocks), dim3(kThreads), 0, st,
+  hipLaunchKernelGGL((window_attention_kernel<ET, WS, OUT8, OUTMX>), dim3(blocks), dim3(kThreads), 0, st,
                      static_cast<const typename ET::e*>(qkv), static_cast<const typename ET::e*>(qkv_bias),
-                     static_cast<const typename ET::e*>(rel_bias), out, g, (int)n, out_inv_scale);
+                     static_cast<const typename ET::e*>(rel_bias), out, g, (int)n, out_inv_scale, out_scales);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
 
-template <class ET, bool OUT8 = false>
+template <class ET, bool OUT8 = false, bool OUTMX = false>
 int window_attention_entry(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
                                 void* out_dev, int64_t B, int64_t H, int64_t W, int num_heads, int head_dim,
-                                int window_size, int shift, float out_inv_scale = 1.0f) {
+                                int window_size, int shift, float out_inv_scale = 1.0f,
+                                unsigned char* out_scales = nullptr) {
   if (!qkv_dev || !qkv_bias_dev || !rel_bias_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || num_heads <= 0)
     return CODETR_E_BADARG;
   if (head_dim != HD || shift < 0 || shift >= window_size) return CODETR_E_UNSUPPORTED;
@@ -352,10 +386,10 @@ int window_attention_entry(void* stream, const void* qkv_dev, const void* qkv_bi
   g.nWin = (g.Hp / window_size) * g.nWx;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (window_size) {
-    case 12: return launch_ws<ET, 12, OUT8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale);
-    case 8: return launch_ws<ET, 8, OUT8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale);
-    case 7: return launch_ws<ET, 7, OUT8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale);
-    case 4: return launch_ws<ET, 4, OUT8>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale);
+    case 12: return launch_ws<ET, 12, OUT8, OUTMX>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
+    case 8: return launch_ws<ET, 8, OUT8, OUTMX>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
+    case 7: return launch_ws<ET, 7, OUT8, OUTMX>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
+    case 4: return launch_ws<ET, 4, OUT8, OUTMX>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
   }
   return CODETR_E_UNSUPPORTED;
 }
@@ -377,6 +411,16 @@ int codetr_window_attention_bf16(void* stream, const void* qkv_dev, const void* 
                                  int window_size, int shift) {
   return window_attention_entry<BF16E>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, B, H, W, num_heads,
                                        head_dim, window_size, shift);
+}
+
+int codetr_window_attention_fp8mx_f16(void* stream, const void* qkv_dev, const void* qkv_bias_dev,
+                                      const void* rel_bias_dev, void* out8_dev, void* out_scales_dev, int64_t B, int64_t H,
+                                      int64_t W, int num_heads, int head_dim, int window_size, int shift) {
+  if (!out_scales_dev) return CODETR_E_BADARG;
+  if ((num_heads * (int64_t)head_dim) % 128 != 0 || (reinterpret_cast<uintptr_t>(out8_dev) & 3)) return CODETR_E_UNSUPPORTED;
+  return window_attention_entry<F16E, true, true>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out8_dev, B, H, W, num_heads,
+                                                  head_dim, window_size, shift, 1.0f,
+                                                  static_cast<unsigned char*>(out_scales_dev));
 }
 
 int codetr_window_attention_fp8out_f16(void* stream, const void* qkv_dev, const void* qkv_bias_dev,

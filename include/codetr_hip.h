@@ -332,6 +332,35 @@ int codetr_layernorm_fp8_f16(void *stream, const void *x_f16_dev, const void *ga
                              void *y8_dev, int64_t rows, int64_t C, float eps, float scale);
 
 /* ------------------------------------------------------------------------------------------
+ * The same path with MX BLOCK SCALES on the activations (no calibration, no static scale): every 32 consecutive
+ * K-elements of an activation row share one e8m0 exponent byte (2^(byte - 127)) chosen by the producer from the block's
+ * own maximum, and v_mfma_scale_f32_16x16x128_f8f6f4 applies it in hardware -- a lane's scale byte covers exactly the 32
+ * operand bytes that lane holds.  Weights keep one fp32 scale per output channel (unit block scales in the instruction).
+ *
+ * Scale tensors: codetr_mx_scale_bytes(M, K) bytes for an activation [M, K], byte of (row m, block kb = k / 32) at
+ *   (((kb >> 2) * MB + (m >> 7)) * 64 + (kb & 3) * 16 + (m & 15)) * 8 + ((m >> 4) & 7),   MB = ceil(M / 128)
+ * (the 8 bytes a lane of the GEMM needs per 128-wide k-tile are contiguous: csrc/mx_scale.h).
+ *
+ *   codetr_linear_fp8mx          y = act((x8 (*) x_scales) . w8^T * w_scale[n] + bias[n]) (+ residual); y fp16, or -- when
+ *                                y_scales_dev is given (no residual, N % 128 == 0) -- e4m3 with block scales along N, laid
+ *                                out for a consumer GEMM over the same M rows whose K is this N
+ *   codetr_cast_fp8mx_f16        x [rows, C] fp16 -> e4m3 + scales (C % 128 == 0)
+ *   codetr_layernorm_fp8mx_f16   LayerNorm (as codetr_layernorm_fp8_f16) -> e4m3 + scales (C % 128 == 0)
+ *   codetr_window_attention_fp8mx_f16  codetr_window_attention_f16 with its output as e4m3 + scales: one block per
+ *                                (token, head) -- head_dim == 32 is the MX block
+ * ------------------------------------------------------------------------------------------ */
+int64_t codetr_mx_scale_bytes(int64_t M, int64_t K);
+int codetr_linear_fp8mx(void *stream, const void *x8_dev, const void *x_scales_dev, const void *w8_dev,
+                        const float *w_scale_dev, const void *bias_f16_dev, const void *residual_f16_dev, void *y_dev,
+                        void *y_scales_dev, int64_t M, int64_t N, int64_t K, int act);
+int codetr_cast_fp8mx_f16(void *stream, const void *x_f16_dev, void *y8_dev, void *y_scales_dev, int64_t rows, int64_t C);
+int codetr_layernorm_fp8mx_f16(void *stream, const void *x_f16_dev, const void *gamma_f16_dev, const void *beta_f16_dev,
+                               void *y8_dev, void *y_scales_dev, int64_t rows, int64_t C, float eps);
+int codetr_window_attention_fp8mx_f16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
+                                      const void *rel_bias_dev, void *out8_dev, void *out_scales_dev, int64_t B, int64_t H,
+                                      int64_t W, int num_heads, int head_dim, int window_size, int shift);
+
+/* ------------------------------------------------------------------------------------------
  * Small fp16 element-wise / gather kernels of the decoder and the detection head (csrc/small_ops.hip): the last
  * ATen launches of the fp16 forward, bit-identical to the ATen formulation (one fp16 rounding per operation).
  *   codetr_add_f16           out[i] = a[i % a_period] + b[i]  (`query + query_pos`, reference transformer_mmcv.py:400-404;

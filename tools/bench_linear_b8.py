@@ -29,4 +29,8 @@ if "--fp8" in sys.argv:
         out = torch.empty(M, N, dtype=FP8 if out8 else torch.float16, device="cuda")
         tn = timeit(lambda: _cabi.linear_fp8(x8, w8, ws, 0.01, b, r, act, out, 0.05 if out8 else 0.0))
         fl = 2.0 * M * N * K
-        print(f"fp8 {name:12s} M={M:8d} N={N:5d} K={K:5d}  {tn*1e6:8.1f} us {fl/tn/1e12:7.1f} TF/s  (out {'e4m3' if out8 else 'f16'})")
+        # the same GEMM with MX block scales on the activation (and, for fc1, on the e4m3 output)
+        sx = torch.full((_cabi.mx_scale_bytes(M, K),), 0x7F, dtype=torch.uint8, device="cuda")
+        sy = torch.empty(_cabi.mx_scale_bytes(M, N), dtype=torch.uint8, device="cuda") if out8 else None
+        tm = timeit(lambda: _cabi.linear_fp8mx(x8, sx, w8, ws, b, r, act, out, sy))
+        print(f"fp8 {name:12s} M={M:8d} N={N:5d} K={K:5d}  static {tn*1e6:8.1f} us {fl/tn/1e12:7.1f} TF/s | MX {tm*1e6:8.1f} us {fl/tm/1e12:7.1f} TF/s  (out {'e4m3' if out8 else 'f16'})")
