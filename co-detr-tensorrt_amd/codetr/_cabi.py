@@ -69,10 +69,14 @@ SIGNATURES = {
     "codetr_patch_im2col_b16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp]),
     "codetr_linear_variant": (_cp, [_i64, _i64, _i64, _i32, _i32, _i32]),
     "codetr_add_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64]),
+    "codetr_add_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64]),
     "codetr_sigmoid_f16": (_i32, [_vp, _vp, _vp, _i64]),
+    "codetr_sigmoid_bf16": (_i32, [_vp, _vp, _vp, _i64]),
     "codetr_gather_rows_b16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64]),
     "codetr_decode_boxes_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, ctypes.c_float, ctypes.c_float]),
+    "codetr_decode_boxes_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, ctypes.c_float, ctypes.c_float]),
     "codetr_valid_ratios_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32]),
+    "codetr_valid_ratios_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32]),
     "codetr_linear_fp8": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i32, ctypes.c_float, _i64, _i64, _i64,
                                  _i32]),
     "codetr_cast_fp8_f16": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float]),
@@ -81,8 +85,12 @@ SIGNATURES = {
     "codetr_linear_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32]),
     "codetr_query_sine_embed_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp,
                                            _vp]),
+    "codetr_query_sine_embed_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, _i32, _vp, _vp,
+                                           _vp]),
     "codetr_encoder_geometry_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "codetr_encoder_geometry_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "codetr_row_max_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
+    "codetr_row_max_bf16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
     "codetr_preprocess_u8_f16": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "codetr_preprocess_u8_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "codetr_batched_nms_f32": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float, _vp]),
@@ -290,7 +298,8 @@ def query_sine_embed(ref, valid_ratios, pos_feat, temperature=10000.0, apply_sig
     ref_in = torch.empty((B, Nq, L, d), dtype=ref.dtype, device=ref.device)
     ref_in32 = torch.empty((B, Nq, L, d), dtype=torch.float32, device=ref.device) if valid_ratios32 is not None else None
     embed = torch.empty((B, Nq, d * pos_feat), dtype=ref.dtype, device=ref.device)
-    rc = load().codetr_query_sine_embed_f16(current_stream_ptr(ref.device), ref.data_ptr(), valid_ratios.data_ptr(),
+    fn = load().codetr_query_sine_embed_bf16 if ref.dtype == torch.bfloat16 else load().codetr_query_sine_embed_f16
+    rc = fn(current_stream_ptr(ref.device), ref.data_ptr(), valid_ratios.data_ptr(),
                                             valid_ratios32.data_ptr() if valid_ratios32 is not None else None, B, Nq,
                                             d, L, pos_feat, float(temperature), 1 if apply_sigmoid else 0,
                                             ref_in.data_ptr(), ref_in32.data_ptr() if ref_in32 is not None else None,
@@ -327,12 +336,14 @@ def encoder_geometry(valid_ratios, mask_flat, shapes):
     B, S = mask_flat.shape
     L = len(shapes)
     dev = mask_flat.device
-    ref = torch.empty((B, S, 2), dtype=torch.float16, device=dev)
-    ref_lvl = torch.empty((B, S, L, 2), dtype=torch.float16, device=dev)
-    prop = torch.empty((B, S, 4), dtype=torch.float16, device=dev)
+    dt = valid_ratios.dtype
+    ref = torch.empty((B, S, 2), dtype=dt, device=dev)
+    ref_lvl = torch.empty((B, S, L, 2), dtype=dt, device=dev)
+    prop = torch.empty((B, S, 4), dtype=dt, device=dev)
     state = torch.empty((B, S), dtype=torch.uint8, device=dev)
     hw = (ctypes.c_int64 * (2 * L))(*[int(v) for s in shapes for v in s])
-    rc = load().codetr_encoder_geometry_f16(current_stream_ptr(dev), valid_ratios.data_ptr(), mask_flat.data_ptr(), B, L, hw,
+    fn = load().codetr_encoder_geometry_bf16 if valid_ratios.dtype == torch.bfloat16 else load().codetr_encoder_geometry_f16
+    rc = fn(current_stream_ptr(dev), valid_ratios.data_ptr(), mask_flat.data_ptr(), B, L, hw,
                                             ref.data_ptr(), ref_lvl.data_ptr(), prop.data_ptr(), state.data_ptr())
     check(rc, "codetr_encoder_geometry_f16")
     return ref, ref_lvl, prop, state
@@ -342,7 +353,8 @@ def row_max(x2d):
     CALLS["row_max"] += 1
     rows, C = x2d.shape
     out = torch.empty((rows,), dtype=x2d.dtype, device=x2d.device)
-    rc = load().codetr_row_max_f16(current_stream_ptr(x2d.device), x2d.data_ptr(), out.data_ptr(), rows, C)
+    fn = load().codetr_row_max_bf16 if x2d.dtype == torch.bfloat16 else load().codetr_row_max_f16
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), out.data_ptr(), rows, C)
     check(rc, "codetr_row_max_f16")
     return out
 
@@ -828,14 +840,15 @@ def layernorm_fp8(x2d, weight, bias, eps, scale, out2d):
 # ---- small element-wise / gather kernels (csrc/small_ops.hip) -------------------------------------------------
 def add_f16(a, b, out, a_period):
     CALLS["small_ops"] += 1
-    check(load().codetr_add_f16(current_stream_ptr(b.device), a.data_ptr(), b.data_ptr(), out.data_ptr(), b.numel(), a_period),
-          "codetr_add_f16")
+    fn = load().codetr_add_bf16 if b.dtype == torch.bfloat16 else load().codetr_add_f16
+    check(fn(current_stream_ptr(b.device), a.data_ptr(), b.data_ptr(), out.data_ptr(), b.numel(), a_period), "codetr_add")
     return out
 
 
 def sigmoid_f16(x, out):
     CALLS["small_ops"] += 1
-    check(load().codetr_sigmoid_f16(current_stream_ptr(x.device), x.data_ptr(), out.data_ptr(), x.numel()), "codetr_sigmoid_f16")
+    fn = load().codetr_sigmoid_bf16 if x.dtype == torch.bfloat16 else load().codetr_sigmoid_f16
+    check(fn(current_stream_ptr(x.device), x.data_ptr(), out.data_ptr(), x.numel()), "codetr_sigmoid")
     return out
 
 
@@ -850,7 +863,8 @@ def gather_rows(src, idx, out):
 def decode_boxes(coords_unact, idx, num_classes, img_w, img_h, boxes, labels):
     CALLS["small_ops"] += 1
     B, Nq, _ = coords_unact.shape
-    check(load().codetr_decode_boxes_f16(current_stream_ptr(idx.device), coords_unact.data_ptr(), idx.data_ptr(), boxes.data_ptr(),
+    fn = load().codetr_decode_boxes_bf16 if coords_unact.dtype == torch.bfloat16 else load().codetr_decode_boxes_f16
+    check(fn(current_stream_ptr(idx.device), coords_unact.data_ptr(), idx.data_ptr(), boxes.data_ptr(),
                                          labels.data_ptr(), B, Nq, idx.shape[1], num_classes, float(img_w), float(img_h)),
           "codetr_decode_boxes_f16")
 
@@ -858,6 +872,7 @@ def decode_boxes(coords_unact, idx, num_classes, img_w, img_h, boxes, labels):
 def valid_ratios(counts, level_wh, out, out32=None):
     CALLS["small_ops"] += 1
     B, L, _ = counts.shape
-    check(load().codetr_valid_ratios_f16(current_stream_ptr(counts.device), counts.data_ptr(), level_wh.data_ptr(), out.data_ptr(),
-                                         out32.data_ptr() if out32 is not None else None, B, L), "codetr_valid_ratios_f16")
+    fn = load().codetr_valid_ratios_bf16 if level_wh.dtype == torch.bfloat16 else load().codetr_valid_ratios_f16
+    check(fn(current_stream_ptr(counts.device), counts.data_ptr(), level_wh.data_ptr(), out.data_ptr(),
+             out32.data_ptr() if out32 is not None else None, B, L), "codetr_valid_ratios")
     return out

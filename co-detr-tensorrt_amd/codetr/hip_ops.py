@@ -343,7 +343,7 @@ def groupnorm_tokens_into(x, gamma, beta, groups, eps, dest, row_start):
 
 
 def query_sine_embed_supported(ref, valid_ratios, pos_feat):
-    return (ref.is_cuda and ref.dtype == torch.float16 and valid_ratios.dtype == torch.float16
+    return (ref.is_cuda and ref.dtype in (torch.float16, torch.bfloat16) and valid_ratios.dtype == ref.dtype
             and ref.shape[-1] in (2, 4) and pos_feat % 8 == 0 and valid_ratios.shape[1] <= ref.shape[-1] * pos_feat // 8)
 
 
@@ -366,8 +366,8 @@ def encoder_geometry(valid_ratios, mask_flat, shapes):
     """Reference points, their per-level scaling, two-stage proposals (already masked) and the keep / drop state of
     every encoder token in one launch (csrc/encoder_geometry.hip); f16 valid_ratios [B,L,2], mask_flat [B,S] bool."""
     _gpu(mask_flat, "encoder_geometry")
-    if valid_ratios.dtype != torch.float16:
-        raise RuntimeError("encoder_geometry is the f16 inference path; fp32 parity runs use the ATen formulation")
+    if valid_ratios.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("encoder_geometry is the 16-bit inference path; fp32 parity runs use the ATen formulation")
     with torch.cuda.device(mask_flat.device):
         return _cabi.encoder_geometry(valid_ratios.contiguous(), mask_flat.contiguous(),
                                       [tuple(int(v) for v in s) for s in shapes])
@@ -376,7 +376,7 @@ def encoder_geometry(valid_ratios, mask_flat, shapes):
 def row_max(x):
     """x.max(-1)[0] for a dense f16 tensor (NaN propagates)"""
     _gpu(x, "row_max")
-    if x.dtype != torch.float16 or not x.is_contiguous():
+    if x.dtype not in (torch.float16, torch.bfloat16) or not x.is_contiguous():
         return x.max(-1)[0]
     with torch.cuda.device(x.device):
         return _cabi.row_max(x.view(-1, x.shape[-1])).view(x.shape[:-1])
@@ -894,7 +894,8 @@ def layer_norm_fp8(x, weight, bias, eps, scale):
 # fp32 / bf16 parity runs and autograd
 # ---------------------------------------------------------------------------------------------------------------
 def _native16(*ts):
-    return (not torch.is_grad_enabled()) and all(t.is_cuda and t.dtype == torch.float16 and t.data_ptr() % 16 == 0 for t in ts)
+    return ((not torch.is_grad_enabled()) and ts[0].dtype in (torch.float16, torch.bfloat16)
+            and all(t.is_cuda and t.dtype == ts[0].dtype and t.data_ptr() % 16 == 0 for t in ts))
 
 
 def add(a, b):
@@ -959,7 +960,7 @@ def valid_ratios(counts, level_wh):
     _gpu(counts, "valid_ratios")
     if _native16(level_wh) and counts.dtype == torch.float32 and counts.is_contiguous() and level_wh.is_contiguous():
         out = torch.empty(counts.shape, dtype=level_wh.dtype, device=counts.device)
-        out32 = torch.empty(counts.shape, dtype=torch.float32, device=counts.device) if level_wh.dtype == torch.float16 else None
+        out32 = torch.empty(counts.shape, dtype=torch.float32, device=counts.device)
         with torch.cuda.device(counts.device):
             _cabi.valid_ratios(counts, level_wh, out, out32)
         if out32 is not None:

@@ -381,7 +381,7 @@ class CoDinoTransformer(nn.Module):
             valid_ratios = hip_ops.valid_ratios(valid_counts, _level_wh(shapes, feat.dtype, dev))  # [B,L,2]
         else:
             valid_ratios = torch.stack([get_valid_ratio(m, dtype=feat.dtype) for m in mlvl_masks], 1)  # [B,L,2]
-        native_geom = feat.is_cuda and feat.dtype == torch.float16 and mask.dtype == torch.bool
+        native_geom = feat.is_cuda and feat.dtype in (torch.float16, torch.bfloat16) and mask.dtype == torch.bool
         if native_geom:
             # reference points, per-level scaling, masked proposals and the keep / drop state of every token: one launch
             reference_points, ref_by_level, proposals, row_state = hip_ops.encoder_geometry(valid_ratios, mask, shapes)

@@ -28,16 +28,41 @@ struct Levels {
   int h[kMaxLevels], w[kMaxLevels];
   int64_t start[kMaxLevels];
 };
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float h_round(float v) { return (float)(_Float16)v; }
+// 16-bit storage <-> float; BF: bfloat16 (the bf16 model's instantiations: same formulas, that type's roundings and its
+// finfo.max), else fp16
+template <bool BF>
+__device__ __forceinline__ float ld16(unsigned short bits) {
+  if (BF) return __uint_as_float(((unsigned)bits) << 16);
+  _Float16 h;
+  __builtin_memcpy(&h, &bits, 2);
+  return (float)h;
+}
+template <bool BF>
+__device__ __forceinline__ unsigned short st16(float v) {
+  if (BF) {
+    const unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+  _Float16 h = (_Float16)v;
+  unsigned short bits;
+  __builtin_memcpy(&bits, &h, 2);
+  return bits;
+}
+template <bool BF>
+__device__ __forceinline__ float h_round(float v) { return ld16<BF>(st16<BF>(v)); }
 
-__global__ __launch_bounds__(256) void encoder_geometry_kernel(const _Float16* __restrict__ valid_ratios,
+template <bool BF>
+__global__ __launch_bounds__(256) void encoder_geometry_kernel(const unsigned short* __restrict__ valid_ratios,
                                                                const unsigned char* __restrict__ mask_flat, Levels lv,
                                                                int L, int64_t S, int64_t total,
-                                                               _Float16* __restrict__ ref, _Float16* __restrict__ ref_lvl,
-                                                               _Float16* __restrict__ proposals,
+                                                               unsigned short* __restrict__ ref,
+                                                               unsigned short* __restrict__ ref_lvl,
+                                                               unsigned short* __restrict__ proposals,
                                                                unsigned char* __restrict__ row_state) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -48,40 +73,38 @@ __global__ __launch_bounds__(256) void encoder_geometry_kernel(const _Float16* _
   const int r = (int)(s - lv.start[l]);
   const int W = lv.w[l], H = lv.h[l];
   const int y = r / W, x = r - y * W;
-  const _Float16* vr = valid_ratios + (size_t)b * L * 2;
-  const float rx = h_round(((float)x + 0.5f) / h_round((float)vr[2 * l] * (float)W));
-  const float ry = h_round(((float)y + 0.5f) / h_round((float)vr[2 * l + 1] * (float)H));
-  *reinterpret_cast<f16x2*>(ref + i * 2) = f16x2{(_Float16)rx, (_Float16)ry};
+  const unsigned short* vr = valid_ratios + (size_t)b * L * 2;
+  const float rx = h_round<BF>(((float)x + 0.5f) / h_round<BF>(ld16<BF>(vr[2 * l]) * (float)W));
+  const float ry = h_round<BF>(((float)y + 0.5f) / h_round<BF>(ld16<BF>(vr[2 * l + 1]) * (float)H));
+  *reinterpret_cast<u16x2*>(ref + i * 2) = u16x2{st16<BF>(rx), st16<BF>(ry)};
   for (int k = 0; k < L; ++k)
-    *reinterpret_cast<f16x2*>(ref_lvl + (i * L + k) * 2) =
-        f16x2{(_Float16)(rx * (float)vr[2 * k]), (_Float16)(ry * (float)vr[2 * k + 1])};
-  const float wl = h_round(0.05f * (float)(1 << l));
+    *reinterpret_cast<u16x2*>(ref_lvl + (i * L + k) * 2) =
+        u16x2{st16<BF>(rx * ld16<BF>(vr[2 * k])), st16<BF>(ry * ld16<BF>(vr[2 * k + 1]))};
+  const float wl = h_round<BF>(0.05f * (float)(1 << l));
   const float p[4] = {rx, ry, wl, wl};
-  const float lo = h_round(-4.6f), hi = h_round(4.6f);
+  const float lo = h_round<BF>(-4.6f), hi = h_round<BF>(4.6f);
   bool keep = mask_flat[i] == 0, finite = true;
-  f16x4 o;
+  float of[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const _Float16 q = (_Float16)logf(p[k] / (1.0f - p[k]));
-    const float qf = (float)q;
+    const float qf = h_round<BF>(logf(p[k] / (1.0f - p[k])));
     keep = keep && qf > lo && qf < hi;  // NaN compares false, as in the reference
     finite = finite && (qf - qf == 0.0f);
-    o[k] = q;
+    of[k] = qf;
   }
   if (!keep) {
     // prop * 0 + 1 * finfo.max, element-wise: finite -> max, inf / NaN -> NaN
+    const float fmax_t = BF ? __uint_as_float(0x7f7f0000u) : 65504.0f;   // finfo(bf16).max / finfo(f16).max
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float qf = (float)o[k];
-      o[k] = (qf - qf == 0.0f) ? (_Float16)65504.0f : (_Float16)__builtin_nanf("");
-    }
+    for (int k = 0; k < 4; ++k) of[k] = (of[k] - of[k] == 0.0f) ? fmax_t : __builtin_nanf("");
   }
-  *reinterpret_cast<f16x4*>(proposals + i * 4) = o;
+  *reinterpret_cast<u16x4*>(proposals + i * 4) = u16x4{st16<BF>(of[0]), st16<BF>(of[1]), st16<BF>(of[2]), st16<BF>(of[3])};
   row_state[i] = keep ? 0 : 2;
 }
 
 // out[r] = max over the C columns of x[r, :] (NaN wins, as torch.max): the two-stage ranking score of a token
-__global__ __launch_bounds__(256) void row_max_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ out,
+template <bool BF>
+__global__ __launch_bounds__(256) void row_max_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
                                                       int64_t rows, int C) {
   // 16 lanes per row, 8 columns per lane per step
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -89,21 +112,20 @@ __global__ __launch_bounds__(256) void row_max_kernel(const _Float16* __restrict
   float m = -__builtin_inff();
   bool nan = false;
   if (row < rows) {
-    const _Float16* xr = x + row * C;
+    const unsigned short* xr = x + row * C;
     if ((C & 7) == 0) {
       for (int c = sub * 8; c < C; c += 128) {
-        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-        const f16x8 v = *reinterpret_cast<const f16x8*>(xr + c);
+        const u16x8 v = *reinterpret_cast<const u16x8*>(xr + c);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float f = (float)v[e];
+          const float f = ld16<BF>(v[e]);
           nan = nan || f != f;
           m = f > m ? f : m;
         }
       }
     } else {
       for (int c = sub; c < C; c += 16) {
-        const float f = (float)xr[c];
+        const float f = ld16<BF>(xr[c]);
         nan = nan || f != f;
         m = f > m ? f : m;
       }
@@ -116,14 +138,16 @@ __global__ __launch_bounds__(256) void row_max_kernel(const _Float16* __restrict
     m = m2 > m ? m2 : m;
     nan = nan || n2;
   }
-  if (row < rows && sub == 0) out[row] = nan ? (_Float16)__builtin_nanf("") : (_Float16)m;
+  if (row < rows && sub == 0) out[row] = st16<BF>(nan ? __builtin_nanf("") : m);
 }
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int codetr_encoder_geometry_f16(void* stream, const void* valid_ratios_dev, const void* mask_flat_dev, int64_t B,
+
+template <bool BF>
+int encoder_geometry_impl(void* stream, const void* valid_ratios_dev, const void* mask_flat_dev, int64_t B,
                                 int num_levels, const int64_t* level_shapes_host, void* reference_points_dev,
                                 void* reference_by_level_dev, void* proposals_dev, void* row_state_dev) {
   if (!valid_ratios_dev || !mask_flat_dev || !level_shapes_host || !reference_points_dev || !reference_by_level_dev ||
@@ -143,23 +167,47 @@ int codetr_encoder_geometry_f16(void* stream, const void* valid_ratios_dev, cons
   }
   const int64_t total = B * S;
   if ((total + 255) / 256 > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  hipLaunchKernelGGL(encoder_geometry_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const _Float16*>(valid_ratios_dev),
+  hipLaunchKernelGGL(encoder_geometry_kernel<BF>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(valid_ratios_dev),
                      static_cast<const unsigned char*>(mask_flat_dev), lv, num_levels, S, total,
-                     static_cast<_Float16*>(reference_points_dev), static_cast<_Float16*>(reference_by_level_dev),
-                     static_cast<_Float16*>(proposals_dev), static_cast<unsigned char*>(row_state_dev));
+                     static_cast<unsigned short*>(reference_points_dev), static_cast<unsigned short*>(reference_by_level_dev),
+                     static_cast<unsigned short*>(proposals_dev), static_cast<unsigned char*>(row_state_dev));
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
 
-int codetr_row_max_f16(void* stream, const void* x_dev, void* out_dev, int64_t rows, int64_t C) {
+template <bool BF>
+int row_max_impl(void* stream, const void* x_dev, void* out_dev, int64_t rows, int64_t C) {
   if (!x_dev || !out_dev || rows <= 0 || C <= 0) return CODETR_E_BADARG;
   if (C > 0x7fffffffLL || (rows * 16 + 255) / 256 > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  hipLaunchKernelGGL(row_max_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const _Float16*>(x_dev), static_cast<_Float16*>(out_dev),
+  hipLaunchKernelGGL(row_max_kernel<BF>, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(x_dev), static_cast<unsigned short*>(out_dev),
                      rows, (int)C);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_encoder_geometry_f16(void* stream, const void* valid_ratios_dev, const void* mask_flat_dev, int64_t B,
+                                int num_levels, const int64_t* level_shapes_host, void* reference_points_dev,
+                                void* reference_by_level_dev, void* proposals_dev, void* row_state_dev) {
+  return encoder_geometry_impl<false>(stream, valid_ratios_dev, mask_flat_dev, B, num_levels, level_shapes_host,
+                                      reference_points_dev, reference_by_level_dev, proposals_dev, row_state_dev);
+}
+int codetr_encoder_geometry_bf16(void* stream, const void* valid_ratios_dev, const void* mask_flat_dev, int64_t B,
+                                 int num_levels, const int64_t* level_shapes_host, void* reference_points_dev,
+                                 void* reference_by_level_dev, void* proposals_dev, void* row_state_dev) {
+  return encoder_geometry_impl<true>(stream, valid_ratios_dev, mask_flat_dev, B, num_levels, level_shapes_host,
+                                     reference_points_dev, reference_by_level_dev, proposals_dev, row_state_dev);
+}
+int codetr_row_max_f16(void* stream, const void* x_dev, void* out_dev, int64_t rows, int64_t C) {
+  return row_max_impl<false>(stream, x_dev, out_dev, rows, C);
+}
+int codetr_row_max_bf16(void* stream, const void* x_dev, void* out_dev, int64_t rows, int64_t C) {
+  return row_max_impl<true>(stream, x_dev, out_dev, rows, C);
 }
 
 }  // extern "C"

@@ -21,13 +21,35 @@
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void query_sine_embed_kernel(const _Float16* __restrict__ ref,
-                                                               const _Float16* __restrict__ valid_ratios,
+// 16-bit storage <-> float; BF: bfloat16, else fp16
+template <bool BF>
+__device__ __forceinline__ float ld16(unsigned short bits) {
+  if (BF) return __uint_as_float(((unsigned)bits) << 16);
+  _Float16 h;
+  __builtin_memcpy(&h, &bits, 2);
+  return (float)h;
+}
+template <bool BF>
+__device__ __forceinline__ unsigned short st16(float v) {
+  if (BF) {
+    const unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+  _Float16 h = (_Float16)v;
+  unsigned short bits;
+  __builtin_memcpy(&bits, &h, 2);
+  return bits;
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void query_sine_embed_kernel(const unsigned short* __restrict__ ref,
+                                                               const unsigned short* __restrict__ valid_ratios,
                                                                const float* __restrict__ valid_ratios32,
-                                                               _Float16* __restrict__ ref_in, float* __restrict__ ref_in32,
-                                                               _Float16* __restrict__ embed,
+                                                               unsigned short* __restrict__ ref_in, float* __restrict__ ref_in32,
+                                                               unsigned short* __restrict__ embed,
                                                                int64_t rows, int Nq, int ref_dim, int L, int F,
                                                                float log2_temperature, int apply_sigmoid) {
   const int chunks = ref_dim * F / 8;
@@ -38,41 +60,43 @@ __global__ __launch_bounds__(256) void query_sine_embed_kernel(const _Float16* _
   const int b = (int)(row / Nq);
   float s[4], s32[4];
   for (int k = 0; k < ref_dim; ++k) {
-    float v = (float)ref[row * ref_dim + k];
+    float v = ld16<BF>(ref[row * ref_dim + k]);
     s32[k] = apply_sigmoid ? 1.0f / (1.0f + expf(-v)) : v;
-    if (apply_sigmoid) v = (float)(_Float16)(1.0f / (1.0f + __expf(-v)));
+    if (apply_sigmoid) v = ld16<BF>(st16<BF>(1.0f / (1.0f + __expf(-v))));
     s[k] = v;
   }
-  const _Float16* vr = valid_ratios + (size_t)b * L * 2;
+  const unsigned short* vr = valid_ratios + (size_t)b * L * 2;
   const float* vr32 = valid_ratios32 ? valid_ratios32 + (size_t)b * L * 2 : nullptr;
   // level rows of ref_in: lanes c = 0..L-1 of this query write one level each
   if (c < L)
     for (int k = 0; k < ref_dim; ++k) {
-      ref_in[(row * L + c) * ref_dim + k] = (_Float16)(s[k] * (float)vr[c * 2 + (k & 1)]);
+      ref_in[(row * L + c) * ref_dim + k] = st16<BF>(s[k] * ld16<BF>(vr[c * 2 + (k & 1)]));
       if (ref_in32) ref_in32[(row * L + c) * ref_dim + k] = s32[k] * vr32[c * 2 + (k & 1)];
     }
   const int j = (c * 8) / F;                          // coordinate block of this chunk
   const int coord = j == 0 ? 1 : (j == 1 ? 0 : j);    // (y, x, w, h)
   const float v0 = ref_in32 ? s32[coord] * vr32[coord & 1]
-                            : (float)(_Float16)(s[coord] * (float)vr[coord & 1]);  // ref_in[b, q, 0, coord]
+                            : ld16<BF>(st16<BF>(s[coord] * ld16<BF>(vr[coord & 1])));  // ref_in[b, q, 0, coord]
   const float e = v0 * 6.283185307179586f;
   const int ch0 = c * 8 - j * F;
-  f16x8 o;
+  u16x8 o;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int f = (ch0 >> 1) + p;
     const float rev = e * __builtin_amdgcn_exp2f(-log2_temperature * (2.0f * (float)f / (float)F)) * 0.15915494309189535f;
-    o[2 * p] = (_Float16)__builtin_amdgcn_sinf(rev);  // v_sin_f32 on revolutions (angle <= 2 pi here)
-    o[2 * p + 1] = (_Float16)__builtin_amdgcn_cosf(rev);
+    o[2 * p] = st16<BF>(__builtin_amdgcn_sinf(rev));  // v_sin_f32 on revolutions (angle <= 2 pi here)
+    o[2 * p + 1] = st16<BF>(__builtin_amdgcn_cosf(rev));
   }
-  *reinterpret_cast<f16x8*>(embed + row * (int64_t)(ref_dim * F) + c * 8) = o;
+  *reinterpret_cast<u16x8*>(embed + row * (int64_t)(ref_dim * F) + c * 8) = o;
 }
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int codetr_query_sine_embed_f16(void* stream, const void* ref_dev, const void* valid_ratios_dev,
+
+template <bool BF>
+int query_sine_embed_impl(void* stream, const void* ref_dev, const void* valid_ratios_dev,
                                 const float* valid_ratios32_dev, int64_t B, int64_t Nq, int ref_dim, int num_levels,
                                 int pos_feat, float temperature, int apply_sigmoid, void* ref_in_dev, float* ref_in32_dev,
                                 void* embed_dev) {
@@ -83,13 +107,32 @@ int codetr_query_sine_embed_f16(void* stream, const void* ref_dev, const void* v
     return CODETR_E_UNSUPPORTED;
   if (B * Nq > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   const int64_t threads = B * Nq * (ref_dim * pos_feat / 8);
-  hipLaunchKernelGGL(query_sine_embed_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const _Float16*>(ref_dev),
-                     static_cast<const _Float16*>(valid_ratios_dev), valid_ratios32_dev, static_cast<_Float16*>(ref_in_dev),
-                     ref_in32_dev, static_cast<_Float16*>(embed_dev), B * Nq, (int)Nq, ref_dim, num_levels, pos_feat, log2f(temperature),
+  hipLaunchKernelGGL(query_sine_embed_kernel<BF>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(ref_dev),
+                     static_cast<const unsigned short*>(valid_ratios_dev), valid_ratios32_dev, static_cast<unsigned short*>(ref_in_dev),
+                     ref_in32_dev, static_cast<unsigned short*>(embed_dev), B * Nq, (int)Nq, ref_dim, num_levels, pos_feat, log2f(temperature),
                      apply_sigmoid);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // namespace
+
+extern "C" {
+
+int codetr_query_sine_embed_f16(void* stream, const void* ref_dev, const void* valid_ratios_dev,
+                                const float* valid_ratios32_dev, int64_t B, int64_t Nq, int ref_dim, int num_levels,
+                                int pos_feat, float temperature, int apply_sigmoid, void* ref_in_dev, float* ref_in32_dev,
+                                void* embed_dev) {
+  return query_sine_embed_impl<false>(stream, ref_dev, valid_ratios_dev, valid_ratios32_dev, B, Nq, ref_dim, num_levels,
+                                      pos_feat, temperature, apply_sigmoid, ref_in_dev, ref_in32_dev, embed_dev);
+}
+int codetr_query_sine_embed_bf16(void* stream, const void* ref_dev, const void* valid_ratios_dev,
+                                 const float* valid_ratios32_dev, int64_t B, int64_t Nq, int ref_dim, int num_levels,
+                                 int pos_feat, float temperature, int apply_sigmoid, void* ref_in_dev, float* ref_in32_dev,
+                                 void* embed_dev) {
+  return query_sine_embed_impl<true>(stream, ref_dev, valid_ratios_dev, valid_ratios32_dev, B, Nq, ref_dim, num_levels,
+                                     pos_feat, temperature, apply_sigmoid, ref_in_dev, ref_in32_dev, embed_dev);
 }
 
 }  // extern "C"

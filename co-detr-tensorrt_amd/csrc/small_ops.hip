@@ -15,20 +15,31 @@ namespace {
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+// 16-bit storage <-> float; BF: bfloat16 (the bf16 model's instantiations), else fp16
+template <bool BF>
 __device__ __forceinline__ float h2f(unsigned short bits) {
+  if (BF) return __uint_as_float(((unsigned)bits) << 16);
   _Float16 h;
   __builtin_memcpy(&h, &bits, 2);
   return (float)h;
 }
+template <bool BF>
 __device__ __forceinline__ unsigned short f2h(float v) {
+  if (BF) {
+    const unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
   _Float16 h = (_Float16)v;
   unsigned short bits;
   __builtin_memcpy(&bits, &h, 2);
   return bits;
 }
-__device__ __forceinline__ float rh(float v) { return h2f(f2h(v)); }  // round to fp16, keep as float
+template <bool BF>
+__device__ __forceinline__ float rh(float v) { return h2f<BF>(f2h<BF>(v)); }  // round to the storage type, keep as float
 
 // out[i] = a[i % a_period] + b[i]   (a_period = n: plain add; a_period < n: `a` broadcast over the leading dimension)
+template <bool BF>
 __global__ __launch_bounds__(256) void add_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
                                                   unsigned short* __restrict__ out, int64_t n8, int64_t period8) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -37,15 +48,16 @@ __global__ __launch_bounds__(256) void add_kernel(const unsigned short* __restri
   const s16x8 vb = *reinterpret_cast<const s16x8*>(b + i * 8);
   s16x8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (short)f2h(h2f((unsigned short)va[e]) + h2f((unsigned short)vb[e]));
+  for (int e = 0; e < 8; ++e) o[e] = (short)f2h<BF>(h2f<BF>((unsigned short)va[e]) + h2f<BF>((unsigned short)vb[e]));
   *reinterpret_cast<s16x8*>(out + i * 8) = o;
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256) void sigmoid_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ out,
                                                       int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  out[i] = f2h(1.0f / (1.0f + expf(-h2f(x[i]))));
+  out[i] = f2h<BF>(1.0f / (1.0f + expf(-h2f<BF>(x[i]))));
 }
 
 // out[b, k, :] = src[b, idx[b, k], :]   (16-bit elements, C % 8 == 0 or C == 4)
@@ -69,6 +81,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned short* 
 //   q = idx / C, label = idx % C, (cx, cy, w, h) = sigmoid(coords_unact[b, q]) (fp16), xyxy = (cx - 0.5 w, cy - 0.5 h,
 //   cx + 0.5 w, cy + 0.5 h), scaled by (W, H, W, H), clamped to [0, W] x [0, H]; every step rounded to fp16 like the
 //   ATen sequence sigmoid / mul / sub / add / cat / mul / clamp / minimum.
+template <bool BF>
 __global__ __launch_bounds__(256) void decode_boxes_kernel(const unsigned short* __restrict__ coords_unact,
                                                            const int64_t* __restrict__ idx, unsigned short* __restrict__ boxes,
                                                            int64_t* __restrict__ labels, int64_t B, int64_t Nq, int64_t K,
@@ -81,41 +94,44 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const unsigned short*
   q = q < 0 ? 0 : (q >= Nq ? Nq - 1 : q);
   const uint2 raw = *reinterpret_cast<const uint2*>(coords_unact + (b * Nq + q) * 4);
   float c[4];
-  c[0] = rh(1.0f / (1.0f + expf(-h2f((unsigned short)(raw.x & 0xffffu)))));
-  c[1] = rh(1.0f / (1.0f + expf(-h2f((unsigned short)(raw.x >> 16)))));
-  c[2] = rh(1.0f / (1.0f + expf(-h2f((unsigned short)(raw.y & 0xffffu)))));
-  c[3] = rh(1.0f / (1.0f + expf(-h2f((unsigned short)(raw.y >> 16)))));
-  const float hw = rh(0.5f * c[2]), hh = rh(0.5f * c[3]);
-  float v[4] = {rh(c[0] - hw), rh(c[1] - hh), rh(c[0] + hw), rh(c[1] + hh)};
-  const float Wh = rh(Wimg), Hh = rh(Himg);   // the scale tensor is fp16 too
+  c[0] = rh<BF>(1.0f / (1.0f + expf(-h2f<BF>((unsigned short)(raw.x & 0xffffu)))));
+  c[1] = rh<BF>(1.0f / (1.0f + expf(-h2f<BF>((unsigned short)(raw.x >> 16)))));
+  c[2] = rh<BF>(1.0f / (1.0f + expf(-h2f<BF>((unsigned short)(raw.y & 0xffffu)))));
+  c[3] = rh<BF>(1.0f / (1.0f + expf(-h2f<BF>((unsigned short)(raw.y >> 16)))));
+  const float hw = rh<BF>(0.5f * c[2]), hh = rh<BF>(0.5f * c[3]);
+  float v[4] = {rh<BF>(c[0] - hw), rh<BF>(c[1] - hh), rh<BF>(c[0] + hw), rh<BF>(c[1] + hh)};
+  const float Wh = rh<BF>(Wimg), Hh = rh<BF>(Himg);   // the scale tensor is fp16 too
   const float sc[4] = {Wh, Hh, Wh, Hh};
   unsigned short o[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float x = rh(v[e] * sc[e]);
+    float x = rh<BF>(v[e] * sc[e]);
     x = x != x ? x : (x < 0.f ? 0.f : x);   // clamp(min=0) keeps NaN
     x = (x != x || sc[e] != sc[e]) ? __builtin_nanf("") : fminf(x, sc[e]);   // torch.minimum propagates NaN
-    o[e] = f2h(x);
+    o[e] = f2h<BF>(x);
   }
   *reinterpret_cast<uint2*>(boxes + t * 4) = uint2{(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
 }
 
 // valid_ratios[b, l, j] = fp16(counts[b, l, j]) / wh[l, j]   (get_valid_ratio: sum(~mask row/col) / W or H, in fp16)
 // out32 (optional): the same ratio in fp32, counts / size unrounded (what the fp32 reference computes)
+template <bool BF>
 __global__ __launch_bounds__(256) void valid_ratios_kernel(const float* __restrict__ counts, const unsigned short* __restrict__ wh,
                                                            unsigned short* __restrict__ out, float* __restrict__ out32, int n,
                                                            int L2) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  out[i] = f2h(rh(counts[i]) / h2f(wh[i % L2]));
-  if (out32) out32[i] = counts[i] / h2f(wh[i % L2]);
+  out[i] = f2h<BF>(rh<BF>(counts[i]) / h2f<BF>(wh[i % L2]));
+  if (out32) out32[i] = counts[i] / h2f<BF>(wh[i % L2]);
 }
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int codetr_add_f16(void* stream, const void* a_dev, const void* b_dev, void* out_dev, int64_t n, int64_t a_period) {
+
+template <bool BF>
+int add_impl(void* stream, const void* a_dev, const void* b_dev, void* out_dev, int64_t n, int64_t a_period) {
   if (!a_dev || !b_dev || !out_dev || n < 0 || a_period <= 0) return CODETR_E_BADARG;
   if (n == 0) return 0;
   if (n % 8 != 0 || a_period % 8 != 0 || n % a_period != 0) return CODETR_E_UNSUPPORTED;
@@ -123,23 +139,59 @@ int codetr_add_f16(void* stream, const void* a_dev, const void* b_dev, void* out
     return CODETR_E_UNSUPPORTED;
   const int64_t n8 = n / 8, blocks = (n8 + 255) / 256;
   if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(add_kernel<BF>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const unsigned short*>(a_dev), static_cast<const unsigned short*>(b_dev),
                      static_cast<unsigned short*>(out_dev), n8, a_period / 8);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
 
-int codetr_sigmoid_f16(void* stream, const void* x_dev, void* out_dev, int64_t n) {
+template <bool BF>
+int sigmoid_impl(void* stream, const void* x_dev, void* out_dev, int64_t n) {
   if (!x_dev || !out_dev || n < 0) return CODETR_E_BADARG;
   if (n == 0) return 0;
   const int64_t blocks = (n + 255) / 256;
   if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(sigmoid_kernel<BF>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const unsigned short*>(x_dev), static_cast<unsigned short*>(out_dev), n);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
+
+template <bool BF>
+int decode_boxes_impl(void* stream, const void* coords_unact_dev, const int64_t* idx_dev, void* boxes_dev,
+                            int64_t* labels_dev, int64_t B, int64_t Nq, int64_t K, int num_classes, float img_w,
+                            float img_h) {
+  if (!coords_unact_dev || !idx_dev || !boxes_dev || !labels_dev || B < 0 || Nq <= 0 || K < 0 || num_classes <= 0)
+    return CODETR_E_BADARG;
+  if (B == 0 || K == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(coords_unact_dev) | reinterpret_cast<uintptr_t>(boxes_dev)) & 7) return CODETR_E_UNSUPPORTED;
+  const int64_t blocks = (B * K + 255) / 256;
+  if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  hipLaunchKernelGGL(decode_boxes_kernel<BF>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(coords_unact_dev), idx_dev, static_cast<unsigned short*>(boxes_dev),
+                     labels_dev, B, Nq, K, num_classes, img_w, img_h);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+template <bool BF>
+int valid_ratios_impl(void* stream, const float* counts_dev, const void* level_wh_f16_dev, void* out_dev,
+                            float* out32_dev, int64_t B, int L) {
+  if (!counts_dev || !level_wh_f16_dev || !out_dev || B < 0 || L <= 0) return CODETR_E_BADARG;
+  if (B == 0) return 0;
+  const int64_t n = B * L * 2;
+  if (n > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  hipLaunchKernelGGL(valid_ratios_kernel<BF>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     counts_dev, static_cast<const unsigned short*>(level_wh_f16_dev), static_cast<unsigned short*>(out_dev),
+                     out32_dev, (int)n, 2 * L);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
+}  // namespace
+
+extern "C" {
 
 int codetr_gather_rows_b16(void* stream, const void* src_dev, const int64_t* idx_dev, void* out_dev, int64_t B, int64_t S,
                            int64_t K, int64_t C) {
@@ -159,33 +211,31 @@ int codetr_gather_rows_b16(void* stream, const void* src_dev, const int64_t* idx
   return err == hipSuccess ? 0 : (int)err;
 }
 
+int codetr_add_f16(void* stream, const void* a_dev, const void* b_dev, void* out_dev, int64_t n, int64_t a_period) {
+  return add_impl<false>(stream, a_dev, b_dev, out_dev, n, a_period);
+}
+int codetr_add_bf16(void* stream, const void* a_dev, const void* b_dev, void* out_dev, int64_t n, int64_t a_period) {
+  return add_impl<true>(stream, a_dev, b_dev, out_dev, n, a_period);
+}
+int codetr_sigmoid_f16(void* stream, const void* x_dev, void* out_dev, int64_t n) { return sigmoid_impl<false>(stream, x_dev, out_dev, n); }
+int codetr_sigmoid_bf16(void* stream, const void* x_dev, void* out_dev, int64_t n) { return sigmoid_impl<true>(stream, x_dev, out_dev, n); }
 int codetr_decode_boxes_f16(void* stream, const void* coords_unact_dev, const int64_t* idx_dev, void* boxes_dev,
                             int64_t* labels_dev, int64_t B, int64_t Nq, int64_t K, int num_classes, float img_w,
                             float img_h) {
-  if (!coords_unact_dev || !idx_dev || !boxes_dev || !labels_dev || B < 0 || Nq <= 0 || K < 0 || num_classes <= 0)
-    return CODETR_E_BADARG;
-  if (B == 0 || K == 0) return 0;
-  if ((reinterpret_cast<uintptr_t>(coords_unact_dev) | reinterpret_cast<uintptr_t>(boxes_dev)) & 7) return CODETR_E_UNSUPPORTED;
-  const int64_t blocks = (B * K + 255) / 256;
-  if (blocks > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  hipLaunchKernelGGL(decode_boxes_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const unsigned short*>(coords_unact_dev), idx_dev, static_cast<unsigned short*>(boxes_dev),
-                     labels_dev, B, Nq, K, num_classes, img_w, img_h);
-  const hipError_t err = hipGetLastError();
-  return err == hipSuccess ? 0 : (int)err;
+  return decode_boxes_impl<false>(stream, coords_unact_dev, idx_dev, boxes_dev, labels_dev, B, Nq, K, num_classes, img_w, img_h);
 }
-
+int codetr_decode_boxes_bf16(void* stream, const void* coords_unact_dev, const int64_t* idx_dev, void* boxes_dev,
+                             int64_t* labels_dev, int64_t B, int64_t Nq, int64_t K, int num_classes, float img_w,
+                             float img_h) {
+  return decode_boxes_impl<true>(stream, coords_unact_dev, idx_dev, boxes_dev, labels_dev, B, Nq, K, num_classes, img_w, img_h);
+}
 int codetr_valid_ratios_f16(void* stream, const float* counts_dev, const void* level_wh_f16_dev, void* out_dev,
                             float* out32_dev, int64_t B, int L) {
-  if (!counts_dev || !level_wh_f16_dev || !out_dev || B < 0 || L <= 0) return CODETR_E_BADARG;
-  if (B == 0) return 0;
-  const int64_t n = B * L * 2;
-  if (n > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
-  hipLaunchKernelGGL(valid_ratios_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     counts_dev, static_cast<const unsigned short*>(level_wh_f16_dev), static_cast<unsigned short*>(out_dev),
-                     out32_dev, (int)n, 2 * L);
-  const hipError_t err = hipGetLastError();
-  return err == hipSuccess ? 0 : (int)err;
+  return valid_ratios_impl<false>(stream, counts_dev, level_wh_f16_dev, out_dev, out32_dev, B, L);
+}
+int codetr_valid_ratios_bf16(void* stream, const float* counts_dev, const void* level_wh_bf16_dev, void* out_dev,
+                             float* out32_dev, int64_t B, int L) {
+  return valid_ratios_impl<true>(stream, counts_dev, level_wh_bf16_dev, out_dev, out32_dev, B, L);
 }
 
 }  // extern "C"

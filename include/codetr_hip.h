@@ -370,17 +370,26 @@ int codetr_window_attention_fp8mx_f16(void *stream, const void *qkv_dev, const v
  *   codetr_decode_boxes_f16  q = idx / C, label = idx % C, sigmoid -> cxcywh -> xyxy -> x (W,H,W,H) -> clamp
  *                            (co_dino_head.py:177-209 + mmdet bbox_cxcywh_to_xyxy); coords_unact [B,Nq,4] = box branch
  *                            output + reference (before the sigmoid); boxes [B,K,4] fp16, labels [B,K] int64
+ * Every entry point of this group, codetr_query_sine_embed_* and codetr_encoder_geometry_* / codetr_row_max_* below have a
+ * _bf16 twin (same formulas with bfloat16 roundings and finfo(bf16).max): a bf16 model's forward is all C-ABI launches too.
  *   codetr_valid_ratios_f16  out[b,l,j] = fp16(counts[b,l,j]) / level_wh[l,j]   (transformer.py:384-400);
  *                            out32 (may be NULL): counts / level_wh in fp32, unrounded
  * ------------------------------------------------------------------------------------------ */
 int codetr_add_f16(void *stream, const void *a_dev, const void *b_dev, void *out_dev, int64_t n, int64_t a_period);
+int codetr_add_bf16(void *stream, const void *a_dev, const void *b_dev, void *out_dev, int64_t n, int64_t a_period);
 int codetr_sigmoid_f16(void *stream, const void *x_dev, void *out_dev, int64_t n);
+int codetr_sigmoid_bf16(void *stream, const void *x_dev, void *out_dev, int64_t n);
 int codetr_gather_rows_b16(void *stream, const void *src_dev, const int64_t *idx_dev, void *out_dev, int64_t B, int64_t S,
                            int64_t K, int64_t C);
 int codetr_decode_boxes_f16(void *stream, const void *coords_unact_dev, const int64_t *idx_dev, void *boxes_dev,
                             int64_t *labels_dev, int64_t B, int64_t Nq, int64_t K, int num_classes, float img_w,
                             float img_h);
+int codetr_decode_boxes_bf16(void *stream, const void *coords_unact_dev, const int64_t *idx_dev, void *boxes_dev,
+                            int64_t *labels_dev, int64_t B, int64_t Nq, int64_t K, int num_classes, float img_w,
+                            float img_h);
 int codetr_valid_ratios_f16(void *stream, const float *counts_dev, const void *level_wh_f16_dev, void *out_dev,
+                            float *out32_dev, int64_t B, int L);
+int codetr_valid_ratios_bf16(void *stream, const float *counts_dev, const void *level_wh_bf16_dev, void *out_dev,
                             float *out32_dev, int64_t B, int L);
 
 /* Split-K form of the same layer for problems with few output tiles and a long K -- the neck's extra
@@ -447,6 +456,10 @@ int codetr_query_sine_embed_f16(void *stream, const void *ref_dev, const void *v
                                 const float *valid_ratios32_dev, int64_t B, int64_t Nq, int ref_dim, int num_levels,
                                 int pos_feat, float temperature, int apply_sigmoid, void *ref_in_dev,
                                 float *ref_in32_dev, void *embed_dev);
+int codetr_query_sine_embed_bf16(void *stream, const void *ref_dev, const void *valid_ratios_dev,
+                                const float *valid_ratios32_dev, int64_t B, int64_t Nq, int ref_dim, int num_levels,
+                                int pos_feat, float temperature, int apply_sigmoid, void *ref_in_dev,
+                                float *ref_in32_dev, void *embed_dev);
 
 /* ------------------------------------------------------------------------------------------
  * Token geometry of the deformable encoder / two-stage proposal head, one launch (f16 path).
@@ -468,10 +481,14 @@ int codetr_query_sine_embed_f16(void *stream, const void *ref_dev, const void *v
 int codetr_encoder_geometry_f16(void *stream, const void *valid_ratios_dev, const void *mask_flat_dev, int64_t B,
                                 int num_levels, const int64_t *level_shapes_host, void *reference_points_dev,
                                 void *reference_by_level_dev, void *proposals_dev, void *row_state_dev);
+int codetr_encoder_geometry_bf16(void *stream, const void *valid_ratios_dev, const void *mask_flat_dev, int64_t B,
+                                int num_levels, const int64_t *level_shapes_host, void *reference_points_dev,
+                                void *reference_by_level_dev, void *proposals_dev, void *row_state_dev);
 
 /* out[r] = max_c x[r, c] (NaN propagates, as torch.max): enc_outputs_class.max(-1)[0], the ranking score of
  * the two-stage top-k (codetr/transformer.py:560).  x [rows, C] f16 dense, out [rows] f16. */
 int codetr_row_max_f16(void *stream, const void *x_dev, void *out_dev, int64_t rows, int64_t C);
+int codetr_row_max_bf16(void *stream, const void *x_dev, void *out_dev, int64_t rows, int64_t C);
 
 /* ------------------------------------------------------------------------------------------
  * Pre- and post-processing either side of CoDETR.forward (the reference's Inferencer, codetr/inferencer.py).
