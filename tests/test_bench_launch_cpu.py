@@ -26,6 +26,17 @@ def test_gpus_2_launches_its_own_ranks_and_prints_one_json_line():
     assert out["steps"] == 3 and out["warmup"] == 1 and out["value"] is None
 
 
+def test_gpus_8_dry_run_the_scale_the_driver_launches():
+    """the N = 8 control flow (BASELINE config 4: batch 64 = 8 images x 8 ranks): eight gloo ranks shard 64 detections
+    sets, all_gather them in order, agree on the MAX-over-ranks time, rank 0 alone prints the line"""
+    p = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--batch", "8"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["gather_ok"] and out["global_batch"] == 64 and out["scaling"] == "weak"
+
+
 def test_single_rank_dry_run_needs_no_launcher():
     p = _run(["--dry-run", "--steps", "2", "--warmup", "0", "--batch", "2"])
     assert p.returncode == 0, p.stderr[-2000:]
