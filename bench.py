@@ -112,6 +112,7 @@ def msda_offset_stats(model, images, masks, halo=4):
     enc_atts = [layer.attentions[0] for layer in model.query_head.transformer.encoder.layers]
     stats = []
     orig_linear, orig_xadd = hip_ops.linear, hip_ops.linear_xadd
+    pyramid_shapes = pyramid(int(images.shape[-2]), int(images.shape[-1])) if enc_atts and enc_atts[0].num_levels == 5 else None
 
     def record(att, proj):
         n_off = att.num_heads * att.num_levels * att.num_points * 2
@@ -119,7 +120,20 @@ def msda_offset_stats(model, images, masks, halo=4):
         bias = att.sampling_offsets.bias.float()
         spread = (off - bias).std().item()
         miss = (off.abs().view(*off.shape[:-1], -1, 2).amax(-1) > halo).float().mean().item()
-        stats.append((spread, miss))
+        # ... and the windows the encoder kernel actually stages (per head and level, three-pass form): a sample is in
+        # when both bilinear corners of floor(offset) are (exact for level-0 queries, whose centre sits on the level's
+        # grid; an estimate for the coarser levels' sub-pixel phases)
+        wmiss = None
+        if pyramid_shapes is not None:
+            passes = hip_ops.msda_encoder_passes(torch.float16, att.num_levels, att.num_points)
+            win = torch.tensor(att._encoder_windows(pyramid_shapes, torch.float16, passes), dtype=torch.float32,
+                               device=off.device)                                       # [M, L, 4] lox, hix, loy, hiy
+            o = off.view(*off.shape[:-1], att.num_heads, att.num_levels, att.num_points, 2)
+            x0, y0 = torch.floor(o[..., 0]), torch.floor(o[..., 1])
+            w = win[:, :, None, :]
+            inside = (x0 >= w[..., 0]) & (x0 + 1 <= w[..., 1]) & (y0 >= w[..., 2]) & (y0 + 1 <= w[..., 3])
+            wmiss = 1.0 - inside.float().mean().item()
+        stats.append((spread, miss, wmiss))
 
     def find(weight):
         for a in enc_atts:
@@ -150,9 +164,14 @@ def msda_offset_stats(model, images, masks, halo=4):
         hip_ops.linear, hip_ops.linear_xadd = orig_linear, orig_xadd
     if not stats:
         return None
-    return {"offset_spread_px_per_encoder_layer": [round(a, 2) for a, _ in stats],
-            "fraction_of_samples_outside_halo_per_layer": [round(b, 4) for _, b in stats],
-            "halo_px": halo}
+    rec = {"offset_spread_px_per_encoder_layer": [round(a, 2) for a, _, _ in stats],
+           "fraction_of_samples_outside_halo_per_layer": [round(b, 4) for _, b, _ in stats],
+           "halo_px": halo}
+    if all(c is not None for _, _, c in stats):
+        rec["fraction_of_samples_outside_staged_windows_per_layer"] = [round(c, 4) for _, _, c in stats]
+        rec["windows_note"] = ("the default encoder kernel stages per-(head, level) windows derived from the offset bias "
+                               "(three passes), not the symmetric halo: this is the share that takes its fix-up queue")
+    return rec
 
 
 def msda_roofline(B, H, W, dtype, device, iters=30):

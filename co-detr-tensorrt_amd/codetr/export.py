@@ -108,6 +108,20 @@ def export_plan(model, batch_inputs, img_masks, path, warmup=2):
         if foreign:
             raise RuntimeError("this model / input shape is not exportable: the forward ran device work outside "
                                f"libcodetr_hip.so that a plan cannot replay: {foreign}")
+        # ... and replay the recorded launches once in-process, on the same memory, with the outputs zeroed first: a launch
+        # list that misses device work the recorder did not see cannot reproduce the recorded detections
+        want = [t.cpu() for t in (boxes, scores, labels)]
+        for t in (boxes, scores, labels):
+            t.zero_()
+        lib = _cabi.load()
+        for name, args in calls:
+            rc = getattr(lib, name)(*args)
+            if rc:
+                raise RuntimeError(f"replay of the recorded launch list failed in {name}: error {rc}")
+        torch.cuda.synchronize(dev)
+        for what, t, w in zip(("boxes", "scores", "labels"), (boxes, scores, labels), want):
+            if not torch.equal(t.cpu(), w):
+                raise RuntimeError(f"the recorded launch list does not reproduce the recorded {what}: not exportable")
         segs = _segments(dev)
 
     def locate(addr, what):

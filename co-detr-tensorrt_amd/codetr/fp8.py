@@ -22,7 +22,9 @@ from . import hip_ops
 from .swin import SwinBlock
 from .transformer_layers import FFN
 
-MARGIN = 1.0   # static mode: scale = absmax * MARGIN / 448 (calibration and evaluation inputs are drawn alike in bench / tests)
+MARGIN = 2.0   # static mode: scale = absmax * MARGIN / 448.  e4m3 is a floating-point format: one binade of headroom costs no
+               # relative precision (only the smallest binade of the activations moves into the subnormals) and keeps inputs
+               # up to twice the calibration set's maximum from saturating at +-448
 # "mx" (default): MX block scales on the Swin activations -- one e8m0 exponent per 32 channels, chosen by the producer
 # kernel from the block's own maximum and applied by the scaled MFMA in hardware: no calibration, no saturation on unseen
 # inputs.  "static": the round-2 scheme (one calibrated scale per tensor), kept for A/B.  The encoder's fused FFN uses

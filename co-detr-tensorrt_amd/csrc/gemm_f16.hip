@@ -666,6 +666,13 @@ int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, c
 #ifdef CODETR_GEMM_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
 #endif
+// diagnostic builds only (tools/micro/gemm256_stamps.hip -DCODETR_GEMM_ABL=mask; WRONG results by construction):
+// 1 = no LDS-DMA inside the main loop, 2 = no MFMAs, 4 = no fragment reads, 8 = no wait + barrier per k-tile
+#ifdef CODETR_GEMM_ABL
+constexpr int kGemmAbl = CODETR_GEMM_ABL;
+#else
+constexpr int kGemmAbl = 0;
+#endif
 // XDEEP: the X operand (the one that misses L2 more: each 256-row slice is shared by the N/256 column tiles only, the W
 // slices by every row tile) is prefetched TWO k-tiles ahead through a 3-slot ring that takes the last 32 KiB of the CU's
 // 160 KiB of LDS; W stays one tile ahead in its 2-slot ring.  In-kernel stamps (tools/micro/gemm256_stamps.hip) show
@@ -727,8 +734,8 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     gw[q] = W + (size_t)gn * K + chunk * 8;
     gx[q] = X + (size_t)gm * K + chunk * 8;
   }
-  auto issue = [&](int t) {
-    unsigned char* buf = lds + (t & 1) * kStageBytes;
+  auto issue = [&](int t, int slot) {
+    unsigned char* buf = lds + (slot & 1) * kStageBytes;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       unsigned char* l = buf + (q * NT + wave * 64) * 16;
@@ -743,20 +750,25 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     }
   };
   const int nk = K / BKT;
+  // k-tile index of loop step i (steps past the end re-fetch the last one).  A per-tile rotation of this walk (so that
+  // tiles sharing an operand slice do not ask for it at the same moment) was measured neutral to -6 % and removed
+  // (profiles/r03_gemm256_ablation.txt).
+  auto ktile = [&](int i) { return i < nk ? i : nk - 1; };
   auto dma16 = [&](const unsigned short* g, unsigned char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
   };
   if (XDEEP) {   // issue order W(0), X(0), X(1): the youngest four pieces may stay in flight at the first wait
+    const size_t k0 = (size_t)ktile(0) * BKT;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma16(gw[q], lds + 3 * kTileBytes + (q * NT + wave * 64) * 16);
+    for (int q = 0; q < 4; ++q) dma16(gw[q] + k0, lds + 3 * kTileBytes + (q * NT + wave * 64) * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma16(gx[q], lds + (q * NT + wave * 64) * 16);
-    const size_t k1 = (size_t)(nk > 1 ? 1 : 0) * BKT;
+    for (int q = 0; q < 4; ++q) dma16(gx[q] + k0, lds + (q * NT + wave * 64) * 16);
+    const size_t k1 = (size_t)ktile(1) * BKT;
 #pragma unroll
     for (int q = 0; q < 4; ++q) dma16(gx[q] + k1, lds + kTileBytes + (q * NT + wave * 64) * 16);
   } else {
-    issue(0);
+    issue(ktile(0), 0);
   }
 #ifdef CODETR_GEMM_STAMPS
   unsigned long long wait_dma = 0, wait_bar = 0;
@@ -772,9 +784,11 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     wait_dma += w1 - w0;
     wait_bar += w2 - w1;
 #else
-    if (XDEEP) wait_vmcnt<4>();   // W(t) and X(t) have landed; the four pieces of X(t+1) may still be in flight
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // tile t is in LDS for everyone; everyone is done reading tile t-1
+    if (!(kGemmAbl & 8)) {
+      if (XDEEP) wait_vmcnt<4>();   // W(t) and X(t) have landed; the four pieces of X(t+1) may still be in flight
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // tile t is in LDS for everyone; everyone is done reading tile t-1
+    }
 #endif
     const unsigned char* bufW = XDEEP ? lds + (3 + (t & 1)) * kTileBytes : lds + (t & 1) * kStageBytes;
     const unsigned char* bufX = XDEEP ? lds + xs * kTileBytes : bufW + kTileBytes;
@@ -782,27 +796,32 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     // LDS wait.  The schedule is pinned: fragments of k-step 1 are read behind the first two MFMAs of step 0, and the
     // 8 DMA pieces of tile t+1 go out one per 3 MFMAs of step 0 (early enough to land under step 1).  Past the last
     // tile the pieces re-fetch it into the idle buffer (no branch in the pinned region); drained before the epilogue.
-    const size_t koff = (size_t)(t + 1 < nk ? t + 1 : t) * BKT;
+    const size_t koff = (size_t)ktile(t + 1) * BKT;
     unsigned char* nbuf = lds + ((t + 1) & 1) * kStageBytes;
     // XDEEP: W(t+1) -> the W slot tile t-1 used, X(t+2) -> the X slot tile t-1 used (re-fetches of the last tile past
     // the end keep the in-flight count uniform)
-    const size_t koffx = (size_t)(t + 2 < nk ? t + 2 : nk - 1) * BKT;
+    const size_t koffx = (size_t)ktile(t + 2) * BKT;
     unsigned char* nbufW = XDEEP ? lds + (3 + ((t + 1) & 1)) * kTileBytes : nbuf;
     const int xs2 = xs >= 1 ? xs - 1 : 2;   // (xs + 2) % 3
     unsigned char* nbufX = XDEEP ? lds + xs2 * kTileBytes : nbuf + kTileBytes;
     xs = xs == 2 ? 0 : xs + 1;
+#ifdef CODETR_GEMM_ABL
+    typename T::frag a[2][4] = {}, b[2][8] = {};
+#else
     typename T::frag a[2][4], b[2][8];
+#endif
     auto read_frags = [&](int ks, int buf) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[buf][i] = read_frag<T, BKT>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
 #pragma unroll
       for (int j = 0; j < 8; ++j) b[buf][j] = read_frag<T, BKT>(bufX, wm * 128 + j * 16 + frow, ks * 4 + fchunk);
     };
-    read_frags(0, 0);
+    if (!(kGemmAbl & 4)) read_frags(0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
     // ---- k-step 0 ----
-    read_frags(1, 1);
-    if (XDEEP) {   // W first: it is needed one tile from now, X two
+    if (!(kGemmAbl & 4)) read_frags(1, 1);
+    if (kGemmAbl & 1) {
+    } else if (XDEEP) {   // W first: it is needed one tile from now, X two
 #pragma unroll
       for (int q = 0; q < 4; ++q) dma16(gw[q] + koff, nbufW + (q * NT + wave * 64) * 16);
 #pragma unroll
@@ -817,7 +836,10 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = T::mfma(a[0][i], b[0][j], acc[i][j]);
+      for (int i = 0; i < 4; ++i) {
+        if (!(kGemmAbl & 2)) acc[i][j] = T::mfma(a[0][i], b[0][j], acc[i][j]);
+        else if (!(kGemmAbl & 4)) asm volatile("" ::"v"(a[0][i]), "v"(b[0][j]));
+      }
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
@@ -830,7 +852,10 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = T::mfma(a[1][i], b[1][j], acc[i][j]);
+      for (int i = 0; i < 4; ++i) {
+        if (!(kGemmAbl & 2)) acc[i][j] = T::mfma(a[1][i], b[1][j], acc[i][j]);
+        else if (!(kGemmAbl & 4)) asm volatile("" ::"v"(a[1][i]), "v"(b[1][j]));
+      }
     __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
   }
   wait_vmcnt<0>();  // the redundant pieces of the last iteration have landed

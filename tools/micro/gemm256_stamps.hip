@@ -3,7 +3,9 @@
 //   /tmp/gemm_stamps M N K [act] [residual]
 // Per workgroup: start, end of the main loop, epilogue stores issued, stores completed (shader cycles) + realtime
 // (100 MHz) at start / end -> main-loop and epilogue time per tile, the clock, and how the tiles of the 256 CUs line up.
+#ifndef NOSTAMPS   // -DNOSTAMPS -DCODETR_GEMM_ABL=mask: ablation builds timed by events only (the stamps themselves cost ~15 %)
 #define CODETR_GEMM_STAMPS
+#endif
 #include "../../co-detr-tensorrt_amd/csrc/gemm_f16.hip"
 
 #include <algorithm>
@@ -23,7 +25,9 @@ int main(int argc, char** argv) {
   const int tiles = (int)(((M + 255) / 256) * ((N + 255) / 256));
   unsigned long long* stamps;
   hipMalloc(&stamps, (size_t)tiles * 64);
+#ifdef CODETR_GEMM_STAMPS
   hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps));
+#endif
   for (int it = 0; it < 5; ++it) codetr_linear_f16(nullptr, X, W, B, res ? R : nullptr, nullptr, Y, M, N, K, act, 0, 0);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -31,6 +35,10 @@ int main(int argc, char** argv) {
   codetr_linear_f16(nullptr, X, W, B, res ? R : nullptr, nullptr, Y, M, N, K, act, 0, 0);
   hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
+#ifndef CODETR_GEMM_STAMPS
+  printf("M %lld N %lld K %lld act %d res %d: kernel %.1f us (event), ablation mask %d\n", (long long)M, (long long)N, (long long)K, act, res, ms * 1e3, kGemmAbl);
+  return 0;
+#endif
   std::vector<unsigned long long> s((size_t)tiles * 8);
   hipMemcpy(s.data(), stamps, s.size() * 8, hipMemcpyDeviceToHost);
   double main_c = 0, epi_issue = 0, epi_done = 0, clk = 0, wdma = 0, wbar = 0;
