@@ -111,3 +111,56 @@ def test_headline_batch4_vs_oracle_rows_and_alone(case):
     alone = F.sample_capture(NAME, cap1)
     _write_report("batch4_image0_vs_alone_fp16", _compare(got, alone, 5e-3, "batch of 4 vs alone", deep_rel=2.5e-2))
     _write_report("alone_vs_oracle_fp16", _compare(alone, fx, 1e-2, "alone vs oracle"))
+
+
+@pytest.mark.parametrize("mode", ["mx", "static"])
+def test_headline_fp8_batch4_vs_oracle_rows(case, mode):
+    """BASELINE config 5 at the headline size and the bench's launch shapes: the same four images through fp8.enable
+    (Swin stage 1-3 linears on e4m3 -- MX block scales, or static scales calibrated on images 2, 3 -- and the encoder's
+    fused FFN on e4m3 with static scales calibrated on images 2, 3), image 0 against the oracle's fixture rows.  The
+    bounds are the measured errors of e4m3 operands (3 mantissa bits compounding over 22 Swin blocks and 6 FFNs; the
+    same with either scaling) with ~1.5x headroom -- they pin the path against breakage, they do not
+    certify 0.1 AP; the row criterion (no row above 5x the tensor bound) holds here as for fp16."""
+    from codetr import _cabi, fp8
+    from helpers_model import row_error_stats
+
+    fx, model, img, mask = case
+    x4, m4 = _batch4(img, mask)
+    picks0 = torch.from_numpy(fx["topk_indices"]).to(DEV)
+    try:
+        with torch.no_grad():
+            assert fp8.calibrate(model, x4[2:], m4[2:]) == 24
+            fp8.enable(model, True, mode)
+            cap = {}
+            model(x4, m4, capture=cap)
+            picks = valid_topk(cap["enc_outputs_class"].float(), cap["enc_outputs_coord_unact"].float(), 900, bound=50.0)
+            picks[0] = picks0[0]
+            del cap
+            before = dict(_cabi.CALLS)
+            cap4 = {}
+            model(x4, m4, forced_topk_indices=picks, capture=cap4)
+            torch.cuda.synchronize()
+            calls = {k: _cabi.CALLS[k] - before[k] for k in before}
+        n8 = calls["linear_fp8"]
+        assert n8 == 4 * 22 and calls["ffn_fp8"] == 6 and calls["ffn_fused"] == 0, calls      # stages 1-3: 2 + 18 + 2 blocks
+        assert calls["msda_encoder"] == 6 and calls["linear_xadd"] == 6, calls
+        got = F.sample_capture(NAME, cap4, image=0, images=4)
+        bounds = {"backbone0": 5e-3, "backbone1": 7e-2, "backbone2": 1.2e-1, "backbone3": 1.4e-1, "memory": 1.2e-1,
+                  "enc_outputs_class": 1.2e-1, "neck0": 5e-3}   # measured: 7.9e-4, 4.5e-2, 8.1e-2, 8.9e-2, 9.1e-2, 8.5e-2, 9.2e-4
+        errs = {}
+        for k, v in got.items():
+            a, r = np.asarray(v, np.float64), np.asarray(fx[k], np.float64)
+            fin = np.isfinite(r)
+            assert (np.isfinite(a) == fin).all(), k
+            e = float(np.linalg.norm((a - r)[fin]) / max(np.linalg.norm(r[fin]), 1e-30))
+            b = bounds.get(k, 1.4e-1)       # neck levels 1-4 and the decoder side: measured 4.4e-2 ... 9.7e-2
+            ratio, frac, worst = row_error_stats(a, r, b)
+            errs[k] = {"rel_l2": float(f"{e:.3e}"), "bound": b, "worst_row_over_limit": round(ratio / 5.0, 3),
+                       "worst_row_outlier_frac": round(frac, 4)}
+        _write_report(f"batch4_image0_vs_oracle_fp8_{mode}", errs)
+        print("headline fp8", mode, {k: v["rel_l2"] for k, v in errs.items()})
+        for k, v in errs.items():
+            assert v["rel_l2"] <= v["bound"], (k, v)
+            assert v["worst_row_over_limit"] <= 1.0, (k, v)
+    finally:
+        fp8.enable(model, False)
