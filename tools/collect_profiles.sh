@@ -18,8 +18,11 @@ python tools/fold_trace.py "$(find /tmp/tr8 -name '*.db' | head -1)" $out/${tag}
 b1="--batch 1 --steps 6 --warmup 2 $common"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr1 -- python bench.py $b1 > /tmp/tr1.log 2>&1
 python tools/fold_trace.py "$(find /tmp/tr1 -name '*.db' | head -1)" $out/${tag}_batch1 1 "rocprofv3 --kernel-trace --stats -- python bench.py $b1"
-# HBM traffic of one replayed graph's launches (4 images): what bench.py's roofline*.traffic cite
+# one replayed graph's launch shapes (4 images): the kernel trace bench.py's live rooflines must agree with, then the HBM traffic
 p4="--batch 4 --streams 1 --steps 2 --warmup 1 $common"
+rm -rf /tmp/tr4
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr4 -- python bench.py $p4 > /tmp/tr4.log 2>&1
+python tools/fold_trace.py "$(find /tmp/tr4 -name '*.db' | head -1)" $out/${tag}_batch4 4 "rocprofv3 --kernel-trace --stats -- python bench.py $p4"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python bench.py $p4 > /tmp/pf.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python bench.py $p4 > /tmp/pw.log 2>&1
 python tools/pmc_fold.py --fetch "$(find /tmp/pf -name '*counter_collection.csv' | head -1)" --write "$(find /tmp/pw -name '*counter_collection.csv' | head -1)" \
