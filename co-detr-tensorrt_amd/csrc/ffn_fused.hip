@@ -30,6 +30,13 @@
 
 #include "codetr_hip.h"
 
+// diagnostic builds only (tools/micro/ffn_ablate.hip -DCODETR_FFN_ABL=mask; WRONG results by construction, never shipped):
+// 1 = no LDS-DMA inside the chunk loop, 2 = no MFMAs, 4 = no W fragment reads inside the chunk loop
+#ifdef CODETR_FFN_ABL
+#define CODETR_FFN_ABL_MASK CODETR_FFN_ABL
+#else
+#define CODETR_FFN_ABL_MASK 0
+#endif
 namespace {
 
 constexpr int C = 256;         // model width (K of the first product, N of the second)
@@ -260,11 +267,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       read_w1(0, aw[0]);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) read_w1(ks + 1, aw[(ks + 1) & 1]);
-        stage_w1(ks, cn, nW1);
+        if (ks + 1 < 8 && !(CODETR_FFN_ABL_MASK & 4)) read_w1(ks + 1, aw[(ks + 1) & 1]);
+        if (!(CODETR_FFN_ABL_MASK & 1)) stage_w1(ks, cn, nW1);
 #pragma unroll
         for (int i = 0; i < 4 * MT; ++i)
-          hacc[i / MT][i % MT] = ET::mfma(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT]);
+          if (!(CODETR_FFN_ABL_MASK & 2))
+            hacc[i / MT][i % MT] = ET::mfma(aw[(CODETR_FFN_ABL_MASK & 4) ? 0 : (ks & 1)][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT]);
+          else if (!(CODETR_FFN_ABL_MASK & 4)) asm volatile("" ::"v"(aw[ks & 1][i / MT]));
         // 2 MFMAs, then the 4 reads of the next step and the DMA piece, then the other 6
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -305,12 +314,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       read_w2(0, a2[0]);
 #pragma unroll
       for (int ntp = 0; ntp < 8; ++ntp) {
-        if (ntp + 1 < 8) read_w2(ntp + 1, a2[(ntp + 1) & 1]);
-        stage_w2(ntp, cn, nW2);
+        if (ntp + 1 < 8 && !(CODETR_FFN_ABL_MASK & 4)) read_w2(ntp + 1, a2[(ntp + 1) & 1]);
+        if (!(CODETR_FFN_ABL_MASK & 1)) stage_w2(ntp, cn, nW2);
 #pragma unroll
         for (int i = 0; i < 4 * MT; ++i) {   // MFMA index i -> (t, s, mt)
           const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / 2;
-          yacc[nt][mt] = ET::mfma(a2[ntp & 1][ts], pf[ts & 1][mt], yacc[nt][mt]);
+          if (!(CODETR_FFN_ABL_MASK & 2))
+            yacc[nt][mt] = ET::mfma(a2[(CODETR_FFN_ABL_MASK & 4) ? 0 : (ntp & 1)][ts], pf[ts & 1][mt], yacc[nt][mt]);
+          else if (!(CODETR_FFN_ABL_MASK & 4)) asm volatile("" ::"v"(a2[ntp & 1][ts]));
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
