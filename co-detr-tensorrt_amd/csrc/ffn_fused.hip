@@ -31,7 +31,8 @@
 #include "codetr_hip.h"
 
 // diagnostic builds only (tools/micro/ffn_ablate.hip -DCODETR_FFN_ABL=mask; WRONG results by construction, never shipped):
-// 1 = no LDS-DMA inside the chunk loop, 2 = no MFMAs, 4 = no W fragment reads inside the chunk loop
+// 1 = no LDS-DMA inside the chunk loop, 2 = no MFMAs, 4 = no W fragment reads inside the chunk loop, 8 = no waits / barriers in the
+// chunk loop, 16 = no ReLU / pack between the products (B operand of product 2 = stale registers)
 #ifdef CODETR_FFN_ABL
 #define CODETR_FFN_ABL_MASK CODETR_FFN_ABL
 #else
@@ -240,8 +241,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       const unsigned char* sW2 = ringB + (gc & 1) * kW2Bytes;
       unsigned char* nW1 = ringA + ((gc + 1) & 1) * kW1Bytes;
       unsigned char* nW2 = ringB + ((gc + 1) & 1) * kW2Bytes;
-      if (c > 0) wait_vmcnt<8>();
-      __builtin_amdgcn_s_barrier();  // T
+      if (!(CODETR_FFN_ABL_MASK & 8)) {
+        if (c > 0) wait_vmcnt<8>();
+        __builtin_amdgcn_s_barrier();  // T
+      }
 
       // ---- H^T = W1c . X^T : D[i = h][j = m] ----
       f32x4 hacc[4][MT];
@@ -282,6 +285,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       }
       // ---- ReLU + pack: B operand of the second product, k-slot 8g+j = rows 4g..4g+3 of tiles 2s and 2s+1 ----
       V8 pf[2][MT];
+      if (CODETR_FFN_ABL_MASK & 16) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pf[s][mt] = xf[mt][s];
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(hacc[ht][mt]));
+      } else
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -292,12 +305,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int r = 0; r < 4; ++r) pf[s][mt][h * 4 + r] = (E)hacc[2 * s + h][mt][r];
       // ReLU on the packed halves (one op per two values).  max(NaN, 0) = 0 drops a NaN of the hidden unit, but a NaN
       // there can only come from a NaN / inf in this row of X, which the residual add puts back.
+      if (!(CODETR_FFN_ABL_MASK & 16))
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) pf[s][mt] = ET::relu(pf[s][mt]);
-      if (c > 0) wait_vmcnt<8>();
-      __builtin_amdgcn_s_barrier();  // M
+      if (!(CODETR_FFN_ABL_MASK & 8)) {
+        if (c > 0) wait_vmcnt<8>();
+        __builtin_amdgcn_s_barrier();  // M
+      }
       // ---- Y^T += W2c . relu(H)^T : D[i = n][j = m], k = hidden unit (permuted identically on both operands) ----
       // W2 fragments (pre-packed: the 8 k-slots of lane group g are 16 contiguous bytes), read two n-tiles ahead
       auto read_w2 = [&](int ntp, V8 (&a)[4]) {  // n-tiles 2*ntp, 2*ntp+1; index [t*2 + s]
