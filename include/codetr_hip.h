@@ -129,7 +129,9 @@ int codetr_msda_fused_forward_ref32_bf16(void *stream, const void *value_dev, co
                                          int M, int D, int L, int64_t Nq, int P, void *out_dev);
 
 /* ------------------------------------------------------------------------------------------
- * Encoder self-attention form of the fused op (same arithmetic, bit-identical results; LDS-staged gather).
+ * Encoder self-attention form of the fused op (LDS-staged gather).  bf16, and fp16 shapes other than L == 5, P == 4: the
+ * general kernel's arithmetic, bit-identical results.  fp16 with L == 5, P == 4: packed-half blend, within the op tolerance
+ * of codetr_msda_fused_forward_f16 but not bit-identical (see the _win entry below).
  *
  * For DetrTransformerEncoder (codetr/transformer.py:81-92), where the queries ARE the pixels of the flattened
  * multi-level map (Nq == S, query q = pixel q) and reference_points are 2-d (get_reference_points,
@@ -173,8 +175,8 @@ int codetr_msda_encoder_forward_bf16(void *stream, const void *value_dev, const 
  *                     (fp16 resolves a coordinate in [0.5, 1) to 1/2048: a quarter pixel on a 480-wide level).
  * Windows change speed, never results beyond the rounding of the packed blend: for fp16 with L == 5, P == 4 the blend
  * runs on packed halves (fp16 corner weights, 8-term fp16 partial sums added in fp32; samples outside the windows
- * are added in fp32): within rtol 1e-2 / atol 2e-3 of the fp64 oracle (the reference's own half test allows rtol 1e-2 /
- * atol 1e-3 for a kernel that accumulates in half: tests/test_multi_scale_deformable_attention.py:62, 363-364), not
+ * are added in fp32): within rtol 1e-2 / atol 1e-3 of the fp64 oracle (the reference's own half tolerance,
+ * tests/test_multi_scale_deformable_attention.py:62, 363-364), not
  * bit-identical to codetr_msda_fused_forward_f16.
  * codetr_msda_encoder_lds_bytes: LDS bytes per workgroup a launch would need (variant 1: generic single pass, 2: packed
  * single pass, 3: three passes), or a negative CODETR_E_* code. */

@@ -5,8 +5,8 @@ in test_msda_gpu.py) and against the float64 CPU oracle directly.
 Two kernels serve the entry point:
   * fp16 at the model's shape (5 levels x 4 points): the packed-half blend (v2) -- fp16 corner weights, 8-term fp16
     partial sums added in fp32.  Tolerance, stated here and in include/codetr_hip.h: against the float64 oracle
-    rtol 1e-2 / atol 2e-3 element-wise (the reference's own half test allows rtol 1e-2 / atol 1e-3 for a kernel that
-    accumulates all 80 terms in half, tests/test_multi_scale_deformable_attention.py:62, 363-364) and relative L2
+    rtol 1e-2 / atol 1e-3 element-wise (the reference's own half tolerance, for a kernel that accumulates all 80
+    terms in half: tests/test_multi_scale_deformable_attention.py:62, 363-364) and relative L2
     <= 1e-3; against the general kernel (fp32 blend, one rounding) relative L2 <= 1e-3 and |d| <= 3e-3 + 3e-3 |x|
     element-wise.  Measured: relative L2 4-6e-4 (the final fp16 rounding alone is 2e-4).
   * every other shape / bf16: same formulas and accumulation order as the general kernel -- BIT-IDENTICAL.
@@ -155,7 +155,7 @@ def test_three_pass_fp32_reference_points_against_float64_oracle():
     expect = msda_oracle.msda_forward_numpy(value.double().cpu().numpy(), ssn,
                                             msda_oracle.level_start_index_from_shapes(ssn), loc.numpy(), w.numpy())
     got = out.float().cpu().numpy()
-    np.testing.assert_allclose(got, expect, rtol=1e-2, atol=2e-3)
+    np.testing.assert_allclose(got, expect, rtol=1e-2, atol=1e-3)
     assert np.linalg.norm(got - expect) / np.linalg.norm(expect) <= 1e-3
 
 
@@ -205,7 +205,7 @@ def test_against_float64_oracle(shapes, off_scale):
     expect = msda_oracle.msda_forward_numpy(value.double().cpu().numpy(), ssn,
                                             msda_oracle.level_start_index_from_shapes(ssn), loc.numpy(), w.numpy())
     got = out.float().cpu().numpy()
-    np.testing.assert_allclose(got, expect, rtol=1e-2, atol=2e-3)
+    np.testing.assert_allclose(got, expect, rtol=1e-2, atol=1e-3)
     rel = np.linalg.norm(got - expect) / np.linalg.norm(expect)
     assert rel <= (1e-3 if _packed(out, L, P) else 4e-4), rel
 
@@ -263,7 +263,7 @@ def test_full_size_sampled_queries_against_float64_oracle():
     expect = msda_oracle.msda_forward_numpy(value.double().cpu().numpy(), ssn,
                                             msda_oracle.level_start_index_from_shapes(ssn), loc.numpy(), w.numpy())
     got = out[0, idx.to(DEV)].float().cpu().numpy()
-    np.testing.assert_allclose(got, expect[0], rtol=1e-2, atol=2e-3)
+    np.testing.assert_allclose(got, expect[0], rtol=1e-2, atol=1e-3)
     assert np.linalg.norm(got - expect[0]) / np.linalg.norm(expect[0]) <= 1e-3
 
 
