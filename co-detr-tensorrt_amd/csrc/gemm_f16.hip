@@ -91,18 +91,19 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
 
 // nn.GELU (erf form): 0.5 x (1 + erf(x / sqrt 2)).  libm's erff costs ~50 VALU ops per element and made the
 // GELU epilogues VALU-bound; erf is evaluated with Abramowitz-Stegun 7.1.26 instead
-// (1 v_rcp + 1 v_exp + 7 FMA, |erf error| <= 1.5e-7, i.e. < 2^-22 relative on the output: three orders
-// of magnitude below the fp16/bf16 rounding of the result).
+// (|erf error| <= 1.5e-7, i.e. < 2^-22 relative on the output: three orders of magnitude below the fp16 / bf16
+// rounding of the result).
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-z * z);  // erf(|x|/sqrt2)
-  const float erf_v = x < 0.f ? -e : e;
-  return 0.5f * x * (1.0f + erf_v);
+  // 0.5 x (1 + erf(x / sqrt 2)) = 0.5 x + |x| (0.5 - (0.5 p(t) t) exp(-x^2 / 2)),  t = 1 / (1 + 0.3275911 |x| / sqrt 2):
+  // the sign of erf folds into |x|, the halves into the coefficients -- 11 plain ops + v_rcp + v_exp (15 + 2 before)
+  const float u = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, u, 1.0f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float ez = __builtin_amdgcn_exp2f(u * u * (-0.5f * 1.4426950408889634f));
+  return fmaf(u, fmaf(-(p * t), ez, 0.5f), 0.5f * x);
 }
 
 // LDS image of one operand tile: [128 rows][CH = BKT/8 chunks of 16 B].  The DMA destination is lane-linear, so

@@ -42,15 +42,17 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) {  // as gemm_f16.hip (Abramowitz-Stegun 7.1.26)
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-z * z);
-  return 0.5f * x * (1.0f + (x < 0.f ? -e : e));
+__device__ __forceinline__ float gelu_erf(float x) {
+  // 0.5 x (1 + erf(x / sqrt 2)) = 0.5 x + |x| (0.5 - (0.5 p(t) t) exp(-x^2 / 2)),  t = 1 / (1 + 0.3275911 |x| / sqrt 2):
+  // the sign of erf folds into |x|, the halves into the coefficients -- 11 plain ops + v_rcp + v_exp (15 + 2 before)
+  const float u = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, u, 1.0f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float ez = __builtin_amdgcn_exp2f(u * u * (-0.5f * 1.4426950408889634f));
+  return fmaf(u, fmaf(-(p * t), ez, 0.5f), 0.5f * x);
 }
 
 // XOR swizzle of the 16-byte chunk index of a 128-byte LDS row.  A lane's fragment is two ds_read_b128 (chunks 2g, 2g+1,
