@@ -659,12 +659,14 @@ def main():
         nb0 = max(1, a.batch // nstreams)
         calib = torch.randn(nb0, 3, H, W, device=device, generator=gc).to(dtype)
         fp8.calibrate(model, calib, masks[:nb0].contiguous())
+        sat8 = fp8.saturation(model, images[:nb0].contiguous(), masks[:nb0].contiguous())   # the TIMED images vs those scales
         fp8.enable(model)
         del calib
         fp16_graphs, graphs = graphs, capture()
         e8, per8 = timed(False)
         fp8_line = {"images_per_s": round(a.steps * a.batch / e8, 3), "ms_per_step": round(e8 / a.steps * 1e3, 3),
                     "p50_ms_per_image": round(per8[len(per8) // 2] / a.batch, 3), "config": fp8.report(model),
+                    "static_scale_headroom": sat8,
                     "dtype": "fp8 e4m3: Swin stage 1-3 linears with MX block scales (e8m0 per 32 channels, hardware-applied), "
                              "encoder FFN with static scales calibrated on other images; f16 elsewhere, f32 accumulation"}
         if not a.no_roofline:

@@ -71,6 +71,37 @@ def calibrate(model, batch_inputs, img_masks):
     return n
 
 
+@torch.no_grad()
+def saturation(model, batch_inputs, img_masks):
+    """How close these inputs come to the calibrated static ranges: one fp16 forward in recording mode (the fp8 path is
+    switched back to what it was afterwards) and, per recorded tensor, its absolute maximum over what the static scale
+    represents without clamping (scale * 448).  Returns {"tensors": n, "saturating": number of tensors with a ratio > 1,
+    "worst_ratio": max}.  MX-scaled tensors cannot saturate and are not counted."""
+    blocks, ffns = _blocks(model), _ffns(model)
+    saved = [(b, getattr(b, "fp8_mode", None)) for b in blocks + ffns]
+    for b in blocks + ffns:
+        b.fp8_mode = "calibrate"
+        b.__dict__.pop("_fp8_amax", None)
+    try:
+        model(batch_inputs, img_masks)
+    finally:
+        for b, m in saved:
+            b.fp8_mode = m
+    n = sat = 0
+    worst = 0.0
+    for b in blocks + ffns:
+        amax, scales = b.__dict__.pop("_fp8_amax", None), getattr(b, "_fp8_scales", None)
+        if not amax or not scales:
+            continue
+        for k, v in amax.items():
+            if k in scales:
+                r = float(v) / (scales[k] * hip_ops.FP8_MAX)
+                n += 1
+                sat += r > 1.0
+                worst = max(worst, r)
+    return {"tensors": n, "saturating": int(sat), "worst_ratio": round(worst, 4)}
+
+
 def enable(model, on=True, mode=None):
     """switch the blocks to the fp8 path: Swin blocks to MX block scales (mode "mx", no calibration needed) or to their
     calibrated static scales (mode "static"); calibrated FFNs to the fused e4m3 kernel.  Blocks whose shapes the fp8

@@ -130,6 +130,8 @@ def test_headline_fp8_batch4_vs_oracle_rows(case, mode):
     try:
         with torch.no_grad():
             assert fp8.calibrate(model, x4[2:], m4[2:]) == 24
+            sat = fp8.saturation(model, x4[:2], m4[:2])      # the evaluated images against scales calibrated on the others
+            assert sat["tensors"] >= 4 * 22 and sat["saturating"] == 0 and sat["worst_ratio"] <= 1.0, sat
             fp8.enable(model, True, mode)
             cap = {}
             model(x4, m4, capture=cap)
