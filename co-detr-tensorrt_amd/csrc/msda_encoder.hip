@@ -171,9 +171,12 @@ __device__ __forceinline__ void load_raw(Raw<TR, KMAX>& raw, const typename TR::
   }
 }
 
-// floor(a / b) for 0 <= a < 2^22, 0 < b: one reciprocal + a fix-up instead of the ~35-instruction integer division
+// floor(a / b) for 0 <= a < 2^22, 0 < b: one reciprocal + a fix-up instead of the ~35-instruction integer division.
+// v_rcp_f32 (1 ulp) is enough: a * rcp(b) is then within 0.75 of a / b, the truncated quotient within one of the true
+// one, and the two corrections below repair that (the correctly rounded __frcp_rn costs ~10 instructions more per call,
+// a dozen calls per workgroup)
 __device__ __forceinline__ int fdiv(int a, int b) {
-  int q = (int)((float)a * __frcp_rn((float)b));
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
   const int r = a - q * b;
   q += r >= b ? 1 : 0;
   q -= r < 0 ? 1 : 0;
@@ -993,8 +996,13 @@ __device__ __forceinline__ void pass_v3(float (&acc)[8], const float (&aw)[5], c
                                         const unsigned char* __restrict__ vimg, const unsigned pix_bytes,
                                         const EncGeom& g, const int sub) {
   using V = typename TR::vec;
+  using LV = const __attribute__((address_space(3))) V*;
   constexpr unsigned kRow = 64;
+  // the lane's 16-byte slice of a row AND the LDS address of `patch`: the quad broadcast + add then yields the final LDS
+  // address (patch + a as pointer arithmetic costs one more v_add_u32 per corner row pair: the array's LDS base is a
+  // link-time constant the compiler does not fold into the ds_read offset)
   const unsigned lane_byte = (unsigned)sub * 16;
+  const unsigned lds_lane = lane_byte + (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)patch;
   unsigned ad0[NLV], ad1[NLV], mw01[NLV], mw23[NLV], rw01[NLV], rw23[NLV], hw[NLV];
   unsigned bad = 0;
 #pragma unroll
@@ -1029,8 +1037,9 @@ __device__ __forceinline__ void pass_v3(float (&acc)[8], const float (&aw)[5], c
     mw23[i] = isbad ? 0u : rw23[i];
     hw[i] = ((unsigned)h0 << 16) | ((unsigned)w0 & 0xffffu);
     const int xo = tx * (int)kRow + mB[3];
-    ad0[i] = (unsigned)(max(ty, 0) * mB[2] + xo);
-    ad1[i] = (unsigned)(min(ty + 1, H - 1) * mB[2] + xo);
+    // (24-bit multiplies: a row index < 2^15 times a row pitch of a few KB -- v_mad_i32_i24 instead of the 64-bit mad)
+    ad0[i] = (unsigned)(__mul24(max(ty, 0), mB[2]) + xo);
+    ad1[i] = (unsigned)(__mul24(min(ty + 1, H - 1), mB[2]) + xo);
     bad |= isbad ? 1u << (sub + 4 * i) : 0u;
   }
   bad |= dpp_u<kXor2>(bad);
@@ -1043,13 +1052,13 @@ __device__ __forceinline__ void pass_v3(float (&acc)[8], const float (&aw)[5], c
     unsigned wA[2], wB[2];
     auto fetch = [&](int s_, int buf) {
       const int o = s_ & 3, i = s_ >> 2;
-      const unsigned a0 = quad_bcast_add(ad0[i], o, lane_byte), a1 = quad_bcast_add(ad1[i], o, lane_byte);
+      const unsigned a0 = quad_bcast_add(ad0[i], o, lds_lane), a1 = quad_bcast_add(ad1[i], o, lds_lane);
       wA[buf] = quad_bcast_u(mw01[i], o);
       wB[buf] = quad_bcast_u(mw23[i], o);
-      rows[buf][0] = *reinterpret_cast<const V*>(patch + a0);
-      rows[buf][1] = *reinterpret_cast<const V*>(patch + a0 + kRow);
-      rows[buf][2] = *reinterpret_cast<const V*>(patch + a1);
-      rows[buf][3] = *reinterpret_cast<const V*>(patch + a1 + kRow);
+      rows[buf][0] = *(LV)(uintptr_t)a0;
+      rows[buf][1] = *(LV)(uintptr_t)(a0 + kRow);
+      rows[buf][2] = *(LV)(uintptr_t)a1;
+      rows[buf][3] = *(LV)(uintptr_t)(a1 + kRow);
     };
     fetch(0, 0);
     h2 h[4];
@@ -1175,6 +1184,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
       qs[it] = slot_query3(s_meta, L, sl < total ? sl : total - 1, lv, x, y);
       if (CREF) {  // get_reference_points (reference transformer.py:280-305): centre / (valid ratio * size), fp32
         const int* mt = s_meta + lv * kMetaInts;
+        // (IEEE divisions on purpose: the v_rcp_f32 form is 9 instructions shorter per coordinate and measured 3 % SLOWER --
+        // gpurun_out r04n, same box -- the allocation at the 128-register cap is that fragile)
         bx[it] = ((float)x + 0.5f) / (__int_as_float(mt[24]) * (float)mt[1]);
         by[it] = ((float)y + 0.5f) / (__int_as_float(mt[25]) * (float)mt[0]);
       }
@@ -1237,7 +1248,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int row = (e0 + lane) >> 2;
         if (e0 + lane < n) {
           const int y = (int)(((float)row + 0.5f) * inv);
-          const unsigned char* gp = vimg + (src0 + (unsigned)(y * (W - pw) + row) * pix_bytes);
+          // (24-bit multiplies: rows and pixel indices < 2^24, see plan_encoder)
+          const unsigned char* gp = vimg + (src0 + (unsigned)__mul24(__mul24(y, W - pw) + row, (int)pix_bytes));
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                            (__attribute__((address_space(3))) void*)(dst0 + (size_t)e0 * 16), 16, 0, 0);
         }
