@@ -679,7 +679,7 @@ constexpr int kGemmAbl = 0;
 // 160 KiB of LDS; W stays one tile ahead in its 2-slot ring.  In-kernel stamps (tools/micro/gemm256_stamps.hip) show
 // the 2-stage loop waiting for its LDS-DMA ~48 % of the time at 8 images (4300 cycles per k-tile against 2050 of MFMA
 // work): the operand fetch takes ~2 us under load and only one tile time was there to hide it.
-template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, bool XDEEP = false>
+template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, bool XDEEP = false, bool SDMA = false>
 __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* __restrict__ X,
                                                          const unsigned short* __restrict__ W,
                                                          const unsigned short* __restrict__ bias,
@@ -735,6 +735,31 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     gw[q] = W + (size_t)gn * K + chunk * 8;
     gx[q] = X + (size_t)gm * K + chunk * 8;
   }
+  // SDMA: the same pieces addressed as (wave-uniform 64-bit base of the tile's first row and k-tile, in SGPRs) + (per-thread
+  // 32-bit byte offset, fixed for the whole tile): the LDS-DMA is then one inline-assembly instruction per piece -- no
+  // 64-bit vector add, no v_readfirstlane for its LDS destination, eight address registers less (the pointer form spilled
+  // two registers that were reloaded inside the loop, and a scratch reload counts in vmcnt: the counted wait then asked
+  // for half of the tile that was meant to stay in flight)
+  unsigned woff[4], xoff[4];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned char* Wt = reinterpret_cast<const unsigned char*>(W) + (size_t)n0 * K * 2;
+  const unsigned char* Xt = reinterpret_cast<const unsigned char*>(X) + (size_t)m0 * K * 2;
+  if (SDMA) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = q * 64 + (tid >> 3), pos = tid & 7;
+      const int chunk = pos ^ sw<BKT>(r);
+      const int rn = n0 + r < N ? r : N - 1 - n0, rm = m0 + r < M ? r : M - 1 - m0;   // edge tiles: the last row again
+      woff[q] = (unsigned)((rn * K + chunk * 8) * 2);
+      xoff[q] = (unsigned)((rm * K + chunk * 8) * 2);
+    }
+  }
+  auto sdmaW = [&](int q, int kt, unsigned char* slot) {
+    lds_dma16s(Wt + (size_t)kt * (BKT * 2), woff[q], slot + (q * NT + wave_u * 64) * 16);
+  };
+  auto sdmaX = [&](int q, int kt, unsigned char* slot) {
+    lds_dma16s(Xt + (size_t)kt * (BKT * 2), xoff[q], slot + (q * NT + wave_u * 64) * 16);
+  };
   auto issue = [&](int t, int slot) {
     unsigned char* buf = lds + (slot & 1) * kStageBytes;
 #pragma unroll
@@ -759,7 +784,14 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
   };
-  if (XDEEP) {   // issue order W(0), X(0), X(1): the youngest four pieces may stay in flight at the first wait
+  if (XDEEP && SDMA) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sdmaW(q, ktile(0), lds + 3 * kTileBytes);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sdmaX(q, ktile(0), lds);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sdmaX(q, ktile(1), lds + kTileBytes);
+  } else if (XDEEP) {   // issue order W(0), X(0), X(1): the youngest four pieces may stay in flight at the first wait
     const size_t k0 = (size_t)ktile(0) * BKT;
 #pragma unroll
     for (int q = 0; q < 4; ++q) dma16(gw[q] + k0, lds + 3 * kTileBytes + (q * NT + wave * 64) * 16);
@@ -817,6 +849,41 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
 #pragma unroll
       for (int j = 0; j < 8; ++j) b[buf][j] = read_frag<T, BKT>(bufX, wm * 128 + j * 16 + frow, ks * 4 + fchunk);
     };
+    if (SDMA) {
+      // explicit interleave (the inline-assembly pieces are opaque to sched_group_barrier): step-0 fragments, the first two
+      // MFMAs, the step-1 fragments, then eight groups of (3 MFMAs, 1 piece) -- W(t+1) first, it is needed one tile from
+      // now, X(t+2) two -- each closed by a scheduling barrier; then the remaining 6 + 32 MFMAs
+      read_frags(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+      read_frags(1, 1);
+      auto mf0 = [&](int idx) {
+        const int j = idx >> 2, i = idx & 3;
+        acc[i][j] = T::mfma(a[0][i], b[0][j], acc[i][j]);
+      };
+      mf0(0);
+      mf0(1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int ktw = ktile(t + 1), ktx = ktile(t + 2);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        mf0(2 + 3 * g);
+        mf0(3 + 3 * g);
+        mf0(4 + 3 * g);
+        if (g < 4) sdmaW(g, ktw, nbufW);
+        else sdmaX(g - 4, ktx, nbufX);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int idx = 26; idx < 32; ++idx) mf0(idx);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = T::mfma(a[1][i], b[1][j], acc[i][j]);
+      __builtin_amdgcn_sched_group_barrier(0x008, 38, 0);
+      continue;
+    }
     if (!(kGemmAbl & 4)) read_frags(0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
     // ---- k-step 0 ----
@@ -974,9 +1041,21 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto mk = static_cast<const unsigned char*>(mask);
   // A/B switch, default on (8 images: -3 ... -13 % on every Swin stage 1-3 shape, gpurun_out/r02g/xdeep.txt)
   static const bool xdeep = [] { const char* e = getenv("CODETR_GEMM_XDEEP"); return e ? atoi(e) != 0 : true; }();
+  // scalar-base LDS-DMA (SDMA, see the kernel): default for problems of more than one column tile (-1 ... -2.5 % on the Swin
+  // stage 1-3 shapes, +0.3 % images/s end to end; a single column tile -- N = 192 -- measured 6 % slower and keeps the
+  // pointer form); CODETR_GEMM_SDMA=0 restores the pointer form everywhere
+  static const bool sdma_on = [] { const char* e = getenv("CODETR_GEMM_SDMA"); return e ? atoi(e) != 0 : true; }();
+  const bool sdma = sdma_on && tiles_n > 1;
+#define CODETR_L256S(HB, HR) \
+  hipLaunchKernelGGL((linear_256_kernel<T, ACT, HB, HR, true, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n)
 #define CODETR_L256(HB, HR, XD) \
   hipLaunchKernelGGL((linear_256_kernel<T, ACT, HB, HR, XD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n)
-  if (xdeep && K >= 128) {
+  if (xdeep && sdma && K >= 128) {
+    if (bias && R) CODETR_L256S(true, true);
+    else if (bias) CODETR_L256S(true, false);
+    else if (R) CODETR_L256S(false, true);
+    else CODETR_L256S(false, false);
+  } else if (xdeep && K >= 128) {
     if (bias && R) CODETR_L256(true, true, true);
     else if (bias) CODETR_L256(true, false, true);
     else if (R) CODETR_L256(false, true, true);
@@ -988,6 +1067,7 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
     else CODETR_L256(false, false, false);
   }
 #undef CODETR_L256
+#undef CODETR_L256S
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
