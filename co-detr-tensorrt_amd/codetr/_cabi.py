@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -100,6 +100,11 @@ SIGNATURES = {
     "codetr_linear_splitk_plan": (_i32, [_i64, _i64, _i64, _vp]),
     "codetr_linear_splitk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
     "codetr_linear_splitk_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64]),
+    "codetr_linear_sk_workspace_bytes": (_i64, []),
+    "codetr_linear_sk_supported": (_i32, [_i64, _i64, _i64]),
+    "codetr_linear_sk_preferred": (_i32, [_i64, _i64, _i64, _i32, _i32]),
+    "codetr_linear_sk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
+    "codetr_linear_sk_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
     "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_groupnorm_tokens_workspace_bytes": (_i64, [_i64, _i64, _i64]),
@@ -132,7 +137,7 @@ _lib = None
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
-         "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "mask_pyramid": 0,
+         "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "linear_sk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
@@ -146,6 +151,7 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
 RECORDER = None
 _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
+            "codetr_linear_sk_workspace_bytes", "codetr_linear_sk_supported", "codetr_linear_sk_preferred",
             "codetr_msda_encoder_lds_bytes", "codetr_mx_scale_bytes"}
 
 
@@ -160,7 +166,9 @@ class _RecordingLib:
 
         def launch(*args):
             rc = fn(*args)
-            if RECORDER is not None:
+            # only launches that were accepted: a probe that the library turns down (E_UNSUPPORTED, then the caller
+            # retries another form) enqueued nothing and must not reach an exported plan
+            if RECORDER is not None and rc == 0:
                 RECORDER.append((name, args))
             return rc
 
@@ -286,6 +294,49 @@ def linear(x2d, weight, bias, residual2d, act, out2d, row_mask=None, hm_rows=0, 
         row_mask.data_ptr() if row_mask is not None else None,
         out2d.data_ptr(), M, N, K, _ACT[act], hm_rows, hm_head_dim)
     check(rc, "codetr_linear")
+    return out2d
+
+
+_SK_PREFERRED = {}
+
+
+def linear_sk_preferred(M, N, K, act=None, has_residual=False) -> bool:
+    """True where the persistent GEMM (csrc/gemm_sk.hip) measured faster than codetr_linear_* (the library's own rule)"""
+    key = (M, N, K, act, bool(has_residual))
+    v = _SK_PREFERRED.get(key)
+    if v is None:
+        v = _SK_PREFERRED[key] = bool(load().codetr_linear_sk_preferred(M, N, K, _ACT[act], 1 if has_residual else 0))
+    return v
+
+
+_SK_WORKSPACE = {}
+
+
+def linear_sk_workspace(device):
+    """the zero-filled workspace of the stream-K split (flags & 0x40 only), one per device and stream"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SK_WORKSPACE.get(key)
+    if ws is None:
+        with torch.cuda.device(device):
+            ws = _SK_WORKSPACE[key] = torch.zeros(load().codetr_linear_sk_workspace_bytes(), dtype=torch.uint8, device=device)
+    return ws
+
+
+def linear_sk(x2d, weight, bias, residual2d, act, out2d, flags=0):
+    """y = act(x @ w.T + b) (+ r) by the persistent 256-tile GEMM; flags as in include/codetr_hip.h (0 = default;
+    0x40 = stream-K split of the left-over tiles, which needs the workspace)"""
+    lib = load()
+    CALLS["linear"] += 1
+    CALLS["linear_sk"] += 1
+    M, K = x2d.shape
+    N = weight.shape[0]
+    ws = linear_sk_workspace(x2d.device) if flags & 0x40 else None
+    fn = lib.codetr_linear_sk_f16 if x2d.dtype == torch.float16 else lib.codetr_linear_sk_bf16
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(),
+            bias.data_ptr() if bias is not None else None,
+            residual2d.data_ptr() if residual2d is not None else None, out2d.data_ptr(), M, N, K, _ACT[act],
+            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, flags)
+    check(rc, "codetr_linear_sk")
     return out2d
 
 

@@ -101,6 +101,11 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
                     # few output tiles, long K (the neck's extra level as a GEMM): two-pass split-K, fp32 partials
                     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
                     launch = lambda: _cabi.linear_splitk(x2, w, bias, r2, act, out, splits, ws, mk)  # noqa: E731
+                elif (mk is None and not head_major and out.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
+                      and (r2 is None or r2.data_ptr() % 16 == 0) and (bias is None or bias.data_ptr() % 16 == 0)
+                      and _cabi.linear_sk_preferred(x2.shape[0], N, K, act, r2 is not None)):
+                    # the large short-K layers (Swin stages 0-2, the encoder's output projections): persistent GEMM
+                    launch = lambda: _cabi.linear_sk(x2, w, bias, r2, act, out)  # noqa: E731
                 else:
                     launch = lambda: _cabi.linear(x2, w, bias, r2, act, out, mk, hm_rows, hm_hd)  # noqa: E731
                 if LINEAR_PROFILE is None:

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 38
+#define CODETR_HIP_ABI_VERSION 39
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -411,6 +411,30 @@ int codetr_linear_splitk_f16(void *stream, const void *x_dev, const void *w_dev,
 int codetr_linear_splitk_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                               const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
                               int64_t K, int act, int splits, void *workspace_dev, int64_t workspace_bytes);
+
+/* Persistent form of codetr_linear_* for the large layers (Swin stages 0-3 -- reference codetr/swin.py:92-112,
+ * 331-352 -- where TensorRT picked its own GEMM tactic): one resident workgroup per CU walks whole 256 x 256 tiles with
+ * its operand stream running across tile boundaries (csrc/gemm_sk.hip); same semantics as codetr_linear_* without row
+ * mask / head-major output.
+ *   codetr_linear_sk_supported        1 when (M, N, K) is inside the kernel's domain (K % 64 == 0, K >= 128, N % 8 == 0)
+ *   codetr_linear_sk_preferred        1 when it measured faster than codetr_linear_* on this class of problem
+ *                                     (profiles/r04_gemm_sk.txt): hosts call codetr_linear_sk_* then
+ *   codetr_linear_sk_workspace_bytes  size of the caller-owned workspace (fp32 partial tiles + ticket counters of the
+ *                                     stream-K split) on the current device; it must be ZERO-FILLED ONCE before its
+ *                                     first use -- every launch returns the counters to zero -- and must not be shared
+ *                                     by launches that can run concurrently (one per stream); without the 0x40 flag
+ *                                     it is not touched and may be NULL / 0
+ *   codetr_linear_sk_*                flags: 0 (default); 0x40 = stream-K split of the left-over tiles (correct, measured
+ *                                     slower at this model's K); 0x20 = one workgroup per tile (A/B only) */
+int64_t codetr_linear_sk_workspace_bytes(void);
+int codetr_linear_sk_supported(int64_t M, int64_t N, int64_t K);
+int codetr_linear_sk_preferred(int64_t M, int64_t N, int64_t K, int act, int has_residual);
+int codetr_linear_sk_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                         const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act,
+                         void *workspace_dev, int64_t workspace_bytes, int flags);
+int codetr_linear_sk_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                          const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act,
+                          void *workspace_dev, int64_t workspace_bytes, int flags);
 
 /* ------------------------------------------------------------------------------------------
  * Padding-mask pyramid: everything the detection transformer derives from img_masks, one launch.

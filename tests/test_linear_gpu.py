@@ -323,4 +323,6 @@ def test_linear_ln_matches_layernorm_then_linear(M, N, K, act, dtype):
     # shapes outside the short-K kernel: LayerNorm + linear
     with torch.no_grad():
         assert not hip_ops.linear_ln_supported(x[:500], gam, w)
-        assert torch.equal(hip_ops.linear_ln(x[:500], gam, bet, 1e-5, w, b, act=act), two[:500])
+        # (the same two launches on the same rows -- `two` above may come from another GEMM kernel at its row count)
+        assert torch.equal(hip_ops.linear_ln(x[:500], gam, bet, 1e-5, w, b, act=act),
+                           hip_ops.linear(hip_ops.layer_norm(x[:500], gam, bet, 1e-5), w, b, act=act))
