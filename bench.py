@@ -319,6 +319,23 @@ def kernel_rooflines(model, images, masks, device):
             "note": "at the e4m3 rate the kernel's row traffic (x, y, pos, y + pos) is within 2x of its MFMA time: "
                     "the composite floor is max(flops / 5 PF, bytes / 8 TB/s) per launch",
         }
+    wa = kprof.get("window_attention", [])
+    if wa:
+        # HBM-bound: the qkv rows in (3 C halves per token) and the attention output out, each once; the MFMA work
+        # (QK^T and PV over the window's 144 keys, head_dim 32) alongside
+        nbytes = sum(m["rows"] * m["C"] * (3 * 2 + m["out_bytes"]) for _, _, m in wa)
+        fl = sum(4.0 * m["rows"] * m["window"] ** 2 * m["C"] for _, _, m in wa)
+        t = sum(a.elapsed_time(b) for a, b, _ in wa) * 1e-3
+        out["roofline_window_attention"] = {
+            "kernel": "window_attention_kernel (the %d Swin blocks of one forward: shifted-window softmax attention, "
+                      "pad / roll / partition inside)" % len(wa),
+            "bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": pmc.get("window_attention", {}).get("hbm_bytes_per_launch"),
+            "algorithmic_bytes_per_forward": nbytes, "sum_launch_ms": round(t * 1e3, 3),
+            "avg_launch_us": round(t / len(wa) * 1e6, 1),
+            "mfma": {"achieved_TFLOP/s": round(fl / t / 1e12, 1), "frac": round(fl / t / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+        }
     enc = [(a, b, m) for a, b, m in kprof.get("msda_fused", []) if m["Nq"] == m["S"]]
     if enc:
         from codetr import _cabi as _cabi_mod
@@ -495,9 +512,15 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the extra host-feed pass")
     ap.add_argument("--no-fp8-line", action="store_true", help="skip the fp8 (config 5) sub-record of the fp16 run")
+    ap.add_argument("--pad", type=float, default=0.9,
+                    help="valid fraction per side of the `padded` sub-record's images (1.0 = skip it)")
+    ap.add_argument("--quick", action="store_true", help="headline line only: no sub-records, rooflines or CPU baseline")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU / gloo: launcher, sharding, gather, timing and report with stand-in detections, no model")
     a = ap.parse_args()
+    if a.quick:
+        a.no_cpu_baseline = a.no_roofline = a.no_host_feed = a.no_fp8_line = True
+        a.pad = 1.0
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if not launched and a.gpus > 1:
@@ -620,6 +643,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    rank_stats = {}
+
     def timed(feed_host):
         for _ in range(a.warmup):
             step(feed_host)
@@ -635,12 +660,22 @@ def main():
         elapsed = time.perf_counter() - t0
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
         if world > 1:
-            t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
+            # MAX over ranks is the job's time; MIN and the count of ranks that answered make a straggler or a missing
+            # rank visible in the line (ranks_seen: an all_reduce of ones over the same backend -- RCCL on a real run)
+            dv = "cpu" if share else device
+            t = torch.tensor([elapsed], device=dv, dtype=torch.float64)
+            tmin, ones = t.clone(), torch.ones(1, device=dv, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+            rank_stats.update(ranks_seen=int(ones.item()),
+                              per_rank_images_per_s_min=round(a.steps * a.batch / float(t.item()), 3),
+                              per_rank_images_per_s_max=round(a.steps * a.batch / float(tmin.item()), 3))
             elapsed = float(t.item())
         return elapsed, per_step
 
     elapsed, per_step_ms = timed(a.feed == "host")
+    headline_rank_stats = dict(rank_stats)
     host_feed = None
     if a.feed == "hbm" and not a.no_host_feed:
         e2, _ = timed(True)
@@ -655,28 +690,58 @@ def main():
         # e4m3 (no calibration) + the encoder FFN on e4m3 with static scales calibrated on OTHER images; same K steps
         from codetr import fp8
 
-        gc = torch.Generator(device=device).manual_seed(4242)
-        nb0 = max(1, a.batch // nstreams)
-        calib = torch.randn(nb0, 3, H, W, device=device, generator=gc).to(dtype)
-        fp8.calibrate(model, calib, masks[:nb0].contiguous())
-        sat8 = fp8.saturation(model, images[:nb0].contiguous(), masks[:nb0].contiguous())   # the TIMED images vs those scales
-        fp8.enable(model)
-        del calib
-        fp16_graphs, graphs = graphs, capture()
-        e8, per8 = timed(False)
-        fp8_line = {"images_per_s": round(a.steps * a.batch / e8, 3), "ms_per_step": round(e8 / a.steps * 1e3, 3),
-                    "p50_ms_per_image": round(per8[len(per8) // 2] / a.batch, 3), "config": fp8.report(model),
-                    "static_scale_headroom": sat8,
-                    "dtype": "fp8 e4m3: Swin stage 1-3 linears with MX block scales (e8m0 per 32 channels, hardware-applied), "
-                             "encoder FFN with static scales calibrated on other images; f16 elsewhere, f32 accumulation"}
-        if not a.no_roofline:
-            nb = max(1, a.batch // max(1, nstreams))
-            r8 = kernel_rooflines(model, images[:nb].contiguous(), masks[:nb].contiguous(), device)
-            for k in ("roofline_fp8", "roofline_ffn_fp8"):
-                if k in r8:
-                    fp8_line[k] = r8[k]
-        fp8.enable(model, False)
-        graphs = fp16_graphs
+        fp16_graphs = graphs
+        try:
+            gc = torch.Generator(device=device).manual_seed(4242)
+            nb0 = max(1, a.batch // nstreams)
+            calib = torch.randn(nb0, 3, H, W, device=device, generator=gc).to(dtype)
+            fp8.calibrate(model, calib, masks[:nb0].contiguous())
+            sat8 = fp8.saturation(model, images[:nb0].contiguous(), masks[:nb0].contiguous())   # the TIMED images vs those scales
+            fp8.enable(model)
+            del calib
+            graphs = capture()
+            e8, per8 = timed(False)
+            fp8_line = {"images_per_s": round(a.steps * a.batch / e8, 3), "ms_per_step": round(e8 / a.steps * 1e3, 3),
+                        "p50_ms_per_image": round(per8[len(per8) // 2] / a.batch, 3), "config": fp8.report(model),
+                        "static_scale_headroom": sat8,
+                        "dtype": "fp8 e4m3: Swin stage 1-3 linears with MX block scales (e8m0 per 32 channels, hardware-applied), "
+                                 "encoder FFN with static scales calibrated on other images; f16 elsewhere, f32 accumulation"}
+            if not a.no_roofline:
+                nb = max(1, a.batch // max(1, nstreams))
+                r8 = kernel_rooflines(model, images[:nb].contiguous(), masks[:nb].contiguous(), device)
+                for k in ("roofline_fp8", "roofline_ffn_fp8"):
+                    if k in r8:
+                        fp8_line[k] = r8[k]
+        except Exception as e:  # noqa: BLE001 -- the optional sub-record must never cost the measured fp16 line
+            torch.cuda.synchronize(device)
+            fp8_line = {"error": repr(e)}
+        finally:
+            fp8.enable(model, False)
+            graphs = fp16_graphs
+
+    # ---- the same K steps on PADDED images (reference inferencer.py:354-358: mask = 1 on the last 10 %
+    # of the rows and columns; the graphs read the masks from device memory, so the captured launch lists serve) ----
+    padded_line = None
+    if world == 1 and a.pad < 1.0:
+        try:
+            hv, wv = int(H * a.pad), int(W * a.pad)
+            for _, m_ in subs:
+                m_.zero_()
+                m_[:, hv:, :] = 1
+                m_[:, :, wv:] = 1
+            ep, perp = timed(False)
+            padded_line = {"valid_fraction_per_side": a.pad, "images_per_s": round(a.steps * a.batch / ep, 3),
+                           "ms_per_step": round(ep / a.steps * 1e3, 3),
+                           "p50_ms_per_image": round(perp[len(perp) // 2] / a.batch, 3),
+                           "vs_unpadded": round((a.steps * a.batch / ep) / (a.steps * a.batch * world / elapsed), 4),
+                           "note": "same graphs, same K steps, padding masks = 1 on the last %d %% of rows and columns "
+                                   "(valid ratios skew the encoder's reference points)" % round((1 - a.pad) * 100)}
+        except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize(device)
+            padded_line = {"error": repr(e)}
+        finally:
+            for _, m_ in subs:
+                m_.zero_()
 
     if rank == 0:
         total_images = a.steps * a.batch * world
@@ -711,10 +776,14 @@ def main():
             "reference_note": "reference publishes 79.5 ms/image (TensorRT fp16, RTX 4090, batch 1, README.md:33); "
                               "not the same hardware, so vs_baseline stays null",
         }
+        if world > 1:
+            out.update(headline_rank_stats)
         if host_feed is not None:
             out["host_feed"] = host_feed
         if fp8_line is not None:
             out["fp8"] = fp8_line
+        if padded_line is not None:
+            out["padded"] = padded_line
         if fp8_report is not None:
             out["config"]["fp8"] = fp8_report
         if world == 1 and not a.no_roofline:
@@ -723,6 +792,19 @@ def main():
             # operator and the latency are single-image quantities.
             op = msda_roofline(1, H, W, dtype, device)
             out["latency_batch1"] = batch1_latency(model, images[:1].contiguous(), masks[:1].contiguous(), device)
+            # ... and at the reference's other two published sizes (README.md:33-35: 1920x1280, 1152x768, 608x608)
+            by_size = {a.res: out["latency_batch1"]}
+            for rw, rh in ((1152, 768), (608, 608)):
+                if "%dx%d" % (rw, rh) == a.res or dtype == torch.float32:
+                    continue
+                try:
+                    gi = torch.Generator(device=device).manual_seed(7)
+                    xi1 = torch.randn(1, 3, rh, rw, device=device, generator=gi).to(dtype)
+                    by_size["%dx%d" % (rw, rh)] = batch1_latency(model, xi1, torch.zeros(1, rh, rw, device=device, dtype=dtype), device)
+                except Exception as e:  # noqa: BLE001
+                    torch.cuda.synchronize(device)
+                    by_size["%dx%d" % (rw, rh)] = {"error": repr(e)}
+            out["latency_batch1_by_size"] = by_size
             if dtype == torch.float16:   # (fp16 and fp8 runs)
                 nb = max(1, a.batch // max(1, nstreams))
                 xi, xm = images[:nb].contiguous(), masks[:nb].contiguous()
@@ -735,7 +817,24 @@ def main():
                         # the same kernel with the default init's zero offset weights (round 1's number): best case
                         set_offset_noise(model, 0.0)
                         out["roofline_msda_zero_noise"] = kernel_rooflines(model, xi, xm, device).get("roofline_msda")
+                        # ... and with a wider trained-like spread (the share of samples that leave the
+                        # staged windows, and what they cost, beyond 2 px)
+                        for px in (4.0, 8.0):
+                            set_offset_noise(model, px)
+                            r = kernel_rooflines(model, xi, xm, device).get("roofline_msda")
+                            if r is not None:
+                                r["offsets"] = msda_offset_stats(model, xi, xm)
+                                out["roofline_msda_%dpx" % int(px)] = r
                         set_offset_noise(model, a.offset_noise_px)
+                    if padded_line is not None and "error" not in padded_line:
+                        # the encoder MSDA kernel on the padded images (eager forward, same launch shapes)
+                        pm = xm.clone()
+                        pm[:, int(H * a.pad):, :] = 1
+                        pm[:, :, int(W * a.pad):] = 1
+                        r = kernel_rooflines(model, xi, pm, device).get("roofline_msda")
+                        if r is not None:
+                            r["offsets"] = msda_offset_stats(model, xi, pm)
+                            out["padded"]["roofline_msda"] = r
             else:
                 out["roofline"] = op
         if world == 1 and not a.no_cpu_baseline:
@@ -763,13 +862,18 @@ def dry_run(a, world, rank):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    seen, tmin_s = 1, elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
+        tmin, ones = t.clone(), torch.ones(1, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        elapsed, tmin_s, seen = float(t.item()), float(tmin.item()), int(ones.item())
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "dry run (no model, no GPU)", "value": None, "unit": "images/s", "n_gpus": world,
+                          "ranks_seen": seen, "slowest_over_fastest_rank": round(elapsed / max(tmin_s, 1e-9), 3),
                           "steps": a.steps, "warmup": a.warmup, "dry_run": True, "gather_ok": ok,
                           "global_batch": a.batch * world, "ms_per_step": round(elapsed / (a.warmup + a.steps) * 1e3, 3),
                           "scaling": "weak", "higher_is_better": True}))

@@ -648,7 +648,7 @@ def mha_attention(q, k, v, num_heads, out):
 def linear_xadd_supported(M, N, K, dtype) -> bool:
     """mirror of the library's rule for codetr_linear_xadd_* (the X-stationary kernel's shapes)"""
     return (dtype in (torch.float16, torch.bfloat16) and K in (192, 256) and N % 8 == 0 and 128 <= N <= 1536
-            and M >= 128 * 256 and os.environ.get("CODETR_GEMM_XS", "1") != "0")
+            and M >= 128 * 256)
 
 
 def linear_ln(x2d, gamma, beta, eps, w, bias, act, out2d) -> bool:

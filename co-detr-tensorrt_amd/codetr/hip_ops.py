@@ -502,8 +502,10 @@ def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_s
     out = torch.empty((B, L, C3 // 3), dtype=FP8 if (out_scale is not None or out_mx) else qkv.dtype, device=qkv.device)
     scales = torch.empty(_cabi.mx_scale_bytes(B * L, C3 // 3), dtype=torch.uint8, device=qkv.device) if out_mx else None
     with torch.cuda.device(qkv.device):
-        _cabi.window_attention(qkv, qkv_bias, rel_bias.contiguous(), out, B, H, W, num_heads, window_size, shift, out_scale,
-                               scales)
+        _timed("window_attention", {"rows": B * L, "C": C3 // 3, "heads": num_heads, "window": window_size,
+                                    "out_bytes": out.element_size()},
+               lambda: _cabi.window_attention(qkv, qkv_bias, rel_bias.contiguous(), out, B, H, W, num_heads, window_size,
+                                              shift, out_scale, scales), qkv.device)
     return (out, scales) if out_mx else out
 
 

@@ -171,7 +171,7 @@ __device__ __forceinline__ typename T::frag read_frag(const unsigned char* lds_t
 // lgkmcnt(0); the instruction itself only counts in vmcnt, which the callers wait on by hand.
 __device__ __forceinline__ void lds_dma16s(const unsigned char* src, unsigned voff, unsigned char* dst) {
   const unsigned lds_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)dst);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds_addr) : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_n() {
@@ -196,7 +196,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // s_waitcnt vmcnt: a __syncthreads() would drain the DMA queue, cdna_hip_programming.md section 5).
 // SPLITK: blockIdx.y picks a range of `kps` K tiles; the block's fp32 partial tile goes to Y viewed as
 // float[gridDim.y][M][N] (no bias / activation / residual: splitk_reduce_kernel applies them to the sum).
-template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, int BKT, int STAGES, bool SPLITK = false, bool SPREAD = false>
+template <class T, int ACT, bool HAS_BIAS, bool HAS_RES, int BKT, int STAGES, bool SPLITK = false>
 __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* __restrict__ X,
                                                           const unsigned short* __restrict__ W,
                                                           const unsigned short* __restrict__ bias,
@@ -251,84 +251,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
   const int nk = SPLITK ? (K / BKT - kt0 < kps ? K / BKT - kt0 : kps) : K / BKT;
   const int frow = lane & 15, fchunk = lane >> 4;
   constexpr int KS = BKT / 32;
-  if constexpr (STAGES == 2 && SPREAD) {
-    // ---- 2-buffer pipeline with the DMA of tile t+1 spread over the MFMAs of tile t ----------------------------
-    // Measured variant, NOT the default: instead of a burst of LPS LDS-DMA instructions behind the barrier, one piece
-    // per pair of MFMAs.  It is what makes the one-wave-per-SIMD FFN kernel fast (ffn_fused.hip), but here, with 2-3
-    // waves per SIMD to cover the issue cost, the same-box A/B over the model's 22 shapes came out 2.10 ms vs 2.05 ms
-    // for the burst (better only on K >= 768 / N >= 768 shapes, worse on every K <= 384 one).
-    // Source pointers are per-thread constants (piece_src), advanced by one K tile per iteration.
-    constexpr int PT = BKT / 16;  // pieces per operand tile
-    const unsigned short* gw[PT];
-    const unsigned short* gx[PT];
-#pragma unroll
-    for (int q = 0; q < PT; ++q) {
-      gw[q] = piece_src<BKT>(W, N, K, n0, q, tid) + (size_t)kt0 * BKT;
-      gx[q] = piece_src<BKT>(X, M, K, m0, q, tid) + (size_t)kt0 * BKT;
-    }
-#pragma unroll
-    for (int q = 0; q < PT; ++q) {
-      dma_piece(gw[q], lds, q, wave);
-      dma_piece(gx[q], lds + kTileBytes, q, wave);
-    }
-    for (int t = 0; t < nk; ++t) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();  // everyone's part of tile t is in LDS; everyone is done reading tile t-1
-      const unsigned char* bufW = lds + (t & 1) * kStageBytes;
-      const unsigned char* bufX = bufW + kTileBytes;
-      unsigned char* nextW = lds + ((t + 1) & 1) * kStageBytes;
-      // past the last tile the pieces re-fetch it into the idle buffer (no branch inside the pinned schedule); the
-      // s_waitcnt in front of the epilogue barrier drains them
-      const size_t koff = (size_t)(t + 1 < nk ? t + 1 : t) * BKT;
-      typename T::frag a[2][4], b[2][4];
-      auto read_frags = [&](int ks, int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[buf][i] = read_frag<T, BKT>(bufW, wn * 64 + i * 16 + frow, ks * 4 + fchunk);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[buf][j] = read_frag<T, BKT>(bufX, wm * 64 + j * 16 + frow, ks * 4 + fchunk);
-      };
-      read_frags(0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) read_frags(ks + 1, (ks + 1) & 1);
-        if (ks == 0) {
-#pragma unroll
-          for (int piece = 0; piece < 2 * PT; ++piece) {
-            if (piece < PT) dma_piece(gw[piece] + koff, nextW, piece, wave);
-            else dma_piece(gx[piece - PT] + koff, nextW + kTileBytes, piece - PT, wave);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e >> 2][e & 3] = T::mfma(a[ks & 1][e >> 2], b[ks & 1][e & 3], acc[e >> 2][e & 3]);
-        // Pinned order.  The DMA pieces go out early in the tile, one per pair of MFMAs, so that the last of them has
-        // the rest of the tile's MFMAs to land before the next barrier:
-        //   BK 64: step 0 = 2 MFMAs, the 8 fragment reads of step 1, 7 x (2 MFMAs, 1 piece); step 1 = 2 MFMAs, 1 piece,
-        //          14 MFMAs.     BK 32: 4 x (2 MFMAs, 1 piece), 8 MFMAs.
-        if (KS == 2 && ks == 0) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-          for (int g = 0; g < 7; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          }
-        } else if (KS == 2) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
-        } else {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        }
-      }
-    }
-    wait_vmcnt<0>();  // the redundant pieces of the last iteration have landed
-  } else {
+  {
   auto issue = [&](int t) {
     unsigned char* buf = lds + (t % STAGES) * kStageBytes;
     stage_tile<BKT>(W, N, K, n0, (kt0 + t) * BKT, buf, tid);
@@ -525,20 +448,13 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const unsigned short* 
 //   (stores off / K loop off) shows the short-K layers bound by bytes through the CU's vector-memory path --
 //   L2->LDS operand re-reads (3.35 GB at ~17 TB/s for the encoder FFN up-projection) + staging + stores -- not by
 //   exposed latency.  The lever that remains is a larger tile (fewer operand re-reads); see DESIGN.md section 4.
-// CODETR_GEMM_CFG=<bk><stages> (322, 324, 642) overrides, for A/B measurements only.
 //   Grids of at most one workgroup per CU (the decoder's 900-query layers: 16 tiles) gain nothing from occupancy;
 //     their time is the chain of per-K-step DMA latencies, so they take the 64-deep step (half the steps) as well.
-int pipeline_cfg(int64_t K, int64_t tiles) {
-  static const int forced = [] {
-    const char* e = getenv("CODETR_GEMM_CFG");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced == 324 || forced == 322 || forced == 642) return forced;
-  const int cfg = (K <= 256 && tiles > 256) ? 322 : 642;
-  return forced == 1 ? 1000 + cfg : cfg;  // CODETR_GEMM_CFG=1: DMA pieces spread over the MFMAs (A/B only, see kernel)
-}
+// (The A/B overrides of this choice -- a 4-deep ring, the DMA pieces spread over the MFMAs -- measured slower on every
+// shape in rounds 1-3 and are gone from the library; profiles/r02_*, r03_gemm256_ablation.txt keep the numbers.)
+int pipeline_cfg(int64_t K, int64_t tiles) { return (K <= 256 && tiles > 256) ? 322 : 642; }
 
-template <class T, int ACT, int BKT, int STAGES, bool SPREAD = false>
+template <class T, int ACT, int BKT, int STAGES>
 int launch_cfg(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
                const void* mask, int M, int N, int K, int hm_rows, int hm_hd) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -549,10 +465,10 @@ int launch_cfg(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES, false, SPREAD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
-  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES, false, SPREAD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
-  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES, false, SPREAD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
-  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES, false, SPREAD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  if (bias && R) hipLaunchKernelGGL((linear_kernel<T, ACT, true, true, BKT, STAGES, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else if (bias) hipLaunchKernelGGL((linear_kernel<T, ACT, true, false, BKT, STAGES, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else if (R) hipLaunchKernelGGL((linear_kernel<T, ACT, false, true, BKT, STAGES, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
+  else hipLaunchKernelGGL((linear_kernel<T, ACT, false, false, BKT, STAGES, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n, hm_rows, hm_hd, 0);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -639,10 +555,7 @@ template <class T, int ACT>
 int launch_act(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
                const void* mask, int M, int N, int K, int hm_rows, int hm_hd) {
   switch (pipeline_cfg(K, (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN))) {
-    case 324: return launch_cfg<T, ACT, 32, 4>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
     case 322: return launch_cfg<T, ACT, 32, 2>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
-    case 1322: return launch_cfg<T, ACT, 32, 2, true>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
-    case 1642: return launch_cfg<T, ACT, 64, 2, true>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
     default: return launch_cfg<T, ACT, 64, 2>(st, X, W, bias, R, Y, mask, M, N, K, hm_rows, hm_hd);
   }
 }
@@ -1011,21 +924,15 @@ __global__ __launch_bounds__(512) void linear_256_kernel(const unsigned short* _
 #endif
 }
 
-// the 256-tile kernel: K >= 256 (CODETR_BIG_MIN_K; K = 256 layers whose N fills 256-wide tiles -- value / output
+// the 256-tile kernel: K >= 256 (K = 256 layers whose N fills 256-wide tiles -- value / output
 // projections, enc_output -- measured 5-15 % faster here than on the X-stationary kernel), see the rule at the end
 bool big_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
-  static const int off = [] {
-    const char* e = getenv("CODETR_GEMM_BIG");
-    return e ? atoi(e) == 0 : 0;
-  }();
-  static const int64_t min_k = [] { const char* e = getenv("CODETR_BIG_MIN_K"); return e ? atoll(e) : 256; }();
-  if (off || hm_hd != 0 || K < min_k || K % 64 != 0 || N % 8 != 0) return false;
+  if (hm_hd != 0 || K < 256 || K % 64 != 0 || N % 8 != 0) return false;
   const int64_t tn = (N + 255) / 256, tm = (M + 255) / 256;
-  static const int64_t kBigMinTiles = [] { const char* e = getenv("CODETR_BIG_MIN_TILES"); return e ? atoll(e) : 200; }();
-  // at least ~0.8 tiles per CU (CODETR_BIG_MIN_TILES; 200 measured better than 512 for the single-image shapes: Swin
-  // stage-2 fc1 78 -> 67 us, stage-3 qkv 58 -> 46 us), and little of the 256-wide tile wasted: >= 87.5 % of the tile columns real,
+  // at least ~0.8 tiles per CU (200 measured better than 512 for the single-image shapes: Swin stage-2 fc1 78 -> 67 us,
+  // stage-3 qkv 58 -> 46 us), and little of the 256-wide tile wasted: >= 87.5 % of the tile columns real,
   // or >= 75 % when one column tile covers N (X is then read exactly once: Swin stage-0 fc2, N = 192, 806 -> 678 us)
-  return tm * tn >= kBigMinTiles && (N * 8 >= tn * 256 * 7 || (tn == 1 && N * 4 >= 256 * 3));
+  return tm * tn >= 200 && (N * 8 >= tn * 256 * 7 || (tn == 1 && N * 4 >= 256 * 3));
 }
 
 template <class T, int ACT>
@@ -1039,32 +946,24 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  // A/B switch, default on (8 images: -3 ... -13 % on every Swin stage 1-3 shape, gpurun_out/r02g/xdeep.txt)
-  static const bool xdeep = [] { const char* e = getenv("CODETR_GEMM_XDEEP"); return e ? atoi(e) != 0 : true; }();
-  // scalar-base LDS-DMA (SDMA, see the kernel): default for problems of more than one column tile (-1 ... -2.5 % on the Swin
-  // stage 1-3 shapes, +0.3 % images/s end to end; a single column tile -- N = 192 -- measured 6 % slower and keeps the
-  // pointer form); CODETR_GEMM_SDMA=0 restores the pointer form everywhere
-  static const bool sdma_on = [] { const char* e = getenv("CODETR_GEMM_SDMA"); return e ? atoi(e) != 0 : true; }();
-  const bool sdma = sdma_on && tiles_n > 1;
+  // X two k-tiles ahead in a 3-slot ring (8 images: -3 ... -13 % on every Swin stage 1-3 shape); scalar-base LDS-DMA for
+  // problems of more than one column tile (-1 ... -2.5 %; a single column tile -- N = 192 -- measured 6 % slower with it
+  // and keeps the pointer form)
+  const bool sdma = tiles_n > 1;
 #define CODETR_L256S(HB, HR) \
   hipLaunchKernelGGL((linear_256_kernel<T, ACT, HB, HR, true, true>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n)
-#define CODETR_L256(HB, HR, XD) \
-  hipLaunchKernelGGL((linear_256_kernel<T, ACT, HB, HR, XD>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n)
-  if (xdeep && sdma && K >= 128) {
+#define CODETR_L256(HB, HR) \
+  hipLaunchKernelGGL((linear_256_kernel<T, ACT, HB, HR, true, false>), grid, block, 0, st, x, w, b, r, y, mk, M, N, K, tiles_n)
+  if (sdma) {
     if (bias && R) CODETR_L256S(true, true);
     else if (bias) CODETR_L256S(true, false);
     else if (R) CODETR_L256S(false, true);
     else CODETR_L256S(false, false);
-  } else if (xdeep && K >= 128) {
-    if (bias && R) CODETR_L256(true, true, true);
-    else if (bias) CODETR_L256(true, false, true);
-    else if (R) CODETR_L256(false, true, true);
-    else CODETR_L256(false, false, true);
   } else {
-    if (bias && R) CODETR_L256(true, true, false);
-    else if (bias) CODETR_L256(true, false, false);
-    else if (R) CODETR_L256(false, true, false);
-    else CODETR_L256(false, false, false);
+    if (bias && R) CODETR_L256(true, true);
+    else if (bias) CODETR_L256(true, false);
+    else if (R) CODETR_L256(false, true);
+    else CODETR_L256(false, false);
   }
 #undef CODETR_L256
 #undef CODETR_L256S
@@ -1335,11 +1234,6 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
 // must not straddle blocks: the six decoder value projections as one N = 1536 GEMM, not the 32-wide MSDA heads).  K = 384 (Swin stage 1) fits the registers but measured 20-30 % slower
 // than the tiled kernel (2 workgroups per CU, 48 MFMAs per barrier) and stays there.
 bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
-  static const int off = [] {
-    const char* e = getenv("CODETR_GEMM_XS");
-    return e ? atoi(e) == 0 : 0;
-  }();
-  if (off) return false;
   // (K = 64: the patch-embedding GEMM of the Swin stem, act 0 / no residual only)
   return (K == 192 || K == 256 || K == 64) && N % 8 == 0 && N >= 128 && N <= 1536 && M >= 128 * 256 && hm_hd % 64 == 0;
 }

@@ -94,7 +94,7 @@ __device__ __forceinline__ int key64(int row) {
 // wave-uniform LDS address `lds_addr` + lane * 16.  M0 is written in the statement that reads it.
 __device__ __forceinline__ void lds_dma16(const unsigned char* src, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds_addr)
-               : "memory");
+               : "memory", "m0");
 }
 
 template <int N>
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_memcpy(&f, &v[j], 16);
                 acc[i][jh + j] += f;
               }
+              __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (lane == 0) __hip_atomic_store(a.counters + t * kWaves + wave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -38,6 +38,10 @@
 
 #include "codetr_hip.h"
 
+#ifdef MSDA_ENC_ABLATE
+#include "../../tools/micro/diag_env.h"
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -454,7 +458,7 @@ struct TileId {
 // overlap is an L2 hit instead of a second trip over the fabric -- a raster walk re-fetched every value row about twice
 // (FETCH_SIZE 1.47 x the algorithmic bytes); 4 region rows x the 8 heads of a column = 2.3 MB of neighbourhoods in
 // flight per XCD, inside its 4 MB L2.
-constexpr int kBand = 4;   // default; CODETR_MSDA_BAND overrides (A/B switch, 1 = raster walk; results do not depend on it)
+constexpr int kBand = 4;   // tiles of a band walk 4 region columns at a time (1 = raster walk measured slower; results do not depend on it)
 __device__ __forceinline__ TileId decode_tile(unsigned tile, const EncGeom& g) {
   TileId t;
   const int unit = fdiv((int)tile, g.M);
@@ -966,13 +970,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   encoder_v2_body<TR, DEPTH, KPRE, SCHED, ABL>(value, offs, logits, ref, out, g, off_stride, logit_stride);
 }
 // three workgroups per CU (<= 53 KB of LDS each, <= 168 registers)
-template <class TR, int DEPTH = 1, int KPRE = 0>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void msda_encoder_v2_occ3_kernel(
-    const typename TR::storage* __restrict__ value, const typename TR::storage* __restrict__ offs,
-    const typename TR::storage* __restrict__ logits, const typename TR::storage* __restrict__ ref,
-    typename TR::storage* __restrict__ out, const EncGeom g, const int off_stride, const int logit_stride) {
-  encoder_v2_body<TR, DEPTH, KPRE, true, 0>(value, offs, logits, ref, out, g, off_stride, logit_stride);
-}
 
 // =====================================================================================================================
 // v3 (fp16, 5 levels x 4 points): v2's packed-half gather, restructured for OCCUPANCY.
@@ -1397,16 +1394,18 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
   if (S * M * (int64_t)(D * sizeof(ST)) > 0xffffffffLL) return CODETR_E_TOO_LARGE;  // 32-bit in-image offsets
   const int64_t blocks = B * g.RX * g.RY * M;
   if (blocks >= (1 << 22)) return CODETR_E_UNSUPPORTED;  // (the kernel's cheap tile decode)
+  // (No run-time switches: the band width, the static level walk and the one-pass kernel's variants were A/B-measured in
+  // rounds 2-3 -- profiles/r02_msda_encoder_ab.txt, r03_msda_encoder_ablation.txt -- and the losers are gone.  Timing
+  // experiments build this file with -DMSDA_ENC_ABLATE, which reads its knobs through tools/micro/diag_env.h.)
 #ifdef MSDA_ENC_ABLATE
-  // timing experiments only (make EXTRA=-DMSDA_ENC_ABLATE): bits skip staging / gather / prefetch / stores -- such a
-  // build returns WRONG results and must never ship; the production library has no run-time switch for this
-  static const int ablate = getenv("CODETR_MSDA_ENC_ABLATE") ? atoi(getenv("CODETR_MSDA_ENC_ABLATE")) : 0;
+  static const int ablate = diag_env_int("CODETR_MSDA_ENC_ABLATE", 0);
+  static const int v2_cfg = diag_env_int("CODETR_MSDA_V2_CFG", 0);
 #else
   constexpr int ablate = 0;
+  constexpr int v2_cfg = 0;
 #endif
-  static const int band_env = [] { const char* e = getenv("CODETR_MSDA_BAND"); return e ? atoi(e) : kBand; }();
-  static const bool static_env = [] { const char* e = getenv("CODETR_MSDA_STATIC"); return e ? atoi(e) != 0 : true; }();
-  static const bool v2_env = [] { const char* e = getenv("CODETR_MSDA_V2"); return e ? atoi(e) != 0 : true; }();
+  constexpr int band_env = kBand;
+  constexpr bool static_env = true, v2_env = true;
   g.band = band_env < 1 ? 1 : (band_env > 64 ? 64 : band_env);
   if (passes == 3) {   // three-pass kernel: fp16, 5 levels x 4 points, regions of <= 64 * kMaxIt queries
     if (!std::is_same<TR, F16>::value || P != 4 || L != 5 || g.slots_cap > 64 * kMaxIt || pl.lds_v3 > (size_t)kMaxLds ||
@@ -1425,9 +1424,7 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
       if (e != hipSuccess) return (int)e;
       done3[dev].fetch_or(bit, std::memory_order_release);
     }
-    // diagnostic (occupancy experiments): a floor on the LDS request limits the workgroups per CU; results unchanged
-    static const size_t lds_floor = [] { const char* e = getenv("CODETR_MSDA_LDS_FLOOR"); return e ? (size_t)atol(e) : (size_t)0; }();
-    const size_t lds3 = pl.lds_v3 > lds_floor ? pl.lds_v3 : (lds_floor > (size_t)kMaxLds ? (size_t)kMaxLds : lds_floor);
+    const size_t lds3 = pl.lds_v3;
     hipLaunchKernelGGL(k3, dim3((unsigned)blocks), dim3(kThreads), lds3, st, static_cast<const _Float16*>(value),
                        static_cast<const _Float16*>(offs), static_cast<const _Float16*>(logits),
                        static_cast<const _Float16*>(ref), static_cast<_Float16*>(out), g, (int)off_stride, (int)logit_stride);
@@ -1441,18 +1438,10 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
   auto kern = P == 4 ? (kmax5 ? (L == 5 && static_env ? msda_encoder_kernel<TR, 5, true, true> : msda_encoder_kernel<TR, 5, true>)
                               : msda_encoder_kernel<TR, 8, true>)
                      : (kmax5 ? msda_encoder_kernel<TR, 5, false> : msda_encoder_kernel<TR, 8, false>);
-  static const int v2_cfg = [] { const char* e = getenv("CODETR_MSDA_V2_CFG"); return e ? atoi(e) : 0; }();
   typedef void (*V2Fn)(const _Float16*, const _Float16*, const _Float16*, const _Float16*, _Float16*, const EncGeom, const int, const int);
   V2Fn v2fn = msda_encoder_v2_kernel<F16>;
-  switch (v2_cfg) {
-    case 1: v2fn = msda_encoder_v2_kernel<F16, 2, kPre, true>; break;
-    case 2: v2fn = msda_encoder_v2_kernel<F16, 1, 0, true>; break;
-    case 3: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, false>; break;
-    case 4: v2fn = msda_encoder_v2_kernel<F16, 2, 0, true>; break;
-    case 5: v2fn = msda_encoder_v2_kernel<F16, 2, 1, true>; break;
-    case 6: v2fn = msda_encoder_v2_occ3_kernel<F16, 1, 0>; break;
-    case 7: v2fn = msda_encoder_v2_occ3_kernel<F16, 1, 1>; break;
 #ifdef MSDA_ENC_ABLATE   // timing experiments only: WRONG results
+  switch (v2_cfg) {
     case 101: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 1>; break;
     case 102: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 2>; break;
     case 103: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 3>; break;
@@ -1460,9 +1449,9 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
     case 108: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 8>; break;
     case 107: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 7>; break;
     case 115: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 15>; break;
-#endif
     default: break;
   }
+#endif
   const void* kfn = v2 ? reinterpret_cast<const void*>(v2fn) : reinterpret_cast<const void*>(kern);
   // > 64 KB of dynamic LDS needs the attribute on the CURRENT device's function object: remembered per (device, kernel)
   // -- a process-wide "already set" flag would skip it when the process moves to a second GPU

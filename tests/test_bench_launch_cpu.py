@@ -23,6 +23,7 @@ def test_gpus_2_launches_its_own_ranks_and_prints_one_json_line():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] and out["gather_ok"] and out["global_batch"] == 6
+    assert out["ranks_seen"] == 2 and out["slowest_over_fastest_rank"] >= 1.0
     assert out["steps"] == 3 and out["warmup"] == 1 and out["value"] is None
 
 
@@ -35,6 +36,7 @@ def test_gpus_8_dry_run_the_scale_the_driver_launches():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["gather_ok"] and out["global_batch"] == 64 and out["scaling"] == "weak"
+    assert out["ranks_seen"] == 8   # every rank answered the all_reduce of ones
 
 
 def test_single_rank_dry_run_needs_no_launcher():

@@ -1,9 +1,9 @@
 #!/bin/bash
 # SQ counter passes over tools/bench_msda_encoder.py (run on the GPU box): per-launch means for both MSDA kernels.
-#   bash tools/pmc_msda_encoder.sh <out.txt> <noise> <windows 0|1> [CODETR_MSDA_V2 value] [passes 1|3] [counts 0|1]
+#   bash tools/pmc_msda_encoder.sh <out.txt> <noise> <windows 0|1> - [passes 1|3] [counts 0|1]   (4th argument: unused since round 4)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-out=$1; noise=$2; win=$3; export CODETR_MSDA_V2=${4:-1}; passes=${5:-1}; counts=${6:-0}
-echo "== noise $noise px, windows $win, CODETR_MSDA_V2=$CODETR_MSDA_V2, passes $passes, fp32 reference points $counts (batch 1, 1920x1280 encoder shape) ==" >> $out
+out=$1; noise=$2; win=$3; passes=${5:-1}; counts=${6:-0}
+echo "== noise $noise px, windows $win, passes $passes, fp32 reference points $counts (batch 1, 1920x1280 encoder shape) ==" >> $out
 for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" \
            "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM" \
            "FETCH_SIZE" "WRITE_SIZE"; do
