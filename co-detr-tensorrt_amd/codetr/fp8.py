@@ -102,20 +102,47 @@ def saturation(model, batch_inputs, img_masks):
     return {"tensors": n, "saturating": int(sat), "worst_ratio": round(worst, 4)}
 
 
-def enable(model, on=True, mode=None):
+# The e4m3 GEMMs that ship: the selection of the sensitivity map (tools/fp8_sensitivity.py, profiles/r04_fp8_sensitivity.json).
+# {stage: ops}; stage = log2(C / 192) of the Swin block (stage 0 has K = 192, not a multiple of 128: never fp8);
+# None = every GEMM the kernels take (the round-3 behaviour, kept as `select="all"`).
+DEFAULT_SELECT = None
+DEFAULT_FFN = True
+
+
+def block_stage(block):
+    """Swin stage of a block from its width: C = 192 * 2^stage in Swin-L (embed_dims of the config otherwise)"""
+    c = block.attn.w_msa.qkv.weight.shape[1]
+    s, base = 0, getattr(block, "_stage_base", 192)
+    while base * 2 <= c:
+        base *= 2
+        s += 1
+    return s
+
+
+def enable(model, on=True, mode=None, select="default", ffn="default"):
     """switch the blocks to the fp8 path: Swin blocks to MX block scales (mode "mx", no calibration needed) or to their
     calibrated static scales (mode "static"); calibrated FFNs to the fused e4m3 kernel.  Blocks whose shapes the fp8
-    GEMM does not take at run time keep running fp16."""
+    GEMM does not take at run time keep running fp16.
+    select (mode "mx"): which GEMMs run in e4m3 -- "default" = DEFAULT_SELECT, "all" / None = all four of every block,
+    or {stage: iterable of "qkv" | "proj" | "fc1" | "fc2"} (stages not named stay fp16); ffn: the encoder FFNs too."""
     mode = mode or MODE
+    sel = DEFAULT_SELECT if select == "default" else (None if select == "all" else select)
+    use_ffn = DEFAULT_FFN if ffn == "default" else bool(ffn)
     for b in _blocks(model):
+        b.fp8_ops = None
         if not on:
             b.fp8_mode = None
         elif mode == "mx":
-            b.fp8_mode = "mx"
+            if sel is None:
+                b.fp8_mode = "mx"
+            else:
+                ops = tuple(o for o in ("qkv", "proj", "fc1", "fc2") if o in tuple(sel.get(block_stage(b), ())))
+                b.fp8_mode = "mx" if ops else None
+                b.fp8_ops = ops or None
         else:
             b.fp8_mode = "run" if hasattr(b, "_fp8_scales") else None
     for f in _ffns(model):
-        f.fp8_mode = "run" if (on and hasattr(f, "_fp8_scales")) else None
+        f.fp8_mode = "run" if (on and use_ffn and hasattr(f, "_fp8_scales")) else None
 
 
 def report(model):

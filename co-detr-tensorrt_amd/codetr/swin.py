@@ -245,8 +245,11 @@ class SwinBlock(nn.Module):
                 return self._forward_fp8_calibrate(x, hw_shape)
             if mode == "run" and all(hip_ops.linear_fp8_supported(rows, w) for w in self._fp8_weights()):
                 return self._forward_fp8(x, hw_shape)
-            if mode == "mx" and all(hip_ops.linear_fp8_supported(rows, w) for w in self._fp8_weights()):
-                return self._forward_fp8mx(x, hw_shape)
+            if mode == "mx":
+                ops = getattr(self, "fp8_ops", None) or ("qkv", "proj", "fc1", "fc2")
+                ws = dict(zip(("qkv", "proj", "fc1", "fc2"), self._fp8_weights()))
+                if ops and all(hip_ops.linear_fp8_supported(rows, ws[o]) for o in ops):
+                    return self._forward_fp8mx(x, hw_shape)
         if (isinstance(n1, nn.LayerNorm) and self.attn.takes_norm(x, hw_shape)
                 and hip_ops.linear_ln_supported(x, n1.weight, self.attn.w_msa.qkv.weight)):
             # norm1 folded into the qkv GEMM's operand load (only that GEMM reads the normalised rows)
@@ -310,17 +313,44 @@ class SwinBlock(nn.Module):
 
     def _forward_fp8mx(self, x, hw_shape):
         """the same chain with MX block scales on every activation (one e8m0 exponent per 32 channels, chosen by the
-        producer from the block's own maximum; applied by the scaled MFMA in hardware): no calibration, no static scale"""
+        producer from the block's own maximum; applied by the scaled MFMA in hardware): no calibration, no static scale.
+        ``self.fp8_ops`` (default: all four) names the GEMMs of this block that run in e4m3 -- the others stay on the fp16
+        kernels, with the producer in front of each chosen accordingly (codetr/fp8.py: the shipped selection comes from the
+        sensitivity map, profiles/r04_fp8_sensitivity.json)"""
         n1, n2, m = self.norm1, self.norm2, self.attn.w_msa
         fc1, fc2 = self.ffn.layers[0][0], self.ffn.layers[1]
-        h8, hs = hip_ops.layer_norm_fp8mx(x, n1.weight, n1.bias, n1.eps)
-        qkv = hip_ops.linear_fp8mx(h8, hs, m.qkv.weight, m.qkv.bias)
-        o8, os_ = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads,
-                                                self.attn.window_size, self.attn.shift_size, out_mx=True)
-        x = hip_ops.linear_fp8mx(o8, os_, m.proj.weight, m.proj.bias, residual=x)
-        h8, hs = hip_ops.layer_norm_fp8mx(x, n2.weight, n2.bias, n2.eps)
-        g8, gs = hip_ops.linear_fp8mx(h8, hs, fc1.weight, fc1.bias, act=self.ffn.act, out_mx=True)
-        return hip_ops.linear_fp8mx(g8, gs, fc2.weight, fc2.bias, residual=x)
+        ops = getattr(self, "fp8_ops", None) or ("qkv", "proj", "fc1", "fc2")
+        if "qkv" in ops:
+            h8, hs = hip_ops.layer_norm_fp8mx(x, n1.weight, n1.bias, n1.eps)
+            qkv = hip_ops.linear_fp8mx(h8, hs, m.qkv.weight, m.qkv.bias)
+        elif hip_ops.linear_ln_supported(x, n1.weight, m.qkv.weight):
+            qkv = hip_ops.linear_ln(x, n1.weight, n1.bias, n1.eps, m.qkv.weight, m.qkv.bias)
+        else:
+            qkv = hip_ops.linear(hip_ops.layer_norm(x, n1.weight, n1.bias, n1.eps), m.qkv.weight, m.qkv.bias)
+        if "proj" in ops:
+            o8, os_ = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads,
+                                                    self.attn.window_size, self.attn.shift_size, out_mx=True)
+            x = hip_ops.linear_fp8mx(o8, os_, m.proj.weight, m.proj.bias, residual=x)
+        else:
+            o = hip_ops.swin_window_attention(qkv, m.qkv.bias, m.relative_position_bias(), hw_shape, m.num_heads,
+                                              self.attn.window_size, self.attn.shift_size)
+            x = hip_ops.linear(o, m.proj.weight, m.proj.bias, residual=x)
+        if "fc1" in ops:
+            h8, hs = hip_ops.layer_norm_fp8mx(x, n2.weight, n2.bias, n2.eps)
+            if "fc2" in ops:
+                g8, gs = hip_ops.linear_fp8mx(h8, hs, fc1.weight, fc1.bias, act=self.ffn.act, out_mx=True)
+            else:
+                g = hip_ops.linear_fp8mx(h8, hs, fc1.weight, fc1.bias, act=self.ffn.act)
+        else:
+            if hip_ops.linear_ln_supported(x, n2.weight, fc1.weight):
+                g = hip_ops.linear_ln(x, n2.weight, n2.bias, n2.eps, fc1.weight, fc1.bias, act=self.ffn.act)
+            else:
+                g = hip_ops.linear(hip_ops.layer_norm(x, n2.weight, n2.bias, n2.eps), fc1.weight, fc1.bias, act=self.ffn.act)
+            if "fc2" in ops:
+                g8, gs = hip_ops.cast_fp8mx(g)
+        if "fc2" in ops:
+            return hip_ops.linear_fp8mx(g8, gs, fc2.weight, fc2.bias, residual=x)
+        return hip_ops.linear(g, fc2.weight, fc2.bias, residual=x)
 
 
 class SwinBlockSequence(nn.Module):

@@ -131,3 +131,33 @@ def test_kernel_name_whitelist_matches_sources():
     for foreign in ("void (anonymous namespace)::elementwise_kernel_with_index<int, ...>", "void at::native::vectorized_elementwise_kernel<4",
                     "Cijk_Alik_Bljk_HHS_BH", "Memcpy DtoD (Device -> Device)", "__amd_rocclr_copyBuffer", "triton_poi_fused_add_0"):
         assert not is_own_kernel(foreign), foreign
+
+
+def test_recorder_keeps_only_accepted_launches():
+    """hip_ops probes the three-pass encoder kernel and retries another form when the library answers
+    E_UNSUPPORTED; the rejected probe enqueued nothing and must not reach an exported launch plan (the in-process replay and
+    the C++ runner would fail on it).  A rejected call returns before any HIP call, so this runs without a GPU."""
+    from codetr import _cabi
+
+    _cabi.RECORDER = []
+    try:
+        lib = _cabi.load()
+        one = ctypes.c_void_p(16)
+        assert lib.codetr_linear_sk_f16(None, one, one, None, None, one, 1000, 256, 192, 3, None, 0, 0) == -4   # act = 3
+        assert lib.codetr_linear_sk_f16(None, None, one, None, None, one, 1000, 256, 192, 0, None, 0, 0) == -1  # null x
+        assert _cabi.RECORDER == []
+        # pure host queries are never recorded either
+        assert lib.codetr_linear_sk_supported(1000, 256, 192) == 1
+        assert _cabi.RECORDER == []
+    finally:
+        _cabi.RECORDER = None
+
+
+def test_product_library_reads_no_environment_variable():
+    """an exported plan or a deployment must not change kernels with the environment -- the A/B
+    switches live in diagnostic builds (tools/micro/diag_env.h) only"""
+    import glob
+
+    for path in glob.glob(os.path.join(ROOT, "co-detr-tensorrt_amd", "csrc", "*.hip")) + \
+            glob.glob(os.path.join(ROOT, "co-detr-tensorrt_amd", "csrc", "*.h")):
+        assert "getenv" not in open(path).read(), path

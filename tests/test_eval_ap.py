@@ -51,3 +51,24 @@ def test_proxy_ground_truth_from_detections():
     many = [dict(boxes=np.arange(40.).reshape(10, 4), scores=np.linspace(0.9, 0.5, 10), labels=np.zeros(10, int))]
     top3 = eval_ap.detections_as_ground_truth(many, 0.0, top=3)
     assert len(top3[0]["labels"]) == 3 and np.array_equal(top3[0]["boxes"], many[0]["boxes"][:3])
+
+
+def test_ignore_regions_absorb_detections_like_coco_crowds():
+    """a detection inside a crowd region is neither a true nor a false positive (overlap = intersection over ITS area, any
+    number of detections per region); the region itself is not ground truth"""
+    import eval_ap
+
+    gt = [dict(boxes=[[0, 0, 10, 10], [100, 100, 300, 300]], labels=[1, 1], ignore=[False, True])]
+    det = [dict(boxes=[[110, 110, 130, 130], [0, 0, 10, 10], [500, 500, 510, 510], [150, 150, 170, 170]],
+                scores=[0.95, 0.9, 0.5, 0.4], labels=[1, 1, 1, 1])]
+    r = eval_ap.coco_ap(det, gt)
+    # ranking after the two crowd detections leave it: TP (0.9), FP (0.5) -> precision 1 at recall 1
+    assert r["n_gt"] == 1 and r["AP"] == 1.0
+    # the same boxes without the flag: the crowd box is a second (missed... matched at IoU 0.01? no) ground truth and the
+    # detections on it are false positives ahead of the true one
+    r2 = eval_ap.coco_ap(det, [dict(boxes=gt[0]["boxes"], labels=gt[0]["labels"])])
+    assert r2["n_gt"] == 2 and r2["AP"] < 0.5
+    # a class that only has ignore regions is not evaluated
+    only = eval_ap.coco_ap([dict(boxes=[[100, 100, 120, 120]], scores=[0.9], labels=[2])],
+                           [dict(boxes=[[100, 100, 300, 300]], labels=[2], ignore=[True])])
+    assert only["n_gt"] == 0

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round evidence run (on the GPU box, through gpurun): bench lines, kernel traces at 8 images / 1 image per step, PMC
 # passes (each in its own run, never with a trace).  Writes only small folded files under gpurun_out/final/.
-#   tools/collect_profiles.sh <tag>      e.g. r02
-tag=${1:-r02}
+#   tools/collect_profiles.sh <tag>      e.g. r04
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
 if [ -z "$SKIP_BENCH" ]; then
@@ -10,7 +10,7 @@ timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/bench.err
 timeout 600 python bench.py --dtype fp8 --no-cpu-baseline > $out/${tag}_bench_fp8.json 2>> $out/bench.err
 fi
 # (--no-fp8-line: the default line's fp8 sub-record would put its calibration forward and e4m3 kernels into the fp16 traces)
-common="--no-cpu-baseline --no-graph --no-roofline --no-host-feed --no-fp8-line"
+common="--no-cpu-baseline --no-graph --no-roofline --no-host-feed --no-fp8-line --pad 1.0"
 b8="--streams 1 --steps 3 --warmup 1 $common"
 rm -rf /tmp/tr8 /tmp/tr1 /tmp/pf /tmp/pw /tmp/pm
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr8 -- python bench.py $b8 > /tmp/tr8.log 2>&1
@@ -27,6 +27,12 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python 
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python bench.py $p4 > /tmp/pw.log 2>&1
 python tools/pmc_fold.py --fetch "$(find /tmp/pf -name '*counter_collection.csv' | head -1)" --write "$(find /tmp/pw -name '*counter_collection.csv' | head -1)" \
    --label "bench.py $p4 (4 images = one replayed graph of the default run)" > $out/${tag}_pmc_traffic.json
+# ... and the matrix-pipe busy counters at the same launch shapes (own pass: counters never share a run with a trace)
+rm -rf /tmp/pm4
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pm4 -- python bench.py $p4 > /tmp/pm4.log 2>&1
+python tools/pmc_fold.py --fetch "$(find /tmp/pf -name '*counter_collection.csv' | head -1)" --write "$(find /tmp/pw -name '*counter_collection.csv' | head -1)" \
+   --mfma "$(find /tmp/pm4 -name '*counter_collection.csv' | head -1)" --stats $out/${tag}_batch4_kernel_stats.csv \
+   --label "bench.py $p4 (4 images = one replayed graph of the default run)" > $out/${tag}_pmc_b4_fp16.json
 # BASELINE config 3 (1152x768): HBM GB/s + MFMA busy per kernel group
 c3="--res 1152x768 --batch 1 --steps 4 --warmup 1 $common"
 rm -rf /tmp/pf /tmp/pw /tmp/pm /tmp/tr3

@@ -44,7 +44,12 @@ def box_iou(a, b):
 
 def coco_ap(detections, ground_truth, iou_thrs=IOU_THRS, max_dets=100):
     """detections: list (one per image) of dict(boxes [N,4] xyxy, scores [N], labels [N]);
-    ground_truth: list of dict(boxes [M,4], labels [M]).  -> dict(AP, AP50, AP75, per_class {label: AP}, n_gt)."""
+    ground_truth: list of dict(boxes [M,4], labels [M], optional ignore [M] bool -- COCO `iscrowd` regions).
+    -> dict(AP, AP50, AP75, per_class {label: AP}, n_gt).
+    Ignore regions follow the COCO procedure: a detection is matched to an unmatched regular box first (highest IoU above
+    the threshold); failing that, to an ignore region whose overlap -- intersection over the DETECTION's area, a crowd box
+    can absorb any number of detections -- reaches the threshold, and is then neither a true nor a false positive;
+    ignore regions do not count as ground truth."""
     assert len(detections) == len(ground_truth)
     dets = []
     for d in detections:
@@ -53,35 +58,50 @@ def coco_ap(detections, ground_truth, iou_thrs=IOU_THRS, max_dets=100):
         order = np.argsort(-s[ok], kind="stable")[:max_dets]
         dets.append(dict(boxes=np.asarray(d["boxes"], dtype=np.float64).reshape(-1, 4)[ok][order], scores=s[ok][order],
                          labels=np.asarray(d["labels"]).reshape(-1)[ok][order]))
-    gts = [dict(boxes=np.asarray(g["boxes"], dtype=np.float64).reshape(-1, 4), labels=np.asarray(g["labels"]).reshape(-1))
-           for g in ground_truth]
-    classes = sorted(set(int(c) for g in gts for c in g["labels"]))
+    gts = []
+    for g in ground_truth:
+        lab = np.asarray(g["labels"]).reshape(-1)
+        ign = np.asarray(g.get("ignore", np.zeros(len(lab), dtype=bool)), dtype=bool).reshape(-1)
+        gts.append(dict(boxes=np.asarray(g["boxes"], dtype=np.float64).reshape(-1, 4), labels=lab, ignore=ign))
+    classes = sorted(set(int(c) for g in gts for c in g["labels"][~g["ignore"]]))
     T = len(iou_thrs)
     ap = np.full((len(classes), T), np.nan)
     for ci, c in enumerate(classes):
-        scores, tp = [], [[] for _ in range(T)]
+        scores, tp, dropped = [], [[] for _ in range(T)], [[] for _ in range(T)]
         n_gt = 0
         for d, g in zip(dets, gts):
-            gb = g["boxes"][g["labels"] == c]
+            of_c = g["labels"] == c
+            gb, gi = g["boxes"][of_c & ~g["ignore"]], g["boxes"][of_c & g["ignore"]]
             sel = d["labels"] == c
             db, ds = d["boxes"][sel], d["scores"][sel]
             n_gt += len(gb)
             if len(db) == 0:
                 continue
             iou = box_iou(db, gb) if len(gb) else np.zeros((len(db), 0))
+            if len(gi):   # overlap with an ignore region: intersection over the detection's own area
+                lt = np.maximum(db[:, None, :2], gi[None, :, :2])
+                rb = np.minimum(db[:, None, 2:], gi[None, :, 2:])
+                inter = np.clip(rb - lt, 0, None).prod(-1)
+                area = np.clip(db[:, 2:] - db[:, :2], 0, None).prod(-1)
+                ioa = (inter / np.maximum(area[:, None], 1e-12)).max(1)
+            else:
+                ioa = np.zeros(len(db))
             scores.append(ds)
             for ti, thr in enumerate(iou_thrs):
                 taken = np.zeros(len(gb), dtype=bool)
                 hit = np.zeros(len(db), dtype=bool)
+                drop = np.zeros(len(db), dtype=bool)
                 for i in range(len(db)):   # detections of one image arrive sorted by score
-                    if len(gb) == 0:
-                        break
-                    cand = np.where(~taken, iou[i], -1.0)
-                    j = int(cand.argmax())
-                    if cand[j] >= thr:
-                        taken[j] = True
-                        hit[i] = True
+                    if len(gb):
+                        cand = np.where(~taken, iou[i], -1.0)
+                        j = int(cand.argmax())
+                        if cand[j] >= thr:
+                            taken[j] = True
+                            hit[i] = True
+                            continue
+                    drop[i] = ioa[i] >= thr
                 tp[ti].append(hit)
+                dropped[ti].append(drop)
         if n_gt == 0:
             continue
         if not scores:
@@ -91,6 +111,10 @@ def coco_ap(detections, ground_truth, iou_thrs=IOU_THRS, max_dets=100):
         order = np.argsort(-s, kind="stable")
         for ti in range(T):
             t = np.concatenate(tp[ti])[order]
+            t = t[~np.concatenate(dropped[ti])[order]]   # detections absorbed by an ignore region leave the ranking
+            if len(t) == 0:
+                ap[ci, ti] = 0.0
+                continue
             ctp, cfp = np.cumsum(t), np.cumsum(~t)
             rec = ctp / n_gt
             prec = ctp / np.maximum(ctp + cfp, 1)
@@ -104,7 +128,7 @@ def coco_ap(detections, ground_truth, iou_thrs=IOU_THRS, max_dets=100):
         return dict(AP=float("nan"), AP50=float("nan"), AP75=float("nan"), per_class={}, n_gt=0)
     thr = list(np.round(iou_thrs, 2))
     out = dict(AP=float(ap[valid].mean()), per_class={classes[i]: float(ap[i].mean()) for i in np.where(valid)[0]},
-               n_gt=int(sum(len(g["labels"]) for g in gts)))
+               n_gt=int(sum(int((~g["ignore"]).sum()) for g in gts)))
     out["AP50"] = float(ap[valid][:, thr.index(0.5)].mean()) if 0.5 in thr else float("nan")
     out["AP75"] = float(ap[valid][:, thr.index(0.75)].mean()) if 0.75 in thr else float("nan")
     return out
@@ -185,10 +209,8 @@ def run_coco(args):
     cat_to_label = {c: i for i, c in enumerate(cat_ids)}
     by_img = {}
     for a in ann["annotations"]:
-        if a.get("iscrowd", 0):
-            continue
-        x, y, w, h = a["bbox"]
-        by_img.setdefault(a["image_id"], []).append(([x, y, x + w, y + h], cat_to_label[a["category_id"]]))
+        x, y, w, h = a["bbox"]   # crowd regions stay, flagged: detections on them are neither true nor false positives
+        by_img.setdefault(a["image_id"], []).append(([x, y, x + w, y + h], cat_to_label[a["category_id"]], bool(a.get("iscrowd", 0))))
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
     model, meta = codetr.build_CoDETR(args.config, args.weights, "cuda:0")
     model = model.to(dtype)
@@ -200,7 +222,7 @@ def run_coco(args):
         p = inf([rgb], device="cuda:0", dtype=dtype)["predictions"][0]
         dets.append(dict(boxes=p["bboxes"], scores=p["scores"], labels=p["labels"]))
         g = by_img.get(im["id"], [])
-        gts.append(dict(boxes=[b for b, _ in g], labels=[c for _, c in g]))
+        gts.append(dict(boxes=[b for b, _, _ in g], labels=[c for _, c, _ in g], ignore=[i for _, _, i in g]))
     r = coco_ap(dets, gts)
     print(json.dumps({k: r[k] for k in ("AP", "AP50", "AP75", "n_gt")}, indent=1))
 
