@@ -25,7 +25,7 @@ def main():
     from codetr import _cabi, hip_ops
 
     if os.environ.get("CODETR_LIB"):   # timing experiments: a diagnostic build of the library (e.g. -DMSDA_ENC_ABLATE)
-        _cabi.LIB_PATH = os.environ["CODETR_LIB"]
+        _cabi.LIB_PATH, _cabi._lib, _cabi._rec_lib = os.environ["CODETR_LIB"], None, None   # (import codetr loaded the product build)
 
     dev = "cuda:0"
     shapes = [(320, 480), (160, 240), (80, 120), (40, 60), (20, 30)]

@@ -112,6 +112,11 @@ int main(int argc, char** argv) {
       // encoder (40920 tokens per image, 256 channels)
       {"enc.value", 40920 * s, 256, 256, 0, false},
       {"enc.out", 40920 * s, 256, 256, 0, true},
+      // the X-stationary kernel's shapes (encoder at 204600 tokens per image, Swin stage 0 at 153600)
+      {"xs.offlog", 204600 * s, 480, 256, 0, false},
+      {"xs.s0qkv", 153600 * s, 576, 192, 0, false},
+      {"xs.s0proj", 153600 * s, 192, 192, 0, true},
+      {"xs.s0fc1", 153600 * s, 768, 192, 2, false},
   };
   if (quick) shapes.resize(9);
   const int64_t ws_bytes = wsb();
