@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -105,6 +105,9 @@ SIGNATURES = {
     "codetr_linear_sk_preferred": (_i32, [_i64, _i64, _i64, _i32, _i32]),
     "codetr_linear_sk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
     "codetr_linear_sk_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
+    "codetr_decoder_layer_supported": (_i32, [_i32] * 7),
+    "codetr_decoder_layer_blob_halfs": (_i64, [_i32] * 4),
+    "codetr_decoder_layer_f16": (_i32, [_vp] * 18 + [_i64, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, ctypes.c_float]),
     "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_groupnorm_tokens_workspace_bytes": (_i64, [_i64, _i64, _i64]),
@@ -142,7 +145,7 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
          "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0,
-         "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0, "ffn_fp8": 0}
+         "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0, "ffn_fp8": 0, "decoder_layer": 0}
 
 
 # Launch recording (codetr/export.py): while RECORDER is a list, every launch-type entry point called through `load()`
@@ -152,7 +155,8 @@ RECORDER = None
 _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
             "codetr_linear_sk_workspace_bytes", "codetr_linear_sk_supported", "codetr_linear_sk_preferred",
-            "codetr_msda_encoder_lds_bytes", "codetr_mx_scale_bytes"}
+            "codetr_msda_encoder_lds_bytes", "codetr_mx_scale_bytes", "codetr_decoder_layer_supported",
+            "codetr_decoder_layer_blob_halfs"}
 
 
 class _RecordingLib:
@@ -643,6 +647,27 @@ def mha_attention(q, k, v, num_heads, out):
             q.shape[1], k.shape[1], num_heads, 32, q.stride(1), k.stride(1), v.stride(1), out.stride(1))
     check(rc, "codetr_mha_attention")
     return out
+
+
+def decoder_layer_supported(embed_dims, num_heads, num_levels, num_points, hidden, ref_dim, pos_feat) -> bool:
+    return bool(load().codetr_decoder_layer_supported(embed_dims, num_heads, num_levels, num_points, hidden, ref_dim, pos_feat))
+
+
+def decoder_layer_blob_halfs(which, num_levels, num_points, hidden) -> int:
+    """element count of a packed weight blob of codetr_decoder_layer_f16: which = 0 tail | 1 head | 2 pos | 3 final norm"""
+    return int(load().codetr_decoder_layer_blob_halfs(which, num_levels, num_points, hidden))
+
+
+def decoder_layer(x, attn, qpos, ref, vr32, value, shapes, starts, tail_w, pos_w, head_w, final_norm, x_out, ref_out,
+                  qpos_out, qk_out, v_out, B, Nq, S, L, P, hidden, eps, temperature):
+    """one launch of codetr_decoder_layer_f16 (include/codetr_hip.h); tensors or None, see the header for the roles"""
+    CALLS["decoder_layer"] += 1
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    rc = load().codetr_decoder_layer_f16(current_stream_ptr(x.device), p(x), p(attn), p(qpos), p(ref), p(vr32), p(value),
+                                         p(shapes), p(starts), p(tail_w), p(pos_w), p(head_w), p(final_norm), p(x_out),
+                                         p(ref_out), p(qpos_out), p(qk_out), p(v_out), B, Nq, S, L, P, hidden, float(eps),
+                                         float(temperature))
+    check(rc, "codetr_decoder_layer_f16")
 
 
 def linear_xadd_supported(M, N, K, dtype) -> bool:

@@ -124,11 +124,125 @@ class DinoTransformerDecoder(nn.Module):
                               emb(pos_tensor[..., 3])), dim=-1)
         raise ValueError(f"Unknown pos_tensor shape(-1):{n}")
 
+    # ------------------------------------------------------------------ one launch per layer (csrc/decoder_layer.hip)
+    def _fused_weights(self, reg_branches):
+        """Packed weights of codetr_decoder_layer_f16 for every layer, or None when the decoder is not the shape that
+        kernel serves (post-norm DINO layer: MultiheadAttention(256, 8), MultiScaleDeformableAttention(8 heads of 32),
+        ReLU FFN, box refinement through a 3-layer reg branch, 2-layer ref_point_head).  Built once per parameter set
+        (hip_ops.derived): tail blob per layer, head blob per layer, the shared ref_point_head blob, the output norm."""
+        from . import _cabi
+        from .multi_scale_deformable_attention import HEAD_MAJOR_VALUE, MultiScaleDeformableAttention
+        from .transformer_layers import MultiheadAttention
+        if os.environ.get("CODETR_DEC_FUSED", "1") == "0" or HEAD_MAJOR_VALUE or reg_branches is None:
+            return None
+        C = self.embed_dims
+        if len(reg_branches) < len(self.layers):
+            return None
+        order = ("self_attn", "norm", "cross_attn", "norm", "ffn", "norm")
+        lin = lambda m, o, i: isinstance(m, nn.Linear) and m.weight.shape == (o, i) and m.bias is not None  # noqa: E731
+        rp = list(self.ref_point_head)
+        if not (len(rp) == 3 and lin(rp[0], C, 2 * C) and isinstance(rp[1], nn.ReLU) and lin(rp[2], C, C)):
+            return None
+        geo = None
+        params = []
+        for lid, layer in enumerate(self.layers):
+            if layer.operation_order != order or layer.pre_norm:
+                return None
+            sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
+            if not (isinstance(sa, MultiheadAttention) and isinstance(ca, MultiScaleDeformableAttention)):
+                return None
+            if sa.attn.in_proj_weight is None or sa.attn.in_proj_bias is None or sa.attn.out_proj.bias is None:
+                return None
+            fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
+            g = (ca.num_heads, ca.num_levels, ca.num_points, fc1.out_features)
+            if geo is None:
+                geo = g
+            rb = list(reg_branches[lid])
+            if not (g == geo and sa.num_heads == 8 and ffn.act == "relu" and ffn.add_identity and ffn.fp8_mode is None
+                    and lin(fc1, g[3], C) and lin(fc2, C, g[3]) and lin(ca.output_proj, C, C)
+                    and ca.sampling_offsets.bias is not None and ca.attention_weights.bias is not None
+                    and len(rb) == 5 and lin(rb[0], C, C) and lin(rb[2], C, C) and lin(rb[4], 4, C)
+                    and isinstance(rb[1], nn.ReLU) and isinstance(rb[3], nn.ReLU)
+                    and all(isinstance(n, nn.LayerNorm) and n.weight is not None and n.eps == self.norm.eps
+                            for n in layer.norms)):
+                return None
+            params += [p for p in layer.parameters()] + [p for p in reg_branches[lid].parameters()]
+        params += list(self.ref_point_head.parameters()) + list(self.norm.parameters())
+        if any(p.dtype != torch.float16 or not p.is_cuda for p in params):
+            return None
+        M, L, P, F = geo
+        if not _cabi.decoder_layer_supported(C, M, L, P, F, 4, C // 2):
+            return None
+
+        def build():
+            cat = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).contiguous()  # noqa: E731
+            tails, heads = [], []
+            for lid, layer in enumerate(self.layers):
+                sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
+                n1, n2, n3 = layer.norms
+                fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
+                rb = list(reg_branches[lid])
+                pad = rb[4].bias.new_zeros(4)
+                tails.append(cat([sa.attn.out_proj.weight, sa.attn.out_proj.bias, n1.weight, n1.bias,
+                                  ca.sampling_offsets.weight, ca.attention_weights.weight, ca.sampling_offsets.bias,
+                                  ca.attention_weights.bias, ca.output_proj.weight, ca.output_proj.bias, n2.weight, n2.bias,
+                                  fc1.weight, fc1.bias, fc2.weight, fc2.bias, n3.weight, n3.bias,
+                                  rb[0].weight, rb[0].bias, rb[2].weight, rb[2].bias, rb[4].weight, rb[4].bias, pad]))
+                Wi, bi = sa.attn.in_proj_weight, sa.attn.in_proj_bias               # rows [q | k | v]
+                heads.append(cat([Wi[: 2 * C], bi[: 2 * C], Wi[2 * C:], bi[2 * C:]]))
+            pos = cat([rp[0].weight, rp[0].bias, rp[2].weight, rp[2].bias])
+            fin = cat([self.norm.weight, self.norm.bias])
+            sizes = [_cabi.decoder_layer_blob_halfs(w, L, P, F) for w in range(4)]
+            if (any(t.numel() != sizes[0] for t in tails) or any(h.numel() != sizes[1] for h in heads)
+                    or pos.numel() != sizes[2] or fin.numel() != sizes[3]):
+                raise AssertionError("decoder_layer weight blobs do not match the library's layout")
+            return dict(tails=tails, heads=heads, pos=pos, fin=fin, L=L, P=P, F=F)
+
+        return hip_ops.derived(params, "_codetr_decoder_blobs", build)
+
+    def _forward_fused(self, blobs, query, v_all, reference_points, valid_ratios, spatial_shapes, level_start_index):
+        """6 x (self-attention core, one codetr_decoder_layer_f16 launch) + the head-only launch in front."""
+        from . import _cabi
+        B, Nq, C = query.shape
+        S = v_all[0].shape[1]
+        L, P, F = blobs["L"], blobs["P"], blobs["F"]
+        vr32 = valid_ratios._codetr_f32.contiguous()
+        dev = query.device
+        new = lambda *shape: torch.empty(shape, dtype=query.dtype, device=dev)  # noqa: E731
+        x, ref = query.contiguous(), reference_points.contiguous()
+        qpos, qk, v = new(B, Nq, C), new(B, Nq, 2 * C), new(B, Nq, C)
+        eps, nl = self.norm.eps, len(self.layers)
+        with torch.cuda.device(dev):
+            _cabi.decoder_layer(x, None, None, ref, vr32, None, None, None, None, blobs["pos"], blobs["heads"][0], None,
+                                None, None, qpos, qk, v, B, Nq, S, L, P, F, eps, 10000.0)
+            for lid in range(nl):
+                attn = new(B, Nq, C)
+                _cabi.mha_attention(qk[..., :C], qk[..., C:], v, 8, attn)
+                last = lid + 1 == nl
+                x_out, ref_out = new(B, Nq, C), new(B, Nq, 4)
+                qpos2, qk2, v2 = (None, None, None) if last else (new(B, Nq, C), new(B, Nq, 2 * C), new(B, Nq, C))
+                _cabi.decoder_layer(x, attn, qpos, ref, vr32, v_all[lid].contiguous(), spatial_shapes, level_start_index,
+                                    blobs["tails"][lid], None if last else blobs["pos"],
+                                    None if last else blobs["heads"][lid + 1], blobs["fin"] if last else None,
+                                    x_out, ref_out, qpos2, qk2, v2, B, Nq, S, L, P, F, eps, 10000.0)
+                x, ref, qpos, qk, v = x_out, ref_out, qpos2, qk2, v2
+        return x, ref
+
     def forward_bf(self, query, value, key_padding_mask, reference_points, valid_ratios, reg_branches, **kw):
         """query [B,Nq,C], value [B,S,C], reference_points [B,Nq,4] unactivated."""
         out = query
         vr = None   # (only the ATen formulation below needs the tiled valid ratios)
         v_all = self._project_values(value, key_padding_mask)
+        if (query.is_cuda and query.dtype == torch.float16 and reference_points.shape[-1] == 4
+                and reference_points.dtype == query.dtype and getattr(valid_ratios, "_codetr_f32", None) is not None
+                and hip_ops.MSDA_FP32_REF and not torch.is_grad_enabled() and kw.get("spatial_shapes") is not None):
+            blobs = self._fused_weights(reg_branches)
+            if blobs is not None and valid_ratios.shape[1] == blobs["L"]:
+                if v_all is None:   # (small memories: each layer's own value projection, mask folded in)
+                    v_all = [hip_ops.linear(value, l.attentions[1].value_proj.weight, l.attentions[1].value_proj.bias,
+                                            row_mask=key_padding_mask) for l in self.layers]
+                return self._forward_fused(blobs, query, v_all, reference_points, valid_ratios, kw["spatial_shapes"],
+                                           kw["level_start_index"])
         for lid, layer in enumerate(self.layers):
             if hip_ops.query_sine_embed_supported(reference_points, valid_ratios, self.embed_dims // 2):
                 ref_in, sine = hip_ops.query_sine_embed(reference_points, valid_ratios, self.embed_dims // 2)

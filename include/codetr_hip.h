@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 39
+#define CODETR_HIP_ABI_VERSION 40
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -643,6 +643,43 @@ int codetr_mha_attention_f16(void *stream, const void *q_dev, const void *k_dev,
 int codetr_mha_attention_bf16(void *stream, const void *q_dev, const void *k_dev, const void *v_dev, void *out_dev,
                               int64_t B, int64_t Nq, int64_t Nk, int num_heads, int head_dim, int64_t q_row_stride,
                               int64_t k_row_stride, int64_t v_row_stride, int64_t out_row_stride);
+
+/* ------------------------------------------------------------------------------------------
+ * One DINO decoder layer's row-local work in one launch (csrc/decoder_layer.hip), f16, embed_dims 256, 8 heads of 32,
+ * 4-d reference boxes, post-norm layer (self_attn, norm, cross_attn, norm, ffn, norm) with box refinement.
+ * Replaces, per layer, the ~19 launches of reference codetr/transformer.py:193-230 (DinoTransformerDecoder.forward:
+ * reference-point scaling, gen_sineembed_for_position :157-190, ref_point_head, the layer, reg_branches[lid]) and
+ * :233-277 / transformer_mmcv.py:583-749 (the layer's operation_order) -- everything except softmax(QK^T)V of the
+ * self-attention, which stays codetr_mha_attention_f16 between two of these launches:
+ *   TAIL (attn_dev != NULL): x1 = LN1(x + attn.Wo^T + bo); (offsets | logits) = (x1 + qpos).Wol^T + bol;
+ *        s = MSDA(value, softmax(logits), ref_xy + off / P * ref_wh / 2) with ref = sigmoid(ref_dev) * valid ratios (fp32);
+ *        x2 = LN2(x1 + s.Wout^T + bout); x3 = LN3(x2 + relu(x2.W1^T + b1).W2^T + b2); ref_out = ref + reg_branch(x3)
+ *   HEAD (head_w_dev != NULL): qpos_out = ref_point_head(sine_embed(sigmoid(ref') * valid_ratios[level 0]));
+ *        qk_out = (x3 + qpos_out).Wqk^T + bqk; v_out = x3.Wv^T + bv       (ref' = ref_out, or ref_dev without a TAIL;
+ *        x3 = x_dev without a TAIL)
+ *   x_out = x3 with a HEAD, else final_norm(x3) (the decoder's output LayerNorm, final_norm_dev = gamma | beta).
+ * Tensors: x, attn, qpos, x_out, qpos_out, v_out [B*Nq, 256]; qk_out [B*Nq, 512]; ref, ref_out [B*Nq, 4] unactivated;
+ * valid_ratios32 [B, L, 2] fp32; value [B, S, 8, 32] (the layer's projected, masked value map); spatial_shapes [L, 2],
+ * level_start [L] int64 on the device.  Packed f16 weights, row-major [out][in] matrices, in this order:
+ *   tail_w: Wo, bo, LN1 gamma, beta, Wol (offsets rows then logits rows: 8*L*P*2 + 8*L*P), bol, Wout, bout, LN2 gamma,
+ *           beta, W1 [hidden][256], b1, W2 [256][hidden], b2, LN3 gamma, beta, Wr1, br1, Wr2, br2, Wr3 [4][256],
+ *           br3 (4 values + 4 of padding)
+ *   head_w: Wqk [512][256], bqk, Wv, bv          pos_w: Wp1 [256][512], bp1, Wp2, bp2        final_norm: gamma, beta
+ * codetr_decoder_layer_blob_halfs(which = 0 tail | 1 head | 2 pos | 3 final norm, ...) returns the element counts.
+ * Rounding points are those of the separate kernels (f16 wherever they materialise a tensor; fp32 statistics, softmax,
+ * sampling arithmetic and accumulation); the results differ from them only by summation order.
+ * CODETR_E_UNSUPPORTED outside L*P <= 32, hidden % 256 == 0, (8*L*P*3) % 16 == 0 and <= 512.
+ * ------------------------------------------------------------------------------------------ */
+int codetr_decoder_layer_supported(int embed_dims, int num_heads, int num_levels, int num_points, int hidden, int ref_dim,
+                                   int pos_feat);
+int64_t codetr_decoder_layer_blob_halfs(int which, int num_levels, int num_points, int hidden);
+int codetr_decoder_layer_f16(void *stream, const void *x_dev, const void *attn_dev, const void *qpos_dev,
+                             const void *ref_dev, const float *valid_ratios32_dev, const void *value_dev,
+                             const int64_t *spatial_shapes_dev, const int64_t *level_start_dev, const void *tail_w_dev,
+                             const void *pos_w_dev, const void *head_w_dev, const void *final_norm_dev, void *x_out_dev,
+                             void *ref_out_dev, void *qpos_out_dev, void *qk_out_dev, void *v_out_dev, int64_t B,
+                             int64_t Nq, int64_t S, int num_levels, int num_points, int hidden, float ln_eps,
+                             float temperature);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm on token-major activations, written into a slice of the flattened multi-level map.
