@@ -176,6 +176,17 @@ class DinoTransformerDecoder(nn.Module):
 
         def build():
             cat = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).contiguous()  # noqa: E731
+
+            def frag(w, rows=None):
+                """[N][K] row-major -> fragment-major (include/codetr_hip.h): block (tile, ks) = 64 lanes x 8 halfs,
+                lane 16 g + r holds w[16 tile + r][32 ks + 8 g ..]; rows padded with zeros to `rows`"""
+                w = w.detach()
+                N, K = w.shape
+                if rows is not None and rows > N:
+                    w = torch.cat((w, w.new_zeros(rows - N, K)), 0)
+                    N = rows
+                return w.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
             tails, heads = [], []
             for lid, layer in enumerate(self.layers):
                 sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
@@ -183,14 +194,17 @@ class DinoTransformerDecoder(nn.Module):
                 fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
                 rb = list(reg_branches[lid])
                 pad = rb[4].bias.new_zeros(4)
-                tails.append(cat([sa.attn.out_proj.weight, sa.attn.out_proj.bias, n1.weight, n1.bias,
-                                  ca.sampling_offsets.weight, ca.attention_weights.weight, ca.sampling_offsets.bias,
-                                  ca.attention_weights.bias, ca.output_proj.weight, ca.output_proj.bias, n2.weight, n2.bias,
-                                  fc1.weight, fc1.bias, fc2.weight, fc2.bias, n3.weight, n3.bias,
-                                  rb[0].weight, rb[0].bias, rb[2].weight, rb[2].bias, rb[4].weight, rb[4].bias, pad]))
+                wol = torch.cat((ca.sampling_offsets.weight, ca.attention_weights.weight), 0)
+                # matrices first (fragment-major), then the small vectors (the kernel copies those to LDS once)
+                tails.append(cat([frag(sa.attn.out_proj.weight), frag(wol, 512), frag(ca.output_proj.weight),
+                                  frag(fc1.weight), frag(fc2.weight), frag(rb[0].weight), frag(rb[2].weight),
+                                  frag(rb[4].weight, 16),
+                                  sa.attn.out_proj.bias, n1.weight, n1.bias, ca.sampling_offsets.bias,
+                                  ca.attention_weights.bias, ca.output_proj.bias, n2.weight, n2.bias, fc1.bias, fc2.bias,
+                                  n3.weight, n3.bias, rb[0].bias, rb[2].bias, rb[4].bias, pad]))
                 Wi, bi = sa.attn.in_proj_weight, sa.attn.in_proj_bias               # rows [q | k | v]
-                heads.append(cat([Wi[: 2 * C], bi[: 2 * C], Wi[2 * C:], bi[2 * C:]]))
-            pos = cat([rp[0].weight, rp[0].bias, rp[2].weight, rp[2].bias])
+                heads.append(cat([frag(Wi[: 2 * C]), frag(Wi[2 * C:]), bi]))
+            pos = cat([frag(rp[0].weight), frag(rp[2].weight), rp[0].bias, rp[2].bias])
             fin = cat([self.norm.weight, self.norm.bias])
             sizes = [_cabi.decoder_layer_blob_halfs(w, L, P, F) for w in range(4)]
             if (any(t.numel() != sizes[0] for t in tails) or any(h.numel() != sizes[1] for h in heads)

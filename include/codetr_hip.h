@@ -660,15 +660,18 @@ int codetr_mha_attention_bf16(void *stream, const void *q_dev, const void *k_dev
  *   x_out = x3 with a HEAD, else final_norm(x3) (the decoder's output LayerNorm, final_norm_dev = gamma | beta).
  * Tensors: x, attn, qpos, x_out, qpos_out, v_out [B*Nq, 256]; qk_out [B*Nq, 512]; ref, ref_out [B*Nq, 4] unactivated;
  * valid_ratios32 [B, L, 2] fp32; value [B, S, 8, 32] (the layer's projected, masked value map); spatial_shapes [L, 2],
- * level_start [L] int64 on the device.  Packed f16 weights, row-major [out][in] matrices, in this order:
- *   tail_w: Wo, bo, LN1 gamma, beta, Wol (offsets rows then logits rows: 8*L*P*2 + 8*L*P), bol, Wout, bout, LN2 gamma,
- *           beta, W1 [hidden][256], b1, W2 [256][hidden], b2, LN3 gamma, beta, Wr1, br1, Wr2, br2, Wr3 [4][256],
- *           br3 (4 values + 4 of padding)
- *   head_w: Wqk [512][256], bqk, Wv, bv          pos_w: Wp1 [256][512], bp1, Wp2, bp2        final_norm: gamma, beta
+ * level_start [L] int64 on the device.  Packed f16 weights: matrices first, FRAGMENT-MAJOR -- a [N][K] nn.Linear weight
+ * is stored as N/16 x K/32 blocks of 64 x 8 halfs, block (tile, ks) at ((tile * K/32 + ks) * 64 + lane) * 8 with
+ * lane = 16 g + r holding W[16 tile + r][32 ks + 8 g .. + 7] (one wave load = 1 KB of whole lines, the MFMA operand
+ * layout) -- then the small vectors, which the kernel copies to LDS once; in this order:
+ *   tail_w: Wo, Wol (offsets rows then logits rows: 8*L*P*2 + 8*L*P, zero rows up to 512), Wout, W1 [2048][256],
+ *           W2 [256][2048], Wr1, Wr2, Wr3 (4 rows + 12 zero rows) | bo, LN1 gamma, beta, bol, bout, LN2 gamma, beta, b1,
+ *           b2, LN3 gamma, beta, br1, br2, br3 (4 values + 4 of padding)
+ *   head_w: Wqk [512][256], Wv [256][256] | bqk, bv       pos_w: Wp1 [256][512], Wp2 | bp1, bp2      final_norm: gamma, beta
  * codetr_decoder_layer_blob_halfs(which = 0 tail | 1 head | 2 pos | 3 final norm, ...) returns the element counts.
  * Rounding points are those of the separate kernels (f16 wherever they materialise a tensor; fp32 statistics, softmax,
  * sampling arithmetic and accumulation); the results differ from them only by summation order.
- * CODETR_E_UNSUPPORTED outside L*P <= 32, hidden % 256 == 0, (8*L*P*3) % 16 == 0 and <= 512.
+ * CODETR_E_UNSUPPORTED outside L*P <= 32, hidden == 2048, (8*L*P*3) % 16 == 0 and <= 512.
  * ------------------------------------------------------------------------------------------ */
 int codetr_decoder_layer_supported(int embed_dims, int num_heads, int num_levels, int num_points, int hidden, int ref_dim,
                                    int pos_feat);

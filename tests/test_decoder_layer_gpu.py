@@ -159,7 +159,7 @@ def test_contract():
     assert _cabi.decoder_layer_supported(256, 8, 5, 4, 2048, 4, 128)
     assert not _cabi.decoder_layer_supported(256, 8, 5, 4, 2048, 2, 128)      # 2-d reference points
     assert not _cabi.decoder_layer_supported(384, 12, 5, 4, 2048, 4, 192)
-    assert not _cabi.decoder_layer_supported(256, 8, 5, 4, 1000, 4, 128)
+    assert not _cabi.decoder_layer_supported(256, 8, 5, 4, 1024, 4, 128)
     assert _cabi.decoder_layer_blob_halfs(1, 5, 4, 2048) == 3 * 256 * 256 + 3 * 256
     assert _cabi.decoder_layer_blob_halfs(3, 5, 4, 2048) == 512
     x = torch.zeros(16, 256, device=DEV, dtype=torch.float16)

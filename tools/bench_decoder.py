@@ -66,6 +66,13 @@ def main():
             gr.replay()
         e1.record()
         torch.cuda.synchronize()
+    lib = _cabi.load()
+    if hasattr(lib, "codetr_decoder_layer_debug_stamps"):   # -DCODETR_DEC_STAMPS build: phase boundaries of the last launch
+        import ctypes
+        buf = (ctypes.c_ulonglong * 32)()
+        lib.codetr_decoder_layer_debug_stamps(buf)
+        t = list(buf)[:14]
+        print("stamps (clock ticks since the kernel's first stamp):", [int(v - t[0]) for v in t])
     print(f"decoder batch {a.batch} {a.res}: {e0.elapsed_time(e1) / a.iters * 1e3:.1f} us per replay, {launches} C-ABI launches")
 
 
