@@ -43,7 +43,7 @@
 __device__ unsigned long long g_dec_stamps[32];
 #define DEC_STAMP(i)                                                          \
   do {                                                                        \
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_stamps[i] = __builtin_readcyclecounter(); \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_stamps[(TAIL && HEAD ? 0 : 16) + (i)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
 #define DEC_STAMP(i) \
@@ -193,7 +193,8 @@ __device__ __forceinline__ void issue(Stream& c) {
       // (rotating the k-steps of the other products per workgroup as well was measured: slower, 858 -> 933 us per decoder)
       constexpr int ks = (ph.mat == M_WP1 ? ph.sub * 8 : 0) + loc.ks;
       constexpr int tile_c = loc.t * kWaves;               // + wave
-      const f16* p = c.mat[ph.mat] + ((size_t)((tile_c + c.wave) * KST + ks) * 64) * 8 + c.lane8;
+      const int tile = ph.mat == M_WR3 ? 0 : tile_c + c.wave;   // (Wr3 is ONE tile: every wave walks it, wave 0's result counts)
+      const f16* p = c.mat[ph.mat] + ((size_t)(tile * KST + ks) * 64) * 8 + c.lane8;
       c.fifo[I % kDepth] = *reinterpret_cast<const f16x8*>(p);
     }
   }

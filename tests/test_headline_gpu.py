@@ -95,7 +95,8 @@ def test_headline_batch4_vs_oracle_rows_and_alone(case):
         calls = {k: _cabi.CALLS[k] - before[k] for k in before}
     assert cap4["route"] == "tokens"
     assert calls["linear_xadd"] == 6 and calls["msda_encoder"] == 6 and calls["ffn_fused"] == 6, calls
-    assert calls["msda_fused"] == 6 and calls["mha_attention"] == 6 and calls["window_attention"] == 24, calls
+    # (decoder: the head-only launch + one per layer, the self-attention cores between them)
+    assert calls["decoder_layer"] == 7 and calls["mha_attention"] == 6 and calls["window_attention"] == 24, calls
     assert calls["linear_xs"] > 0 and calls["linear_tile256"] > 0 and calls["linear_splitk"] > 0, calls
     assert calls["linear_tile128"] > 0 and calls["linear_ln"] == 4 and calls["topk"] == 1, calls
     for a, b in zip(out4, out4b):   # the capture hook changes nothing

@@ -71,8 +71,9 @@ def main():
         import ctypes
         buf = (ctypes.c_ulonglong * 32)()
         lib.codetr_decoder_layer_debug_stamps(buf)
-        t = list(buf)[:14]
-        print("stamps (clock ticks since the kernel's first stamp):", [int(v - t[0]) for v in t])
+        t = list(buf)
+        print("stamps of a tail + head launch (clock ticks since the kernel's first stamp):", [int(v - t[0]) for v in t[:14]])
+        print("stamps of the last (tail-only) launch:", [int(v - t[16]) for v in t[16:26]])
     print(f"decoder batch {a.batch} {a.res}: {e0.elapsed_time(e1) / a.iters * 1e3:.1f} us per replay, {launches} C-ABI launches")
 
 
