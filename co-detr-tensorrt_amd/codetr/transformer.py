@@ -89,6 +89,20 @@ def run_mlp(seq, x, residual=None):
     return x
 
 
+def pack_fragment_major(w, rows=None):
+    """[N][K] row-major nn.Linear weight -> the fragment-major order codetr_decoder_layer_f16 streams (include/codetr_hip.h):
+    N/16 x K/32 blocks of 64 x 8 elements, block (tile, ks) at ((tile * K/32 + ks) * 64 + lane) * 8 with lane = 16 g + r
+    holding w[16 tile + r][32 ks + 8 g .. + 7]; rows padded with zeros up to `rows`.  Returns a flat tensor."""
+    w = w.detach()
+    N, K = w.shape
+    if rows is not None and rows > N:
+        w = torch.cat((w, w.new_zeros(rows - N, K)), 0)
+        N = rows
+    if N % 16 or K % 32:
+        raise ValueError("pack_fragment_major needs N % 16 == 0 and K % 32 == 0")
+    return w.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
+
 class DinoTransformerDecoder(nn.Module):
     def __init__(self, return_intermediate=False, transformerlayers=None, num_layers=None, init_cfg=None):
         super().__init__()
@@ -177,15 +191,7 @@ class DinoTransformerDecoder(nn.Module):
         def build():
             cat = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).contiguous()  # noqa: E731
 
-            def frag(w, rows=None):
-                """[N][K] row-major -> fragment-major (include/codetr_hip.h): block (tile, ks) = 64 lanes x 8 halfs,
-                lane 16 g + r holds w[16 tile + r][32 ks + 8 g ..]; rows padded with zeros to `rows`"""
-                w = w.detach()
-                N, K = w.shape
-                if rows is not None and rows > N:
-                    w = torch.cat((w, w.new_zeros(rows - N, K)), 0)
-                    N = rows
-                return w.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+            frag = pack_fragment_major
 
             tails, heads = [], []
             for lid, layer in enumerate(self.layers):

@@ -10,13 +10,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _decoder(layers, seed=0):
+def _decoder(layers, seed=0, levels=5):
     from codetr.transformer import DinoTransformerDecoder, build_MLP
 
     torch.manual_seed(seed)
     cfg = dict(type="DetrTransformerDecoderLayer",
                attn_cfgs=[dict(type="MultiheadAttention", embed_dims=256, num_heads=8, dropout=0.0),
-                          dict(type="MultiScaleDeformableAttention", embed_dims=256, num_levels=5, dropout=0.0)],
+                          dict(type="MultiScaleDeformableAttention", embed_dims=256, num_levels=levels, dropout=0.0)],
                feedforward_channels=2048, ffn_dropout=0.0,
                operation_order=("self_attn", "norm", "cross_attn", "norm", "ffn", "norm"))
     dec = DinoTransformerDecoder(return_intermediate=True, transformerlayers=cfg, num_layers=layers)
@@ -71,12 +71,12 @@ def _run(dec, reg, inp, fused):
 PYR = [(40, 60), (20, 30), (10, 15), (5, 8), (3, 4)]
 
 
-@pytest.mark.parametrize("B,Nq,layers", [(1, 900, 6), (2, 37, 2), (3, 16, 1), (1, 5, 1)])
-def test_one_launch_per_layer_matches_the_separate_launches(B, Nq, layers):
+@pytest.mark.parametrize("B,Nq,layers,levels", [(1, 900, 6, 5), (2, 37, 2, 5), (3, 16, 1, 5), (1, 5, 1, 5), (2, 300, 2, 4)])
+def test_one_launch_per_layer_matches_the_separate_launches(B, Nq, layers, levels):
     from codetr import _cabi
 
-    dec, reg = _decoder(layers)
-    inp = _inputs(B, Nq, PYR)
+    dec, reg = _decoder(layers, levels=levels)
+    inp = _inputs(B, Nq, PYR[:levels])
     before = dict(_cabi.CALLS)
     out_f, ref_f = _run(dec, reg, inp, True)
     assert _cabi.CALLS["decoder_layer"] == before["decoder_layer"] + layers + 1

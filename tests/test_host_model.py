@@ -264,3 +264,21 @@ def test_checkpoint_loader_refuses_pickled_objects_unless_opted_in(tmp_path):
     with pytest.raises(RuntimeError, match="allow_pickle"):
         load_checkpoint(str(bad))
     assert load_checkpoint(str(bad), allow_pickle=True)["meta"] == fractions.Fraction(1, 2)
+
+
+def test_fragment_major_packing_layout():
+    """codetr.transformer.pack_fragment_major: element (tile, ks, lane = 16 g + r, e) of the packed blob is
+    w[16 tile + r][32 ks + 8 g + e] (the layout include/codetr_hip.h documents for codetr_decoder_layer_f16)"""
+    import torch
+    from codetr.transformer import pack_fragment_major
+
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(20, 96, generator=g)
+    p = pack_fragment_major(w, rows=32)
+    assert p.shape == (32 * 96,)
+    K = 96
+    for tile, ks, gq, r, e in [(0, 0, 0, 0, 0), (0, 2, 3, 15, 7), (1, 1, 2, 3, 5), (1, 0, 0, 4, 0), (1, 2, 1, 9, 3)]:
+        lane = 16 * gq + r
+        got = float(p[((tile * (K // 32) + ks) * 64 + lane) * 8 + e])
+        row, col = 16 * tile + r, 32 * ks + 8 * gq + e
+        assert got == (float(w[row, col]) if row < 20 else 0.0)
