@@ -274,13 +274,16 @@ def kernel_rooflines(model, images, masks, device):
     hbm_bound_launches = sum(1 for p in prof if 2.0 * (p[3] * p[5] + p[4] * p[5] + p[3] * p[4]) / (HBM_PEAK_GBS * 1e9)
                              > p[2] / (MFMA_PEAK_TFLOPS * 1e12))
     alg_bytes = sum(2.0 * (p[3] * p[5] + p[4] * p[5] + p[3] * p[4]) for p in prof)   # X + W + Y once per launch, 2 B each
-    traffic = pmc.get("linear_kernel", {}).get("hbm_bytes_per_launch")
+    # per-launch figure from the PMC pass's PER-FORWARD bytes over THIS run's launch count: the committed pass may have
+    # been taken with a different launch list (round 4 moved the decoder's 72 small Linears into decoder_layer_kernel)
+    pl = pmc.get("linear_kernel", {})
+    traffic = pl["hbm_bytes_per_forward"] / len(prof) if "hbm_bytes_per_forward" in pl else pl.get("hbm_bytes_per_launch")
     out["roofline"] = {
         "kernel": "linear_kernel / linear_256_kernel / linear_xs_kernel <f16> (all %d launches of one forward)" % len(prof),
         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic,
-        "traffic_note": "HBM-side bytes per launch, average over the launches of a forward (committed PMC pass %s)" % pmc.get("_file"),
+        "traffic_note": "HBM-side bytes of the group per forward / this run's launches (committed PMC pass %s)" % pmc.get("_file"),
         "algorithmic_bytes_per_forward": alg_bytes, "algorithmic_bytes_per_launch": round(alg_bytes / len(prof)),
         "traffic_over_algorithmic": round(traffic * len(prof) / alg_bytes, 3) if traffic else None,
         "composite": {"frac": round(bound_s / secs, 4), "bound_ms": round(bound_s * 1e3, 3),
