@@ -224,7 +224,7 @@ class DinoTransformerDecoder(nn.Module):
         """6 x (self-attention core, one codetr_decoder_layer_f16 launch) + the head-only launch in front."""
         from . import _cabi
         B, Nq, C = query.shape
-        S = v_all[0].shape[1]
+        S = v_all[0].shape[1] if not callable(v_all) else v_all(-1)
         L, P, F = blobs["L"], blobs["P"], blobs["F"]
         vr32 = valid_ratios._codetr_f32.contiguous()
         dev = query.device
@@ -241,7 +241,8 @@ class DinoTransformerDecoder(nn.Module):
                 last = lid + 1 == nl
                 x_out, ref_out = new(B, Nq, C), new(B, Nq, 4)
                 qpos2, qk2, v2 = (None, None, None) if last else (new(B, Nq, C), new(B, Nq, 2 * C), new(B, Nq, C))
-                _cabi.decoder_layer(x, attn, qpos, ref, vr32, v_all[lid].contiguous(), spatial_shapes, level_start_index,
+                v_l = v_all(lid) if callable(v_all) else v_all[lid]
+                _cabi.decoder_layer(x, attn, qpos, ref, vr32, v_l.contiguous(), spatial_shapes, level_start_index,
                                     blobs["tails"][lid], None if last else blobs["pos"],
                                     None if last else blobs["heads"][lid + 1], blobs["fin"] if last else None,
                                     x_out, ref_out, qpos2, qk2, v2, B, Nq, S, L, P, F, eps, 10000.0)
@@ -258,9 +259,12 @@ class DinoTransformerDecoder(nn.Module):
                 and hip_ops.MSDA_FP32_REF and not torch.is_grad_enabled() and kw.get("spatial_shapes") is not None):
             blobs = self._fused_weights(reg_branches)
             if blobs is not None and valid_ratios.shape[1] == blobs["L"]:
-                if v_all is None:   # (small memories: each layer's own value projection, mask folded in)
-                    v_all = [hip_ops.linear(value, l.attentions[1].value_proj.weight, l.attentions[1].value_proj.bias,
-                                            row_mask=key_padding_mask) for l in self.layers]
+                if v_all is None:   # (small memories: each layer's own value projection, mask folded in, right before its use)
+                    def v_all(lid):
+                        if lid < 0:
+                            return value.shape[1]
+                        vp = self.layers[lid].attentions[1].value_proj
+                        return hip_ops.linear(value, vp.weight, vp.bias, row_mask=key_padding_mask)
                 return self._forward_fused(blobs, query, v_all, reference_points, valid_ratios, kw["spatial_shapes"],
                                            kw["level_start_index"])
         for lid, layer in enumerate(self.layers):
