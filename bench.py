@@ -675,6 +675,9 @@ def main():
                               per_rank_images_per_s_min=round(a.steps * a.batch / float(t.item()), 3),
                               per_rank_images_per_s_max=round(a.steps * a.batch / float(tmin.item()), 3))
             elapsed = float(t.item())
+        else:
+            rank_stats.update(ranks_seen=1, per_rank_images_per_s_min=round(a.steps * a.batch / elapsed, 3),
+                              per_rank_images_per_s_max=round(a.steps * a.batch / elapsed, 3))
         return elapsed, per_step
 
     elapsed, per_step_ms = timed(a.feed == "host")
