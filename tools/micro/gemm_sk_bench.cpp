@@ -114,6 +114,7 @@ int main(int argc, char** argv) {
       {"enc.out", 40920 * s, 256, 256, 0, true},
       // the X-stationary kernel's shapes (encoder at 204600 tokens per image, Swin stage 0 at 153600)
       {"xs.offlog", 204600 * s, 480, 256, 0, false},
+      {"dec.vproj", 204600 * s, 1536, 256, 0, false},   // value projections of the six decoder layers as one GEMM
       {"xs.s0qkv", 153600 * s, 576, 192, 0, false},
       {"xs.s0proj", 153600 * s, 192, 192, 0, true},
       {"xs.s0fc1", 153600 * s, 768, 192, 2, false},
