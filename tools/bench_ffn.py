@@ -23,6 +23,9 @@ for M in (818400, 204600, 30785):   # 4 images, 1 image, one 608x608 image
     gam, bet, pos = torch.ones(256, device="cuda").half(), torch.zeros(256, device="cuda").half(), torch.randn_like(x)
     tl = timeit(lambda: hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), pos=pos))
 
+    tli = timeit(lambda: hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), ln_in=(gam, bet, 1e-5)))
+    print(f"M={M}: LN -> FFN -> LN one kernel (the encoder layer's form) {tli * 1e6:.1f} us")
+
     def three():
         y = hip_ops.layer_norm(hip_ops.ffn_fused(x, w1, b1, w2, b2), gam, bet, 1e-5)
         return y, y + pos
