@@ -796,8 +796,7 @@ def main():
             "reference_note": "reference publishes 79.5 ms/image (TensorRT fp16, RTX 4090, batch 1, README.md:33); "
                               "not the same hardware, so vs_baseline stays null",
         }
-        if world > 1:
-            out.update(headline_rank_stats)
+        out.update(headline_rank_stats)
         if host_feed is not None:
             out["host_feed"] = host_feed
         if fp8_line is not None:
