@@ -805,7 +805,8 @@ size_t lds_bytes(int LP) {
 
 bool dims_ok(int num_heads, int head_dim, int L, int P, int hidden, int ref_dim, int pos_feat) {
   return num_heads == kM && head_dim == kD && L >= 1 && L <= kMaxL && P >= 1 && L * P <= kMaxLP && ref_dim == 4 &&
-         pos_feat == kC / 2 && hidden == kF && (kM * L * P * 3) % 16 == 0 && kM * L * P * 3 <= 512;
+         pos_feat == kC / 2 && hidden == kF && (kM * L * P * 3) % 16 == 0 && kM * L * P * 3 <= 512 &&
+         lds_bytes(L * P) <= 160 * 1024;   // (entries of every sample point of 128 (row, head) pairs live in LDS)
 }
 
 }  // namespace
