@@ -8,7 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "co-detr-tensorrt_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from bench_linear import timeit  # noqa: E402
-from codetr import hip_ops  # noqa: E402
+from codetr import _cabi, hip_ops  # noqa: E402
+
+if os.environ.get("CODETR_LIB"):   # timing experiments: a diagnostic build of the library (tools/micro/build_variant.sh)
+    _cabi.LIB_PATH, _cabi._lib, _cabi._rec_lib = os.environ["CODETR_LIB"], None, None
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for name, (H, W), heads in (("stage0", (320, 480), 6), ("stage1", (160, 240), 12), ("stage2", (80, 120), 24),
