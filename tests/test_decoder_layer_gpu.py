@@ -90,7 +90,7 @@ def test_one_launch_per_layer_matches_the_separate_launches(B, Nq, layers, level
     # same rounding points, different summation order: a few fp16 ulps per layer on LayerNorm-ed (unit-scale) rows
     d = (out_f.float() - out_u.float())
     rel = float(d.norm() / out_u.float().norm())
-    assert rel < 4e-3 * max(1, layers // 2), rel
+    assert rel < 1e-3 * (1 + layers), rel     # measured: 2.3e-3 after 6 layers, 1e-3 after 2
     assert float(d.abs().max()) < 0.06 * max(1, layers // 2)
     assert float((ref_f.float() - ref_u.float()).abs().max()) < 0.02 * layers
 
