@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "codetr_hip.h"
 
 // diagnostic builds only (tools/micro/ffn_ablate.hip -DCODETR_FFN_ABL=mask; WRONG results by construction, never shipped):
@@ -103,7 +105,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // streaming across tiles (every tile reads the same W), the next tile's rows are requested at the start of the
 // epilogue, and the epilogue works out of the accumulators (no LDS staging, no barrier) while the next tile's first W
 // chunks arrive.
-template <class ET>
+// MTT = 16-row tiles per wave: 2 (128 rows per workgroup, the product shape) or 1 (64 rows per workgroup: a tile takes
+// half the MFMA time for the same weight stream -- used for a left-over partial round, see ffn_entry).
+template <class ET, int MTT = 2>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   using E = typename ET::e;
   using V8 = typename ET::v8;
   using V4 = typename ET::v4;
-  constexpr int MT = 2, WR = 32;   // 16-row tiles / rows per wave; 128 rows per workgroup
+  constexpr int MT = MTT, WR = 16 * MT, TR = 4 * WR;   // 16-row tiles / rows per wave / rows per workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, grp = lane >> 4;
@@ -151,13 +155,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   // a tile's input rows as they come from memory (B-operand layout: lane (j = l15, g) holds X[m][32 ks + 8 g .. + 7])
   V8 xn[MT][8];
   auto load_x = [&](int tile, int mt) {
-    int m = tile * 128 + wave * WR + mt * 16 + l15;
+    int m = tile * TR + wave * WR + mt * 16 + l15;
     m = m < M ? m : M - 1;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) xn[mt][ks] = *reinterpret_cast<const V8*>(X + (size_t)m * C + ks * 32 + grp * 8);
   };
-  load_x(blockIdx.x, 0);
-  load_x(blockIdx.x, 1);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) load_x(blockIdx.x, mt);
   // b1 and the output LayerNorm's parameters go to LDS once per workgroup (read by ds_read in the loop / epilogue: no
   // vector-memory op in the main loop but the LDS-DMA pieces)
   for (int i = tid; i < Hd / 8; i += kThreads)
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 
   int gc = 0;  // chunks consumed so far: ring stage = gc & 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int m0 = tile * 128 + wave * WR;
+    const int m0 = tile * TR + wave * WR;
     // ---- the MFMA operand of the first product and the identity: the rows, or their LayerNorm (the post-norm layer's
     // first norm, whose output nothing else reads).  The 256 values of row (mt, l15) sit in the four lanes l15 + 16 g
     // (8 k-steps x 8 values each): statistics are two xor-shuffles away; fp32 two-pass like layernorm_kernel, result
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = m0 + mt * 16 + l15;
-      if (mt == 0) load_x(next_tile, 0);
+      if (MT == 2 && mt == 0) load_x(next_tile, 0);
       unsigned yp[16][2];
 #pragma unroll
       for (int nt = 0; nt < 16; ++nt) {
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int j = 0; j < 8; ++j) pr[j] = *reinterpret_cast<const V8*>(prow + 32 * j);
       }
-      if (mt == 0) load_x(next_tile, 1);   // xf[0] / yacc[.][0] are dead from here on
+      if (mt == 0) load_x(next_tile, MT - 1);   // xf[0] / yacc[.][0] are dead from here on (MT == 1: the tile's only rows)
       if (ln_g) {
         sm += __shfl_xor(sm, 16, 64);
         sm += __shfl_xor(sm, 32, 64);
@@ -484,21 +488,33 @@ int ffn_entry(void* stream, const void* x_dev, const void* w1_dev, const void* b
        reinterpret_cast<uintptr_t>(pos_dev) | reinterpret_cast<uintptr_t>(y_plus_pos_dev)) & 15)
     return CODETR_E_BADARG;
   // 128 rows per tile (2 x 16 rows per wave; 3 x 16 does not fit the register file with the interleaved DMA issue).
-  // Persistent grid: one workgroup per CU.
-  const int ntiles = (int)((M + 127) / 128);
+  // Persistent grid: one workgroup per CU.  A left-over partial round that fills at most half of the CUs (1 599 tiles on
+  // 256 CUs at one 1920x1280 image: 63 tiles in a 7th round) is served by a second launch with 64-row tiles instead:
+  // twice the workgroups, half the MFMA time per tile -- half a round instead of a whole one.
   int cus = 0, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     cus = 256;
-  const unsigned blocks = (unsigned)(ntiles < cus ? ntiles : cus);
-  hipLaunchKernelGGL((ffn_fused_kernel<ET>), dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const unsigned short*>(x_dev), static_cast<const unsigned short*>(w1_dev),
-                     static_cast<const unsigned short*>(b1_dev), static_cast<const unsigned short*>(w2_dev),
-                     static_cast<const unsigned short*>(b2_dev), static_cast<unsigned short*>(y_dev), (int)M,
-                     (int)hidden, static_cast<const unsigned short*>(ln_gamma_dev),
-                     static_cast<const unsigned short*>(ln_beta_dev), ln_eps,
-                     static_cast<const unsigned short*>(pos_dev), static_cast<unsigned short*>(y_plus_pos_dev),
-                     static_cast<const unsigned short*>(ln_in_gamma_dev),
-                     static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps, ntiles);
+  const int64_t ntiles_all = (M + 127) / 128;
+  const int64_t left = ntiles_all % cus;
+  const bool split = left > 0 && 2 * left <= cus;
+  const int64_t M1 = split ? (ntiles_all - left) * 128 : M;   // rows of the 128-row launch
+  auto launch = [&](auto mt_tag, int64_t row0, int64_t rows) {
+    constexpr int MTT = decltype(mt_tag)::value;
+    const int ntiles = (int)((rows + 64 * MTT - 1) / (64 * MTT));
+    const unsigned blocks = (unsigned)(ntiles < cus ? ntiles : cus);
+    const size_t off = (size_t)row0 * C;
+    auto at = [&](const void* p) { return p ? static_cast<const unsigned short*>(p) + off : nullptr; };
+    hipLaunchKernelGGL((ffn_fused_kernel<ET, MTT>), dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       at(x_dev), static_cast<const unsigned short*>(w1_dev), static_cast<const unsigned short*>(b1_dev),
+                       static_cast<const unsigned short*>(w2_dev), static_cast<const unsigned short*>(b2_dev),
+                       const_cast<unsigned short*>(at(y_dev)), (int)rows, (int)hidden,
+                       static_cast<const unsigned short*>(ln_gamma_dev), static_cast<const unsigned short*>(ln_beta_dev),
+                       ln_eps, at(pos_dev), const_cast<unsigned short*>(at(y_plus_pos_dev)),
+                       static_cast<const unsigned short*>(ln_in_gamma_dev),
+                       static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps, ntiles);
+  };
+  if (M1 > 0) launch(std::integral_constant<int, 2>{}, 0, M1);
+  if (split) launch(std::integral_constant<int, 1>{}, M1, M - M1);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }

@@ -13,7 +13,7 @@ from codetr import _cabi, hip_ops  # noqa: E402
 if os.environ.get("CODETR_LIB"):   # timing experiments: a diagnostic build of the library (e.g. -DCODETR_FFN_NO8)
     _cabi.LIB_PATH, _cabi._lib, _cabi._rec_lib = os.environ["CODETR_LIB"], None, None   # (import codetr loaded the product build)
 
-for M in (818400, 204600, 30785):   # 4 images, 1 image, one 608x608 image
+for M in (818400, 204600, 73656, 30785):   # 4 images, 1 image, one 1152x768 image, one 608x608 image
     x = torch.randn(M, 256, device="cuda").half()
     w1 = (torch.randn(2048, 256, device="cuda") / 16).half()
     b1 = torch.randn(2048, device="cuda").half()
