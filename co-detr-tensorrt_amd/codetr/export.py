@@ -43,8 +43,6 @@ def is_own_kernel(name: str) -> bool:
     m = _OWN_MANGLED.match(name)
     return bool(m) and m.group(2)[:int(m.group(1))] in KERNEL_NAMES
 KIND_INT, KIND_FLOAT, KIND_DEV, KIND_NULL, KIND_HOST, KIND_STREAM = 0, 1, 2, 3, 4, 5
-# environment variables that do not change which kernels run (checkpoint loading policy, the bench's test mode)
-_ENV_ALLOWED = {"CODETR_ALLOW_PICKLE", "CODETR_BENCH_SHARE_GPU"}
 
 
 def _hip():
@@ -84,13 +82,13 @@ def export_plan(model, batch_inputs, img_masks, path, warmup=2):
     Returns a summary dict (launch count, bytes)."""
     if not batch_inputs.is_cuda or batch_inputs.dtype != torch.float16:
         raise ValueError("export_plan records the fp16 GPU path")
-    # a plan must describe the default kernels: the host package's A/B switches (CODETR_* environment variables read at
-    # import) select other launch lists, and a plan recorded under one would silently pin them for every later replay
-    import os
+    # a plan must describe the default kernels: the host package's route switches (module attributes, see
+    # hip_ops.nondefault_switches) select other launch lists, and a plan recorded under one would pin it for every replay
+    from . import hip_ops
 
-    ab = sorted(k for k in os.environ if k.startswith("CODETR_") and k not in _ENV_ALLOWED)
+    ab = hip_ops.nondefault_switches()
     if ab:
-        raise RuntimeError(f"export_plan refuses to record under A/B switches: unset {ab}")
+        raise RuntimeError(f"export_plan refuses to record under A/B switches: reset {ab}")
     dev = batch_inputs.device
     batch_inputs, img_masks = batch_inputs.contiguous(), img_masks.contiguous()
     hip = _hip()

@@ -10,7 +10,6 @@ that op lands, never as a fallback for a native kernel that exists.
 There is no CPU path: a CPU tensor reaching any of these functions is an error (the CPU
 formulation of the model lives in oracle/ and is test infrastructure).
 """
-import os
 
 import torch
 import torch.nn.functional as F
@@ -102,7 +101,7 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
                     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
                     launch = lambda: _cabi.linear_splitk(x2, w, bias, r2, act, out, splits, ws, mk)  # noqa: E731
                 elif (mk is None and not head_major and out.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
-                      and (r2 is None or r2.data_ptr() % 16 == 0) and (bias is None or bias.data_ptr() % 16 == 0)
+                      and w.data_ptr() % 16 == 0 and (r2 is None or r2.data_ptr() % 16 == 0) and (bias is None or bias.data_ptr() % 16 == 0)
                       and _cabi.linear_sk_preferred(x2.shape[0], N, K, act, r2 is not None)):
                     # the large short-K layers (Swin stages 0-2, the encoder's output projections): persistent GEMM
                     launch = lambda: _cabi.linear_sk(x2, w, bias, r2, act, out)  # noqa: E731
@@ -137,7 +136,7 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
     return y
 
 
-LN_GEMM = os.environ.get("CODETR_LN_GEMM", "1") != "0"   # A/B switch: 0 = LayerNorm as its own kernel in front of the GEMM
+LN_GEMM = True   # route switch (tools/ab_host_routes.py patches it): False = LayerNorm as its own kernel in front of the GEMM
 
 
 def linear_ln_supported(x, norm_weight, weight):
@@ -178,10 +177,10 @@ def linear_ln(x, norm_weight, norm_bias, eps, weight, bias=None, act=None):
     return linear(layer_norm(x, norm_weight, norm_bias, eps), weight, bias, act=act)
 
 
-XADD = os.environ.get("CODETR_XADD", "1") != "0"   # A/B switch: 0 = `query + query_pos` as its own kernel / FFN output
+XADD = True   # route switch: False = `query + query_pos` as its own kernel / FFN output
 # Below this many rows the 256-tile GEMM on a stored `query + query_pos` wins over the X-stationary kernel with the add
 # folded in (measured: one 1920x1280 image, 204 600 rows, +0.09 ms per forward; four images -0.35 ms)
-XADD_MIN_ROWS = int(os.environ.get("CODETR_XADD_MIN_ROWS", "400000"))
+XADD_MIN_ROWS = 400000
 
 
 def linear_xadd_supported(x, x_add, weight):
@@ -307,9 +306,12 @@ def layer_norm(x, weight, bias, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)  # fp32 parity runs
 
 
+MERGE_LN = True   # route switch: False = separate patch-merge gather + LayerNorm
+
+
 def patch_merge_layernorm_supported(x, C):
     return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and C % 8 == 0 and 4 * C <= 4096
-            and os.environ.get("CODETR_MERGE_LN", "1") != "0")
+            and MERGE_LN)
 
 
 def patch_merge_layernorm(x, hw, weight_kkc, bias_kkc, eps=1e-5):
@@ -622,12 +624,34 @@ def topk(x, k, want_values=True):
     return v, i
 
 
-MSDA_ENCODER = os.environ.get("CODETR_MSDA_ENC", "1") != "0"      # A/B switch: 0 = general fused kernel in the encoder
-MSDA_HALO = int(os.environ.get("CODETR_MSDA_HALO", "4"))          # staged offset range when no windows are given
-MSDA_WINDOWS = os.environ.get("CODETR_MSDA_WINDOWS", "1") != "0"  # A/B switch: 0 = symmetric halo instead of bias windows
-MSDA_PASSES = int(os.environ.get("CODETR_MSDA_PASSES", "3"))      # A/B switch: 1 = single-pass encoder kernels only
-MSDA_FP32_REF = os.environ.get("CODETR_MSDA_FP32_REF", "1") != "0"  # A/B switch: 0 = reference points read in the model dtype
+# Route switches of the encoder MSDA (plain module attributes; tools/ab_host_routes.py patches them for A/B runs -- the
+# package reads no CODETR_* environment variable except checkpoint.py's CODETR_ALLOW_PICKLE):
+MSDA_ENCODER = True     # False = general fused kernel in the encoder
+MSDA_HALO = 4           # staged offset range when no windows are given
+MSDA_WINDOWS = True     # False = symmetric halo instead of bias windows
+MSDA_PASSES = 3         # 1 = single-pass encoder kernels only
+MSDA_FP32_REF = True    # False = reference points read in the model dtype
 MSDA_LDS_BUDGET = {1: 80 * 1024, 3: 40 * 1024}   # bytes per workgroup: two / four workgroups per CU share 160 KiB
+
+
+_SWITCH_DEFAULTS = {"LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 400000, "MERGE_LN": True, "MSDA_ENCODER": True,
+                    "MSDA_HALO": 4, "MSDA_WINDOWS": True, "MSDA_PASSES": 3, "MSDA_FP32_REF": True, "FP8_MIN_TILES": 96}
+
+
+def nondefault_switches():
+    """Names of the host package's route switches that are not at their default (the measured-best path): the plan
+    exporter refuses to record under any of them, tools/ab_host_routes.py sets them."""
+    import sys
+
+    from . import multi_scale_deformable_attention as msda_mod
+    from . import transformer as tr_mod
+
+    me = sys.modules[__name__]
+    out = [k for k, v in _SWITCH_DEFAULTS.items() if getattr(me, k) != v]
+    if msda_mod.HEAD_MAJOR_VALUE:
+        out.append("HEAD_MAJOR_VALUE")
+    out += [k for k in ("DEC_FUSED", "DEC_VPROJ") if not getattr(tr_mod, k)]
+    return sorted(out)
 
 
 def msda_encoder_passes(dtype, num_levels, num_points):
@@ -717,7 +741,7 @@ def msda(value, spatial_shapes, level_start_index, sampling_locations, attention
 # ---------------------------------------------------------------------------------------------------------------
 FP8 = _cabi.FP8
 FP8_MAX = 448.0
-FP8_MIN_TILES = int(os.environ.get("CODETR_FP8_MIN_TILES", "96"))   # 256x256 output tiles below which fp16 serves the layer
+FP8_MIN_TILES = 96   # 256x256 output tiles below which fp16 serves the layer
 
 
 def fp8_weight(weight):

@@ -10,7 +10,6 @@ Differences by design:
   reference's sequence-first default and just permutes around it.
 """
 import math
-import os
 import warnings
 from typing import Optional
 
@@ -25,7 +24,7 @@ from . import hip_ops
 # 1920x1280 encoder shape (tools/bench_msda.py --fused): 616 us vs 665 us per launch with +-3 px synthetic offsets,
 # 1236 us vs 1447 us with uniformly random locations -- but no difference end to end on the model (22.6 vs 22.5
 # ms/image: freshly initialised offsets are a few pixels), so the op's own [B, S, M, D] layout stays the default.
-HEAD_MAJOR_VALUE = os.environ.get("CODETR_MSDA_HEAD_MAJOR", "0") != "0"
+HEAD_MAJOR_VALUE = False   # route switch (module attribute, patched by tools/ab_host_routes.py)
 
 
 class MultiScaleDeformableAttention(nn.Module):

@@ -8,14 +8,17 @@ reads device data back to the host, so a whole forward is hipGraph-capturable.
 """
 import math
 
-import os
-
 import torch
 import torch.nn as nn
 
 from . import hip_ops
 from .multi_scale_deformable_attention import MultiScaleDeformableAttention
 from .transformer_layers import BaseTransformerLayer, DetrTransformerDecoderLayer, build_norm
+
+
+# Route switches (plain module attributes; tools/ab_host_routes.py patches them, hip_ops.nondefault_switches lists them):
+DEC_FUSED = True   # False = the decoder as separate launches instead of codetr_decoder_layer_f16
+DEC_VPROJ = True   # False = every decoder layer projects its own value map
 
 
 class DetrTransformerEncoder(nn.Module):
@@ -145,9 +148,10 @@ class DinoTransformerDecoder(nn.Module):
         ReLU FFN, box refinement through a 3-layer reg branch, 2-layer ref_point_head).  Built once per parameter set
         (hip_ops.derived): tail blob per layer, head blob per layer, the shared ref_point_head blob, the output norm."""
         from . import _cabi
-        from .multi_scale_deformable_attention import HEAD_MAJOR_VALUE, MultiScaleDeformableAttention
+        from . import multi_scale_deformable_attention as _msda_mod
+        from .multi_scale_deformable_attention import MultiScaleDeformableAttention
         from .transformer_layers import MultiheadAttention
-        if os.environ.get("CODETR_DEC_FUSED", "1") == "0" or HEAD_MAJOR_VALUE or reg_branches is None:
+        if not DEC_FUSED or _msda_mod.HEAD_MAJOR_VALUE or reg_branches is None:
             return None
         C = self.embed_dims
         if len(reg_branches) < len(self.layers):
@@ -249,6 +253,18 @@ class DinoTransformerDecoder(nn.Module):
                 x, ref, qpos, qk, v = x_out, ref_out, qpos2, qk2, v2
         return x, ref
 
+    @staticmethod
+    def _fused_inputs_ok(query, kw):
+        """What _forward_fused assumes beyond dtype / shape of the query: at most 1024 queries (the
+        self-attention core keeps a head's keys in LDS), no self-attention mask of any kind (the fused path would ignore
+        it), and both index tensors present as int64 device tensors (they travel as raw pointers)."""
+        ss, ls = kw.get("spatial_shapes"), kw.get("level_start_index")
+        if ss is None or ls is None or query.shape[1] > 1024:
+            return False
+        if any(kw.get(k) is not None for k in ("query_key_padding_mask", "attn_masks", "attn_mask", "self_attn_mask")):
+            return False
+        return all(t.dtype == torch.int64 and t.is_cuda and t.is_contiguous() for t in (ss, ls))
+
     def forward_bf(self, query, value, key_padding_mask, reference_points, valid_ratios, reg_branches, **kw):
         """query [B,Nq,C], value [B,S,C], reference_points [B,Nq,4] unactivated."""
         out = query
@@ -256,7 +272,7 @@ class DinoTransformerDecoder(nn.Module):
         v_all = self._project_values(value, key_padding_mask)
         if (query.is_cuda and query.dtype == torch.float16 and reference_points.shape[-1] == 4
                 and reference_points.dtype == query.dtype and getattr(valid_ratios, "_codetr_f32", None) is not None
-                and hip_ops.MSDA_FP32_REF and not torch.is_grad_enabled() and kw.get("spatial_shapes") is not None):
+                and hip_ops.MSDA_FP32_REF and not torch.is_grad_enabled() and self._fused_inputs_ok(query, kw)):
             blobs = self._fused_weights(reg_branches)
             if blobs is not None and valid_ratios.shape[1] == blobs["L"]:
                 if v_all is None:   # (small memories: each layer's own value projection, mask folded in, right before its use)
@@ -305,7 +321,7 @@ class DinoTransformerDecoder(nn.Module):
         atts = self._cross_attentions()
         if (atts is None or not memory.is_cuda or memory.dtype not in (torch.float16, torch.bfloat16)
                 or torch.is_grad_enabled()
-                or os.environ.get("CODETR_DEC_VPROJ", "1") == "0"):
+                or not DEC_VPROJ):
             return None
         C = atts[0].value_proj.out_features
         if (any(a.value_proj.out_features != C or a.value_proj.in_features != memory.shape[-1] or a.value_proj.bias is None

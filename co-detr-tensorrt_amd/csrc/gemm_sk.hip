@@ -402,7 +402,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (lane == 0) __hip_atomic_store(a.counters + t * kWaves + wave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (finish && a.M > m0 && a.N > n0) {   // (a piece wholly outside the matrix has nothing to store)
+    // wave-uniform: did this wave issue the epilogue's 32 output stores?  (a piece wholly outside the matrix -- e.g. waves 6, 7
+    // of every tile at N = 192 -- and a non-finishing stream-K part store nothing)
+    const bool stored = finish && a.M > m0 && a.N > n0;
+    if (stored) {
       // ---- epilogue of this wave's 128 x 64 piece, straight from the accumulators ----
       // acc[i][j][r]: output row m0 + j*16 + 4 (lane >> 4) + r, column n0 + 4 (lane & 15) + i: the four n-tiles give the
       // lane 4 consecutive columns = 8 bytes, lanes 0-15 one 128-byte line, a store instruction 4 whole lines
@@ -464,7 +467,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    post = NS - 2;
+    // the relaxed wait (VMN + 32) is only sound behind 32 stores that were really issued: a wave without them has nothing
+    // but LDS-DMA pieces in its queue, and vmcnt(VMN + 32) would let it past pieces the next phases read
+    post = stored && !(kAbl & 16) ? NS - 2 : 0;
     cursor_next(cc, a, wg);
   }
 #undef SK_PHASE

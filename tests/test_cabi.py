@@ -161,3 +161,28 @@ def test_product_library_reads_no_environment_variable():
     for path in glob.glob(os.path.join(ROOT, "co-detr-tensorrt_amd", "csrc", "*.hip")) + \
             glob.glob(os.path.join(ROOT, "co-detr-tensorrt_amd", "csrc", "*.h")):
         assert "getenv" not in open(path).read(), path
+
+
+def test_host_package_reads_no_route_switch_from_the_environment():
+    """`build_CoDETR` in a stray environment must run the kernel set the headline test covers -- the
+    host package's route switches are plain module attributes (hip_ops.nondefault_switches lists the ones that are off
+    their default; tools/ab_host_routes.py patches them).  The one environment read left is the checkpoint loader's
+    explicit pickle opt-in."""
+    import glob
+    import re
+
+    hits = []
+    for path in glob.glob(os.path.join(ROOT, "co-detr-tensorrt_amd", "codetr", "*.py")):
+        for n, line in enumerate(open(path), 1):
+            if re.search(r"os\.environ|getenv\(", line):
+                hits.append((os.path.basename(path), n, line.strip()))
+    assert len(hits) == 1 and hits[0][0] == "checkpoint.py" and "CODETR_ALLOW_PICKLE" in hits[0][2], hits
+    from codetr import hip_ops, transformer
+
+    assert hip_ops.nondefault_switches() == []
+    transformer.DEC_FUSED = False
+    hip_ops.MSDA_PASSES = 1
+    try:
+        assert hip_ops.nondefault_switches() == ["DEC_FUSED", "MSDA_PASSES"]
+    finally:
+        transformer.DEC_FUSED, hip_ops.MSDA_PASSES = True, 3

@@ -56,16 +56,16 @@ def _inputs(B, Nq, shapes, seed=5, masked=True):
 
 
 def _run(dec, reg, inp, fused):
+    from codetr import transformer as tr
+
     query, memory, mask, ref, vr, ss, ls = inp
-    if fused:
-        os.environ.pop("CODETR_DEC_FUSED", None)
-    else:
-        os.environ["CODETR_DEC_FUSED"] = "0"
+    saved = tr.DEC_FUSED
+    tr.DEC_FUSED = bool(fused)   # (route switch: a module attribute since round 5, no environment variable)
     try:
         with torch.no_grad():
             return dec.forward_bf(query, memory, mask, ref, vr, reg, spatial_shapes=ss, level_start_index=ls)
     finally:
-        os.environ.pop("CODETR_DEC_FUSED", None)
+        tr.DEC_FUSED = saved
 
 
 PYR = [(40, 60), (20, 30), (10, 15), (5, 8), (3, 4)]

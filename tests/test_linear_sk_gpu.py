@@ -64,6 +64,17 @@ def test_linear_sk_epilogues(bias, act, res, flags):
     _run(70000, 384, 384, torch.float16, bias, act, res, flags, seed=3)   # 274 x 2 tiles: a left-over round to split
 
 
+@pytest.mark.parametrize("K", [192, 768])
+def test_waves_without_an_epilogue_wait_for_their_dma_pieces(K):
+    """with N = 192 (one column tile, Swin stage-0 proj / fc2) the wn = 3 waves of every tile store nothing,
+    and with M % 256 in 1..128 neither do the wm = 1 waves of the last tile row; such a wave must not take the relaxed
+    `vmcnt(VMN + 32)` wait of the phases behind an epilogue (it would run ahead of LDS-DMA pieces everybody reads).
+    A race shows up as rare wrong elements: many tiles per workgroup, several repeats, no residual."""
+    for rep, M in enumerate((256 * 1300 + 1, 256 * 1300 + 128, 256 * 700 + 64, 256 * 1024 + 100)):
+        for again in range(2):
+            _run(M, 192, K, torch.float16, True, None, False, 0, seed=20 + rep)
+
+
 def test_linear_sk_bf16():
     _run(33000, 776, 256, torch.bfloat16, True, "gelu", True, 0, seed=4)
     _run(33000, 776, 256, torch.bfloat16, True, None, True, 0x40, seed=5)

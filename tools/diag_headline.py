@@ -42,7 +42,8 @@ with torch.no_grad():
     cap1 = {}
     model(x4[:1], m4[:1], forced_topk_indices=picks0, capture=cap1)
 got4, got1 = F.sample_capture(NAME, cap4, image=0, images=4), F.sample_capture(NAME, cap1)
-print(f"CODETR_MSDA_ENC={os.environ.get('CODETR_MSDA_ENC', '1')}")
+import codetr.hip_ops as _ho
+print(f"hip_ops.MSDA_ENCODER={_ho.MSDA_ENCODER}")
 for k in got4:
     r4, r1, r41 = rel(got4[k], fx[k]), rel(got1[k], fx[k]), rel(got4[k], got1[k])
     rr = row_error_stats(got4[k], fx[k], 1e-2) if got4[k].ndim == 2 else (0, 0, 0)
