@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -49,6 +49,10 @@ SIGNATURES = {
     "codetr_msda_encoder_forward_win_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
                                                     _i32, _i32, _vp, _i32, _vp]),
     "codetr_msda_encoder_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32]),
+    "codetr_msda_encoder_forward_packed_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
+                                                      _vp, _i32, _i32, _i32, _i32, _vp]),
+    "codetr_msda_encoder_packed_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32]),
+    "codetr_msda_pack_projection_index": (_i32, [_i32, _i32, _i32, _vp]),
     "codetr_mx_scale_bytes": (_i64, [_i64, _i64]),
     "codetr_linear_fp8mx": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32]),
     "codetr_cast_fp8mx_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64]),
@@ -142,7 +146,7 @@ _lib = None
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "linear_sk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
-         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
+         "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "msda_encoder_packed": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
          "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0,
          "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0, "ffn_fp8": 0, "decoder_layer": 0}
@@ -155,7 +159,8 @@ RECORDER = None
 _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
             "codetr_linear_sk_workspace_bytes", "codetr_linear_sk_supported", "codetr_linear_sk_preferred",
-            "codetr_msda_encoder_lds_bytes", "codetr_mx_scale_bytes", "codetr_decoder_layer_supported",
+            "codetr_msda_encoder_lds_bytes", "codetr_msda_encoder_packed_lds_bytes", "codetr_msda_pack_projection_index",
+            "codetr_mx_scale_bytes", "codetr_decoder_layer_supported",
             "codetr_decoder_layer_blob_halfs"}
 
 
@@ -627,6 +632,46 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points,
         return False
     check(rc, "codetr_msda_encoder_forward_win")
     CALLS["msda_encoder"] += 1
+    return True
+
+
+def msda_encoder_packed_lds_bytes(level_shapes, M, num_points, windows, region, threads) -> int:
+    """LDS bytes per workgroup of codetr_msda_encoder_forward_packed_f16 (negative: CODETR_E_* code)"""
+    L = len(level_shapes)
+    shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
+    return int(load().codetr_msda_encoder_packed_lds_bytes(shapes, M, L, num_points, _windows_array(windows, M, L),
+                                                           int(region[0]), int(region[1]), int(threads)))
+
+
+def msda_pack_projection_index(M, L, P):
+    """source row of the concatenated (sampling_offsets | attention_weights) projection for every column of the
+    lane-major packed layout (list of 64 M ints, -1 = pad), or None when the library has no packed kernel for (L, P)"""
+    idx = (ctypes.c_int32 * (64 * M))()
+    rc = load().codetr_msda_pack_projection_index(M, L, P, idx)
+    if rc == E_UNSUPPORTED:
+        return None
+    check(rc, "codetr_msda_pack_projection_index")
+    return list(idx)
+
+
+def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_counts, region, threads, out,
+                        variant=0) -> bool:
+    """Round-5 encoder kernel: value [B,S,M,32] fp16; packed [B,S,>=64 M] fp16 (lane-major packed projection);
+    valid_counts [B,L,2] fp32; windows [M][L][4]; region (w, h) in finest-level pixels; threads 256 | 512.  Returns
+    False when the library reports the shape as unsupported, raises on any other error."""
+    lib = load()
+    B, S, M, D = value.shape
+    L = len(level_shapes)
+    shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
+    rc = lib.codetr_msda_encoder_forward_packed_f16(
+        current_stream_ptr(value.device), value.data_ptr(), shapes, packed.data_ptr(), packed.shape[-1],
+        valid_counts.data_ptr(), B, S, M, D, L, num_points, _windows_array(windows, M, L), int(region[0]), int(region[1]),
+        int(threads), int(variant), out.data_ptr())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "codetr_msda_encoder_forward_packed_f16")
+    CALLS["msda_encoder"] += 1
+    CALLS["msda_encoder_packed"] += 1
     return True
 
 

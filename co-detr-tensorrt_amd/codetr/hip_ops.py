@@ -728,6 +728,103 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, reference_points
     return out if ok[0] else None
 
 
+# ---- round-5 encoder kernel (csrc/msda_encoder4.hip): lane-major packed projection, scalar geometry, zero border ----
+MSDA_V4 = True                 # route switch: False = the round-3/4 three-pass kernel on the unpacked projection
+MSDA_V4_THREADS = 256          # workgroup size (256: four workgroups per CU; 512: two)
+MSDA_V4_REGION = (16, 8)       # region of a workgroup, pixels of the finest level
+MSDA_V4_LDS_BUDGET = 40 * 1024   # bytes per workgroup
+MSDA_V4_MARGIN_CAP = 40.0      # pixels: windows grow up to this margin around a head's bias points within the LDS budget
+MSDA_V4_VARIANT = 0            # kernel build (include/codetr_hip.h): bit 0 fix-up prefetch, bit 1 three waves per SIMD
+_SWITCH_DEFAULTS.update({"MSDA_V4": True, "MSDA_V4_THREADS": 256, "MSDA_V4_REGION": (16, 8),
+                         "MSDA_V4_LDS_BUDGET": 40 * 1024, "MSDA_V4_MARGIN_CAP": 40.0, "MSDA_V4_VARIANT": 0})
+
+
+def msda_encoder_packed_supported(dtype, head_dim, num_levels, num_points):
+    return MSDA_V4 and MSDA_ENCODER and dtype == torch.float16 and head_dim == 32 and num_levels == 5 and num_points == 4
+
+
+def msda_packed_projection(w_off, b_off, w_aw, b_aw, num_heads, num_levels, num_points):
+    """(sampling_offsets | attention_weights) as ONE [64 M, C] weight + [64 M] bias whose output row is the lane-major
+    packed layout codetr_msda_encoder_forward_packed_f16 reads (include/codetr_hip.h): per head 4 x 16 columns = the
+    (x, y) offsets of point p on the five levels, its five logits, one zero pad column.  Pure row permutation of the
+    reference's two Linears (multi_scale_deformable_attention.py:83-85): no arithmetic changes."""
+    idx = _cabi.msda_pack_projection_index(num_heads, num_levels, num_points)
+    if idx is None:
+        return None
+    ii = torch.tensor(idx, dtype=torch.long, device=w_off.device)
+    wcat = torch.cat((w_off, w_aw), 0)
+    bcat = torch.cat((b_off, b_aw), 0)
+    pad = ii < 0
+    wp = wcat[ii.clamp_min(0)].clone()
+    bp = bcat[ii.clamp_min(0)].clone()
+    wp[pad] = 0
+    bp[pad] = 0
+    return wp.contiguous(), bp.contiguous()
+
+
+def msda_encoder_windows_packed(bias, level_shapes, num_heads, num_levels, num_points):
+    """Staged window per (head, level) for the packed encoder kernel, as msda_encoder_windows: the bounding box of the
+    head's bias points on that level grown by the largest margin (steps of 1/2 pixel, at most MSDA_V4_MARGIN_CAP) that
+    keeps the workgroup inside MSDA_V4_LDS_BUDGET, per pass {0}, {1, 2}, {3, 4}.  Windows are clamped to the level (plus
+    its zero border) by the kernel, so on the coarse levels a generous margin ends as whole-level residency."""
+    import math
+
+    b = bias.detach().float().cpu().view(num_heads, num_levels, num_points, 2)
+    b = torch.round(b * 1024) / 1024
+    lo, hi = b.amin(2).tolist(), b.amax(2).tolist()
+    groups = [[0], [1, 2], [3, 4]]
+    steps = int(2 * MSDA_V4_MARGIN_CAP)
+
+    def window(m, l, mg):
+        return (max(-127, math.floor(lo[m][l][0] - mg)), min(127, math.ceil(hi[m][l][0] + mg)),
+                max(-127, math.floor(lo[m][l][1] - mg)), min(127, math.ceil(hi[m][l][1] + mg)))
+
+    def need(trial):
+        return _cabi.msda_encoder_packed_lds_bytes(level_shapes, num_heads, num_points, [trial] * num_heads,
+                                                   MSDA_V4_REGION, MSDA_V4_THREADS)
+
+    out = []
+    for m in range(num_heads):
+        win = [window(m, l, 0.0) for l in range(num_levels)]
+        for grp in groups:
+            a, z = 0, steps          # largest half-step count that fits (monotone): bisection
+            while a < z:
+                mid = (a + z + 1) // 2
+                trial = list(win)
+                for l in grp:
+                    trial[l] = window(m, l, 0.5 * mid)
+                n = need(trial)
+                if 0 < n <= MSDA_V4_LDS_BUDGET:
+                    a = mid
+                else:
+                    z = mid - 1
+            for l in grp:
+                win[l] = window(m, l, 0.5 * a)
+        out.append(win)
+    return out
+
+
+def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_counts):
+    """Encoder self-attention MSDA on the lane-major packed projection (round-5 kernel).  value [B,S,M,32] fp16, packed
+    [B,S,64 M] fp16, valid_counts [B,L,2] fp32.  Returns None when the library does not take the shape."""
+    _gpu(value, "msda_encoder_packed")
+    B, S, M, D = value.shape
+    if not (valid_counts is not None and valid_counts.dtype == torch.float32 and valid_counts.is_contiguous()
+            and valid_counts.shape == (B, len(level_shapes), 2) and packed.shape[:2] == (B, S) and packed.is_contiguous()):
+        return None
+    out = torch.empty((B, S, M * D), dtype=value.dtype, device=value.device)
+    ok = [True]
+
+    def run():
+        ok[0] = _cabi.msda_encoder_packed(value.contiguous(), level_shapes, packed, num_points, windows, valid_counts,
+                                          MSDA_V4_REGION, MSDA_V4_THREADS, out, MSDA_V4_VARIANT)
+
+    with torch.cuda.device(value.device):
+        _timed("msda_fused", {"B": B, "S": S, "Nq": S, "M": M, "D": D, "L": len(level_shapes), "P": num_points},
+               run, value.device)
+    return out if ok[0] else None
+
+
 def msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step):
     """The reference's native op, hand-written HIP behind the C ABI (always native)."""
     return torch.ops.codetr.multi_scale_deformable_attention(

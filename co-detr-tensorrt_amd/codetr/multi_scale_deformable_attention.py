@@ -91,6 +91,21 @@ class MultiScaleDeformableAttention(nn.Module):
         return hip_ops.derived(ws, "_codetr_fused_proj", lambda: (torch.cat((ws[0], ws[2]), 0).contiguous(),
                                                                   torch.cat((ws[1], ws[3]), 0).contiguous()))
 
+    def _packed_projection(self):
+        """the same two Linears with their rows permuted into the lane-major packed layout of the round-5 encoder
+        kernel ([64 M, C]; hip_ops.msda_packed_projection)"""
+        ws = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
+              self.attention_weights.bias)
+        return hip_ops.derived(ws, "_codetr_packed_proj", lambda: hip_ops.msda_packed_projection(
+            *ws, self.num_heads, self.num_levels, self.num_points))
+
+    def _encoder_windows_packed(self, host_shapes):
+        key = ("_codetr_enc_windows_v4_" + "_".join(f"{int(h)}x{int(w)}" for h, w in host_shapes)
+               + f"_{hip_ops.MSDA_V4_THREADS}_{hip_ops.MSDA_V4_REGION}_{hip_ops.MSDA_V4_LDS_BUDGET}_{hip_ops.MSDA_V4_MARGIN_CAP}")
+        b = self.sampling_offsets.bias
+        return hip_ops.derived((b,), key, lambda: hip_ops.msda_encoder_windows_packed(
+            b, [(int(h), int(w)) for h, w in host_shapes], self.num_heads, self.num_levels, self.num_points))
+
     def _encoder_windows(self, host_shapes, dtype, passes):
         """staged window per (head, level) of the LDS-staged encoder kernel, from the offset bias; rebuilt only when
         the bias tensor or the pyramid changes (one device-to-host copy of 320 values, outside the steady state)"""
@@ -144,6 +159,18 @@ class MultiScaleDeformableAttention(nn.Module):
             v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask)
         v = v.view(B, S, H, -1)
         if query.is_cuda and hip_ops.msda_fused_supported(v.dtype, v.shape[-1], L, P):
+            host_shapes = getattr(spatial_shapes, "_codetr_host", None)
+            counts = getattr(reference_points, "_codetr_valid_counts", None)
+            if (host_shapes is not None and Nq == S and reference_points.shape[-1] == 2 and counts is not None
+                    and hip_ops.MSDA_FP32_REF and hip_ops.msda_encoder_packed_supported(v.dtype, v.shape[-1], L, P)):
+                # encoder self-attention, round-5 kernel: the projection GEMM writes the lane-major packed layout (its
+                # weight rows permuted once), the gather kernel reads it with two 16-byte loads per lane
+                Wp, bp = self._packed_projection()
+                packed = (hip_ops.linear_xadd(query, pos_in_gemm, Wp, bp) if pos_in_gemm is not None
+                          else hip_ops.linear(query, Wp, bp))
+                out = hip_ops.msda_encoder_packed(v, host_shapes, packed, P, self._encoder_windows_packed(host_shapes), counts)
+                if out is not None:
+                    return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
             # one GEMM for (offsets | logits); softmax and location arithmetic happen inside the MSDA kernel
             Wc, bc = self._fused_projection()
             proj = hip_ops.linear_xadd(query, pos_in_gemm, Wc, bc) if pos_in_gemm is not None else hip_ops.linear(query, Wc, bc)
@@ -218,7 +245,7 @@ class MultiScaleDeformableAttention(nn.Module):
         if not hip_ops.msda_fused_supported(value.dtype, hd, L, P):
             return False
         Wc, _ = self._fused_projection()
-        return hip_ops.linear_xadd_supported(query, query_pos, Wc)
+        return hip_ops.linear_xadd_supported(query, query_pos, Wc)   # (the packed projection, N = 64 M, takes the same kernel)
 
     # ------------------------------------------------------------------ reference signature
     def forward(

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 40
+#define CODETR_HIP_ABI_VERSION 41
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -192,6 +192,41 @@ int codetr_msda_encoder_forward_win_bf16(void *stream, const void *value_dev, co
                                          int passes, void *out_dev);
 int64_t codetr_msda_encoder_lds_bytes(const int64_t *level_shapes_host, int M, int L, int P,
                                       const int8_t *windows_host, int variant);
+
+/* Round-5 form of the encoder kernel ("v4", csrc/msda_encoder4.hip): the same op -- ms_deform_attn.cu:31-77, 211-261 with
+ * the softmax / sampling-location prologue of multi_scale_deformable_attention.py:180-196 and the reference points of
+ * transformer.py:280-305 -- for fp16, L == 5, P == 4, D == 32, with the (offsets | logits) projection handed over in a
+ * LANE-MAJOR PACKED layout so that a quad lane of the gather fetches all it needs with two 16-byte loads:
+ *   packed_dev        [B * S][packed_row_stride] fp16, packed_row_stride >= 64 M and a multiple of 8; for head m and
+ *                     point p (= the quad lane), the 16 halves at columns 64 m + 16 p .. + 15 are
+ *                       (x, y) offset of (m, level 0, p), ... , (m, level 4, p)        10 halves   [sampling_offsets rows
+ *                       logit of (m, level 0, p), ... , (m, level 4, p)                 5 halves    ((m L + l) P + p) 2 + xy,
+ *                       one pad half (ignored)                                                       attention_weights rows (m L + l) P + p]
+ *                     i.e. the output of the (sampling_offsets | attention_weights) Linear with its weight rows permuted
+ *                     once on the host (codetr_msda_pack_projection_index gives the permutation).
+ *   valid_counts_dev  [B][L][2] fp32, required: the reference points are computed in fp32 from the query's pixel centre
+ *                     and the valid pixel counts (see codetr_msda_encoder_forward_win_f16).
+ *   windows_host      [M][L][4] int8 as above.  A window may exceed the level: it is clamped to the image plus a one-pixel
+ *                     ZERO border (corners outside the image read zeros from LDS, ms_deform_attn.cu:52-71), so a wide
+ *                     window on a coarse level keeps the whole level resident.
+ *   region_w/region_h region of a workgroup in pixels of the finest level; threads: 256 | 512 per workgroup.  A region may
+ *                     hold at most 3 * threads / 4 queries (CODETR_E_UNSUPPORTED otherwise).
+ *   variant           kernel build, same results: bit 0 = the first fix-up round's rows are requested before the gather
+ *                     loop of their iteration; bit 1 (256 threads only) = three waves per SIMD (168 registers; meant for
+ *                     three workgroups of <= 53 KiB per CU instead of four of <= 40 KiB).
+ * Samples outside the windows are added from global memory with the reference's gate / corner logic: windows change
+ * speed, never results beyond the rounding of the packed blend (same tolerance statement as the _win entry).
+ * codetr_msda_encoder_packed_lds_bytes: LDS bytes per workgroup such a launch needs, or a negative CODETR_E_* code.
+ * codetr_msda_pack_projection_index: idx[64 M] (host): source row of the concatenated [M L P 2 + M L P] projection for
+ * every packed output column, -1 for the pad columns. */
+int codetr_msda_encoder_forward_packed_f16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
+                                           const void *packed_dev, int64_t packed_row_stride,
+                                           const float *valid_counts_dev, int64_t B, int64_t S, int M, int D, int L, int P,
+                                           const int8_t *windows_host, int region_w, int region_h, int threads,
+                                           int variant, void *out_dev);
+int64_t codetr_msda_encoder_packed_lds_bytes(const int64_t *level_shapes_host, int M, int L, int P,
+                                             const int8_t *windows_host, int region_w, int region_h, int threads);
+int codetr_msda_pack_projection_index(int M, int L, int P, int32_t *idx_host);
 
 /* ------------------------------------------------------------------------------------------
  * Patch gather of the Swin stem (mmdet PatchEmbed: Conv2d(C, E, k, stride k) with "corner" zero padding, reference

@@ -340,8 +340,11 @@ def reg_branch(sd, p, x):
     return _lin(sd, p + ".4", x)
 
 
-def decoder(sd, p, query, memory, pad_mask, ref_unact, valid_ratios, spatial_shapes, level_start, reg_prefix):
-    """query [B,Nq,C]; ref_unact [B,Nq,4] (logits). Returns (normed final state [B,Nq,C], refs [B,Nq,4])."""
+def decoder(sd, p, query, memory, pad_mask, ref_unact, valid_ratios, spatial_shapes, level_start, reg_prefix,
+            layer_capture=None):
+    """query [B,Nq,C]; ref_unact [B,Nq,4] (logits). Returns (normed final state [B,Nq,C], refs [B,Nq,4]).
+    layer_capture: a list that receives, per layer, dict(x_in, ref_in_unact, qpos, x_out, ref_out_unact) -- the layer's
+    own inputs and outputs (reference transformer.py:193-230), for single-layer parity tests."""
     x = query
     vr4 = torch.cat((valid_ratios, valid_ratios), -1)  # [B,L,4]
     n_layers = _count(sd, p + ".layers.")
@@ -349,6 +352,8 @@ def decoder(sd, p, query, memory, pad_mask, ref_unact, valid_ratios, spatial_sha
         lp = f"{p}.layers.{i}"
         ref_in = ref_unact.sigmoid()[:, :, None, :] * vr4[:, None]  # [B,Nq,L,4]
         qpos = _lin(sd, p + ".ref_point_head.2", F.relu(_lin(sd, p + ".ref_point_head.0", _sine_embed(ref_in[:, :, 0, :]))))
+        if layer_capture is not None:
+            layer_capture.append(dict(x_in=x, ref_in_unact=ref_unact, qpos=qpos))
         x = mha_module(sd, lp + ".attentions.0", x, qpos)
         x = _ln(sd, lp + ".norms.0", x)
         x = msda_module(sd, lp + ".attentions.1", x, memory, qpos, pad_mask, ref_in, spatial_shapes, level_start)
@@ -356,6 +361,8 @@ def decoder(sd, p, query, memory, pad_mask, ref_unact, valid_ratios, spatial_sha
         x = ffn(sd, lp + ".ffns.0", x)
         x = _ln(sd, lp + ".norms.2", x)
         ref_unact = reg_branch(sd, f"{reg_prefix}.{i}", x) + ref_unact  # no detach, no sigmoid
+        if layer_capture is not None:
+            layer_capture[-1].update(x_out=x, ref_out_unact=ref_unact)
     return _ln(sd, p + ".norm", x), ref_unact
 
 

@@ -36,3 +36,24 @@ def test_oracle_reproduces_the_r50_fixture():
     got = F.sample_capture(name, cap)
     for k, v in got.items():
         np.testing.assert_allclose(v, fx[k], rtol=1e-4, atol=1e-4 * float(np.abs(fx[k]).max()), err_msg=k)
+
+
+def test_oracle_reproduces_the_single_decoder_layer_fixture():
+    """tests/golden/decoder_layer_1920x1280.npz == what oracle/codetr_fp32.decoder computes today for the layer under test
+    on the stored (fp16-rounded) layer inputs (about 5 s): the GPU test's expectation is the oracle's, not an edited file"""
+    import decoder_layer_case as D
+
+    fx = D.load_fixture()
+    dec, reg = D.build_decoder()
+    sd = D.state_dict(dec, reg)
+    lid = int(fx["layer"])
+    one = {k: v for k, v in sd.items() if ".layers." not in k and not k.startswith("reg.")}
+    one.update({k.replace(f"dec.layers.{lid}.", "dec.layers.0."): v for k, v in sd.items() if k.startswith(f"dec.layers.{lid}.")})
+    one.update({k.replace(f"reg.{lid}.", "reg.0."): v for k, v in sd.items() if k.startswith(f"reg.{lid}.")})
+    memory, pad, vr, ss, start = D.memory_and_masks()
+    cap = []
+    with torch.no_grad():
+        M.decoder(one, "dec", torch.from_numpy(fx["x_in"]).float(), memory, pad, torch.from_numpy(fx["ref_in_unact"]).float(),
+                  vr, ss, start, "reg", layer_capture=cap)
+    for k in ("qpos", "x_out", "ref_out_unact"):
+        np.testing.assert_allclose(cap[0][k].numpy(), fx[k], rtol=1e-4, atol=1e-4 * float(np.abs(fx[k]).max()), err_msg=k)

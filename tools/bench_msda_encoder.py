@@ -21,6 +21,12 @@ def main():
     ap.add_argument("--windows", type=int, default=1, help="1: windows from the bias grid, 0: symmetric halo")
     ap.add_argument("--passes", type=int, default=3, help="3: three-pass kernel, 1: single pass")
     ap.add_argument("--counts", type=int, default=0, help="1: reference points computed in fp32 from valid counts")
+    ap.add_argument("--v4", type=int, default=0, help="1: the round-5 packed kernel (codetr_msda_encoder_forward_packed_f16)")
+    ap.add_argument("--threads", type=int, default=256)
+    ap.add_argument("--region", default="16x8")
+    ap.add_argument("--budget", type=int, default=0, help="LDS bytes per workgroup (default 40 KiB x 256 / threads ... see code)")
+    ap.add_argument("--cap", type=float, default=40.0, help="largest window margin in pixels")
+    ap.add_argument("--variant", type=int, default=0, help="v4 kernel build: bit 0 fix-up prefetch, bit 1 three waves per SIMD")
     a = ap.parse_args()
     from codetr import _cabi, hip_ops
 
@@ -64,7 +70,21 @@ def main():
     counts = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=dev)[None].expand(B, L, 2).contiguous()
     enc = lambda: hip_ops.msda_encoder(value, shapes, proj, 0, M * L * P * 2, ref, P, win, a.passes,  # noqa: E731
                                        counts if a.counts else None)
-    if win is not None:
+    if a.v4:
+        hip_ops.MSDA_V4_THREADS = a.threads
+        hip_ops.MSDA_V4_REGION = tuple(int(v) for v in a.region.split("x"))
+        hip_ops.MSDA_V4_LDS_BUDGET = a.budget if a.budget else (40 * 1024 if a.threads == 256 else 80 * 1024)
+        hip_ops.MSDA_V4_MARGIN_CAP = a.cap
+        hip_ops.MSDA_V4_VARIANT = a.variant
+        idx = torch.tensor(_cabi.msda_pack_projection_index(M, L, P), device=dev)
+        packed = proj[..., idx.clamp_min(0)].clone()
+        packed[..., idx < 0] = 0
+        packed = packed.contiguous()
+        win = hip_ops.msda_encoder_windows_packed(bias.reshape(-1), shapes, M, L, P)
+        enc = lambda: hip_ops.msda_encoder_packed(value, shapes, packed, P, win, counts)  # noqa: E731
+        print("v4 windows head 0/1:", win[0], win[1], "lds",
+              _cabi.msda_encoder_packed_lds_bytes(shapes, M, P, win, hip_ops.MSDA_V4_REGION, a.threads))
+    elif win is not None:
         print("windows head 0/1:", win[0], win[1], "lds", _cabi.msda_encoder_lds_bytes(shapes, M, P, win, 3 if a.passes == 3 else 2))
     gen = lambda: hip_ops.msda_fused(value, ss, ls, proj, 0, M * L * P * 2, ref, L, P)  # noqa: E731
     o1, o2 = enc(), gen()
@@ -75,7 +95,8 @@ def main():
     alg = 2 * (B * S * M * D + 3 * B * S * M * L * P + B * S * M * D)
     print(f"batch {B} noise {a.noise} halo {hip_ops.MSDA_HALO}: encoder kernel {t_enc:8.1f} us "
           f"({alg / t_enc / 1e6:6.2f} TB/s algorithmic)   general fused {t_gen:8.1f} us   identical: {same} "
-          f"rel L2 vs general {rel:.2e}  windows {'bias' if a.windows else 'halo'} passes {a.passes} counts {a.counts}")
+          f"rel L2 vs general {rel:.2e}  windows {'bias' if a.windows else 'halo'} passes {a.passes} counts {a.counts}"
+          + (f"  v4 threads {a.threads} region {a.region} cap {a.cap} variant {a.variant} budget {hip_ops.MSDA_V4_LDS_BUDGET}" if a.v4 else ""))
 
 
 if __name__ == "__main__":
