@@ -18,9 +18,11 @@ barrier + torch.cuda.synchronize() on both sides, MAX over ranks.  Rank 0 prints
 
 Weights: seeded default init, except that every MSDA ``sampling_offsets.weight`` (zero in the default init, i.e. every
 query would sample the fixed bias grid -- the best case for the LDS-staged encoder kernel) is drawn so that the sampling
-offsets carry ``--offset-noise-px`` (default 2) pixels of query-dependent spread on top of the bias grid, like trained
-Co-DINO offsets; the measured spread and the fraction of samples that leave the staged neighbourhood are reported in
-``roofline_msda``, next to the same kernel's number at zero spread (``roofline_msda_zero_noise``).
+offsets carry ``--offset-noise-px`` (default 2) pixels of query-dependent spread on top of the bias grid.  2 px is an
+ASSUMPTION, not a measurement of a trained checkpoint (none is available offline; the offsets of reference
+codetr/multi_scale_deformable_attention.py:186-191 are in level pixels and unbounded): the same kernel is therefore also
+measured at 0, 4 and 8 px (``roofline_msda_zero_noise`` / ``_4px`` / ``_8px``, with the share of samples that leave the
+staged windows), and the whole model at 8 px (``value_8px``).
 
 Extra objects on that line: ``host_feed`` -- the same K steps with every step's images copied from pinned host memory
 (PCIe) on the sub-batch streams, i.e. the rate including the input transfer (never ``value``); and at N=1 only:
@@ -114,20 +116,29 @@ def msda_offset_stats(model, images, masks, halo=4):
     orig_linear, orig_xadd = hip_ops.linear, hip_ops.linear_xadd
     pyramid_shapes = pyramid(int(images.shape[-2]), int(images.shape[-1])) if enc_atts and enc_atts[0].num_levels == 5 else None
 
-    def record(att, proj):
+    def record(att, proj, packed):
         n_off = att.num_heads * att.num_levels * att.num_points * 2
+        if packed:   # lane-major packed projection (round-5 encoder kernel): back to the reference's column order
+            from codetr import _cabi as cabi
+            idx = torch.tensor(cabi.msda_pack_projection_index(att.num_heads, att.num_levels, att.num_points), device=proj.device)
+            std = proj.new_zeros(*proj.shape[:-1], n_off + n_off // 2)
+            std[..., idx[idx >= 0]] = proj[..., (idx >= 0).nonzero().flatten()]
+            proj = std
         off = proj[..., :n_off].float()
         bias = att.sampling_offsets.bias.float()
         spread = (off - bias).std().item()
         miss = (off.abs().view(*off.shape[:-1], -1, 2).amax(-1) > halo).float().mean().item()
-        # ... and the windows the encoder kernel actually stages (per head and level, three-pass form): a sample is in
-        # when both bilinear corners of floor(offset) are (exact for level-0 queries, whose centre sits on the level's
-        # grid; an estimate for the coarser levels' sub-pixel phases)
+        # ... and the windows the encoder kernel actually stages (per head and level): a sample is in when both bilinear
+        # corners of floor(offset) are (exact for level-0 queries, whose centre sits on the level's grid; an estimate for
+        # the coarser levels' sub-pixel phases)
         wmiss = None
         if pyramid_shapes is not None:
-            passes = hip_ops.msda_encoder_passes(torch.float16, att.num_levels, att.num_points)
-            win = torch.tensor(att._encoder_windows(pyramid_shapes, torch.float16, passes), dtype=torch.float32,
-                               device=off.device)                                       # [M, L, 4] lox, hix, loy, hiy
+            if packed:
+                wl = att._encoder_windows_packed(pyramid_shapes)
+            else:
+                passes = hip_ops.msda_encoder_passes(torch.float16, att.num_levels, att.num_points)
+                wl = att._encoder_windows(pyramid_shapes, torch.float16, passes)
+            win = torch.tensor(wl, dtype=torch.float32, device=off.device)             # [M, L, 4] lox, hix, loy, hiy
             o = off.view(*off.shape[:-1], att.num_heads, att.num_levels, att.num_points, 2)
             x0, y0 = torch.floor(o[..., 0]), torch.floor(o[..., 1])
             w = win[:, :, None, :]
@@ -138,21 +149,24 @@ def msda_offset_stats(model, images, masks, halo=4):
     def find(weight):
         for a in enc_atts:
             if a._fused_projection()[0] is weight:
-                return a
-        return None
+                return a, False
+            if hip_ops.msda_encoder_packed_supported(torch.float16, 32, a.num_levels, a.num_points) and \
+                    a._packed_projection()[0] is weight:
+                return a, True
+        return None, False
 
     def linear(x, weight, *args, **kw):
         y = orig_linear(x, weight, *args, **kw)
-        a = find(weight)
+        a, packed = find(weight)
         if a is not None and y.shape[-1] == weight.shape[0] and y.dim() == 3 and y.shape[1] > 10000:
-            record(a, y)
+            record(a, y, packed)
         return y
 
     def linear_xadd(x, x_add, weight, bias=None):
         y = orig_xadd(x, x_add, weight, bias)
-        a = find(weight)
+        a, packed = find(weight)
         if a is not None:
-            record(a, y)
+            record(a, y, packed)
         return y
 
     hip_ops.linear, hip_ops.linear_xadd = linear, linear_xadd
@@ -169,8 +183,9 @@ def msda_offset_stats(model, images, masks, halo=4):
            "halo_px": halo}
     if all(c is not None for _, _, c in stats):
         rec["fraction_of_samples_outside_staged_windows_per_layer"] = [round(c, 4) for _, _, c in stats]
-        rec["windows_note"] = ("the default encoder kernel stages per-(head, level) windows derived from the offset bias "
-                               "(three passes), not the symmetric halo: this is the share that takes its fix-up queue")
+        rec["windows_note"] = ("the encoder kernel stages per-(head, level) windows derived from the offset bias (three "
+                               "passes, clamped to the level + a zero border), not the symmetric halo: this is the share "
+                               "that takes its fix-up queue")
     return rec
 
 
@@ -351,6 +366,8 @@ def kernel_rooflines(model, images, masks, device):
         t = sum(a.elapsed_time(b) for a, b, _ in enc) * 1e-3 / len(enc)
         out["roofline_msda"] = {
             "kernel": "%s (the %d encoder launches of one forward, Nq = S = %d)" % (
+                "msda_encoder_v4_kernel (lane-major packed projection, head-major value map, scalar geometry, zero-border "
+                "windows; packed-half blend, three passes, fp32 reference points)" if _cabi_mod.CALLS.get("msda_encoder_packed", 0) > 0 else
                 ("msda_encoder_v3_kernel<F16> (packed-half blend, three passes, fp32 reference points)"
                  if __import__("codetr.hip_ops", fromlist=["x"]).msda_encoder_passes(torch.float16, m["L"], m["P"]) == 3
                  else "msda_encoder_v2_kernel<F16> (packed-half blend, one pass)") if enc_native
@@ -722,16 +739,27 @@ def main():
             # encoder-memory error <= 2e-2 against the fp16 product): 8 of the 88 GEMMs -- timed so that the line says what
             # that selection is worth, and that the full selection above is a FAST mode
             fp8_line["recommended"] = False
-            fp8_line["accuracy"] = {"encoder_memory_rel_l2_vs_fp16": 7.8e-2, "proxy_AP": 0.63, "proxy_AP_fp16": 0.86,
-                                    "source": "profiles/r04_fp8_sensitivity.json (all_e4m3)"}
+            # (accuracy figures are READ from the committed sensitivity run, with its path and date: they are not
+            # measurements of this run -- ADVICE r04)
+            sens_path = os.path.join(ROOT, "profiles", "r04_fp8_sensitivity.json")
+            try:
+                sens = json.load(open(sens_path))
+                fp8_line["accuracy"] = {"encoder_memory_rel_l2_vs_fp16": sens["all_e4m3"]["memory_rel_l2"],
+                                        "proxy_AP": sens["all_e4m3"]["AP"], "proxy_AP_fp16": sens["fp16"]["AP"],
+                                        "source": "profiles/r04_fp8_sensitivity.json (all_e4m3), file of %s -- an earlier "
+                                                  "run of tools/fp8_sensitivity.py, not measured here"
+                                                  % time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(sens_path)))}
+            except (OSError, KeyError, ValueError):
+                fp8_line["accuracy"] = {"source": "profiles/r04_fp8_sensitivity.json not readable"}
             fp8.enable(model, True, "mx", select="accurate")
             graphs = capture()
             ea, pera = timed(False)
             fp8_line["accurate_preset"] = {"images_per_s": round(a.steps * a.batch / ea, 3),
                                            "p50_ms_per_image": round(pera[len(pera) // 2] / a.batch, 3),
                                            "config": fp8.report(model),
-                                           "encoder_memory_rel_l2_vs_fp16": 1.7e-2,
-                                           "note": "stage-3 qkv / fc1 / fc2 + stage-1 fc2 in e4m3, encoder FFN in fp16"}
+                                           "note": "stage-3 qkv / fc1 / fc2 + stage-1 fc2 in e4m3, encoder FFN in fp16; encoder-"
+                                                   "memory error 1.7e-2 vs the fp16 product when tools/fp8_sensitivity.py "
+                                                   "was last run (profiles/r04_fp8_sensitivity.json), not measured here"}
         except Exception as e:  # noqa: BLE001 -- the optional sub-record must never cost the measured fp16 line
             torch.cuda.synchronize(device)
             fp8_line = {"error": repr(e)}
@@ -762,6 +790,26 @@ def main():
         finally:
             for _, m_ in subs:
                 m_.zero_()
+
+    # ---- the same K steps with 8 px of query-dependent MSDA offset spread (the 2 px of the headline is an
+    # assumption; wider offsets push samples out of the encoder kernel's staged windows) ----
+    wide_line = None
+    if world == 1 and a.dtype == "fp16" and a.offset_noise_px > 0 and not a.no_roofline:
+        base_graphs = graphs
+        try:
+            set_offset_noise(model, 8.0)
+            graphs = capture()     # (derived weights -- the packed projections -- are rebuilt: new launch lists)
+            e8px, per8px = timed(False)
+            wide_line = {"images_per_s": round(a.steps * a.batch / e8px, 3), "ms_per_step": round(e8px / a.steps * 1e3, 3),
+                         "p50_ms_per_image": round(per8px[len(per8px) // 2] / a.batch, 3),
+                         "vs_headline": round((a.steps * a.batch / e8px) / (a.steps * a.batch * world / elapsed), 4),
+                         "msda_offset_noise_px": 8.0}
+        except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize(device)
+            wide_line = {"error": repr(e)}
+        finally:
+            set_offset_noise(model, a.offset_noise_px)
+            graphs = base_graphs
 
     if rank == 0:
         total_images = a.steps * a.batch * world
@@ -803,6 +851,8 @@ def main():
             out["fp8"] = fp8_line
         if padded_line is not None:
             out["padded"] = padded_line
+        if wide_line is not None:
+            out["value_8px"] = wide_line
         if fp8_report is not None:
             out["config"]["fp8"] = fp8_report
         if world == 1 and not a.no_roofline:

@@ -50,7 +50,7 @@ SIGNATURES = {
                                                     _i32, _i32, _vp, _i32, _vp]),
     "codetr_msda_encoder_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32]),
     "codetr_msda_encoder_forward_packed_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
-                                                      _vp, _i32, _i32, _i32, _i32, _vp]),
+                                                      _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "codetr_msda_encoder_packed_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32]),
     "codetr_msda_pack_projection_index": (_i32, [_i32, _i32, _i32, _vp]),
     "codetr_mx_scale_bytes": (_i64, [_i64, _i64]),
@@ -655,18 +655,21 @@ def msda_pack_projection_index(M, L, P):
 
 
 def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_counts, region, threads, out,
-                        variant=0) -> bool:
-    """Round-5 encoder kernel: value [B,S,M,32] fp16; packed [B,S,>=64 M] fp16 (lane-major packed projection);
+                        variant=0, head_major=False) -> bool:
+    """Round-5 encoder kernel: value [B,S,M,32] fp16 ([B,M,S,32] with head_major); packed [B,S,>=64 M] fp16 (lane-major packed projection);
     valid_counts [B,L,2] fp32; windows [M][L][4]; region (w, h) in finest-level pixels; threads 256 | 512.  Returns
     False when the library reports the shape as unsupported, raises on any other error."""
     lib = load()
-    B, S, M, D = value.shape
+    if head_major:
+        B, M, S, D = value.shape
+    else:
+        B, S, M, D = value.shape
     L = len(level_shapes)
     shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
     rc = lib.codetr_msda_encoder_forward_packed_f16(
         current_stream_ptr(value.device), value.data_ptr(), shapes, packed.data_ptr(), packed.shape[-1],
         valid_counts.data_ptr(), B, S, M, D, L, num_points, _windows_array(windows, M, L), int(region[0]), int(region[1]),
-        int(threads), int(variant), out.data_ptr())
+        int(threads), int(variant), 1 if head_major else 0, out.data_ptr())
     if rc == E_UNSUPPORTED:
         return False
     check(rc, "codetr_msda_encoder_forward_packed_f16")

@@ -730,13 +730,18 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, reference_points
 
 # ---- round-5 encoder kernel (csrc/msda_encoder4.hip): lane-major packed projection, scalar geometry, zero border ----
 MSDA_V4 = True                 # route switch: False = the round-3/4 three-pass kernel on the unpacked projection
-MSDA_V4_THREADS = 256          # workgroup size (256: four workgroups per CU; 512: two)
-MSDA_V4_REGION = (16, 8)       # region of a workgroup, pixels of the finest level
-MSDA_V4_LDS_BUDGET = 40 * 1024   # bytes per workgroup
+# Measured on MI355X at 4 x 1920x1280, offsets with 0 / 2 / 4 / 8 px of spread (profiles/r05_msda_encoder4_sweep.txt):
+# 512 threads x 16x16 regions x 64 KiB = 918 / 973 / 1210 / 1637 us per launch; 256 x 16x8 x 40 KiB = 926 / 1019 / 1332 /
+# 1832; 80 KiB windows trade 3 % at 2 px for 5 % at 8 px (round-4 kernel: 1220 / 1318 / 1810 / 2566).
+MSDA_V4_THREADS = 512          # workgroup size (256: four workgroups per CU; 512: two)
+MSDA_V4_REGION = (16, 16)      # region of a workgroup, pixels of the finest level
+MSDA_V4_LDS_BUDGET = 64 * 1024   # bytes per workgroup
 MSDA_V4_MARGIN_CAP = 40.0      # pixels: windows grow up to this margin around a head's bias points within the LDS budget
-MSDA_V4_VARIANT = 0            # kernel build (include/codetr_hip.h): bit 0 fix-up prefetch, bit 1 three waves per SIMD
-_SWITCH_DEFAULTS.update({"MSDA_V4": True, "MSDA_V4_THREADS": 256, "MSDA_V4_REGION": (16, 8),
-                         "MSDA_V4_LDS_BUDGET": 40 * 1024, "MSDA_V4_MARGIN_CAP": 40.0, "MSDA_V4_VARIANT": 0})
+MSDA_V4_HEAD_MAJOR = True      # value projection writes [B, M, S, 32] for the packed encoder kernel
+MSDA_V4_VARIANT = 6            # kernel build (include/codetr_hip.h): 6 = rows one step ahead, preparation in front of each gather
+_SWITCH_DEFAULTS.update({"MSDA_V4": True, "MSDA_V4_THREADS": 512, "MSDA_V4_REGION": (16, 16),
+                         "MSDA_V4_LDS_BUDGET": 64 * 1024, "MSDA_V4_MARGIN_CAP": 40.0, "MSDA_V4_VARIANT": 6,
+                         "MSDA_V4_HEAD_MAJOR": True})
 
 
 def msda_encoder_packed_supported(dtype, head_dim, num_levels, num_points):
@@ -804,11 +809,15 @@ def msda_encoder_windows_packed(bias, level_shapes, num_heads, num_levels, num_p
     return out
 
 
-def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_counts):
-    """Encoder self-attention MSDA on the lane-major packed projection (round-5 kernel).  value [B,S,M,32] fp16, packed
-    [B,S,64 M] fp16, valid_counts [B,L,2] fp32.  Returns None when the library does not take the shape."""
+def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_counts, head_major=False):
+    """Encoder self-attention MSDA on the lane-major packed projection (round-5 kernel).  value [B,S,M,32] fp16 (or
+    [B,M,S,32] with head_major: what linear(..., head_major=32) returns), packed [B,S,64 M] fp16, valid_counts [B,L,2]
+    fp32.  Returns None when the library does not take the shape."""
     _gpu(value, "msda_encoder_packed")
-    B, S, M, D = value.shape
+    if head_major:
+        B, M, S, D = value.shape
+    else:
+        B, S, M, D = value.shape
     if not (valid_counts is not None and valid_counts.dtype == torch.float32 and valid_counts.is_contiguous()
             and valid_counts.shape == (B, len(level_shapes), 2) and packed.shape[:2] == (B, S) and packed.is_contiguous()):
         return None
@@ -817,7 +826,7 @@ def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_
 
     def run():
         ok[0] = _cabi.msda_encoder_packed(value.contiguous(), level_shapes, packed, num_points, windows, valid_counts,
-                                          MSDA_V4_REGION, MSDA_V4_THREADS, out, MSDA_V4_VARIANT)
+                                          MSDA_V4_REGION, MSDA_V4_THREADS, out, MSDA_V4_VARIANT, head_major)
 
     with torch.cuda.device(value.device):
         _timed("msda_fused", {"B": B, "S": S, "Nq": S, "M": M, "D": D, "L": len(level_shapes), "P": num_points},

@@ -152,6 +152,28 @@ class MultiScaleDeformableAttention(nn.Module):
             out = hip_ops.msda_fused(v, spatial_shapes, level_start_index, proj, 0, H * L * P * 2, reference_points,
                                      L, P, head_major=True)
             return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
+        host_shapes = getattr(spatial_shapes, "_codetr_host", None)
+        counts = getattr(reference_points, "_codetr_valid_counts", None)
+        if (query.is_cuda and value_projected is None and host_shapes is not None and Nq == S and counts is not None
+                and reference_points.shape[-1] == 2 and hip_ops.MSDA_FP32_REF
+                and hip_ops.msda_encoder_packed_supported(value.dtype, hd, L, P)):
+            # encoder self-attention, round-5 kernel (csrc/msda_encoder4.hip).  Both producers are our own GEMMs, so both
+            # layouts are the gather kernel's choice: the value projection writes the HEAD-MAJOR map [B, M, S, 32] (a staged
+            # window row is one contiguous run), the (offsets | logits) projection the lane-major packed rows (its weight
+            # rows permuted once; two 16-byte loads per lane).  Padding mask folded into the value GEMM (reference :173-176).
+            hm = hip_ops.MSDA_V4_HEAD_MAJOR and self.value_proj.in_features % 64 == 0
+            v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask,
+                               head_major=hd if hm else None)
+            if not hm:
+                v = v.view(B, S, H, -1)
+            Wp, bp = self._packed_projection()
+            packed = (hip_ops.linear_xadd(query, pos_in_gemm, Wp, bp) if pos_in_gemm is not None
+                      else hip_ops.linear(query, Wp, bp))
+            out = hip_ops.msda_encoder_packed(v, host_shapes, packed, P, self._encoder_windows_packed(host_shapes), counts, hm)
+            if out is not None:
+                return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
+            if hm:
+                value_projected = v.permute(0, 2, 1, 3).reshape(B, S, -1)   # (declined shape: the general kernel's layout)
         # value projection with the padding mask folded into the GEMM epilogue (reference :173-176)
         if value_projected is not None:
             v = value_projected
@@ -159,18 +181,6 @@ class MultiScaleDeformableAttention(nn.Module):
             v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask)
         v = v.view(B, S, H, -1)
         if query.is_cuda and hip_ops.msda_fused_supported(v.dtype, v.shape[-1], L, P):
-            host_shapes = getattr(spatial_shapes, "_codetr_host", None)
-            counts = getattr(reference_points, "_codetr_valid_counts", None)
-            if (host_shapes is not None and Nq == S and reference_points.shape[-1] == 2 and counts is not None
-                    and hip_ops.MSDA_FP32_REF and hip_ops.msda_encoder_packed_supported(v.dtype, v.shape[-1], L, P)):
-                # encoder self-attention, round-5 kernel: the projection GEMM writes the lane-major packed layout (its
-                # weight rows permuted once), the gather kernel reads it with two 16-byte loads per lane
-                Wp, bp = self._packed_projection()
-                packed = (hip_ops.linear_xadd(query, pos_in_gemm, Wp, bp) if pos_in_gemm is not None
-                          else hip_ops.linear(query, Wp, bp))
-                out = hip_ops.msda_encoder_packed(v, host_shapes, packed, P, self._encoder_windows_packed(host_shapes), counts)
-                if out is not None:
-                    return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
             # one GEMM for (offsets | logits); softmax and location arithmetic happen inside the MSDA kernel
             Wc, bc = self._fused_projection()
             proj = hip_ops.linear_xadd(query, pos_in_gemm, Wc, bc) if pos_in_gemm is not None else hip_ops.linear(query, Wc, bc)

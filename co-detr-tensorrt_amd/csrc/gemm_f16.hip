@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
             v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[it][e]));
         }
         size_t off = (size_t)m * N + n;
-        if (hm_hd > 0) {  // column-block-major destination y[b][n / hm_hd][position][n % hm_hd] (hm_hd % 64 == 0 here)
+        if (hm_hd > 0) {  // column-block-major destination y[b][n / hm_hd][position][n % hm_hd] (hm_hd % 8 == 0: a lane's 8-column chunk lies inside one block)
           const int bb = m / hm_rows, pos = m - bb * hm_rows;
           const int head = n / hm_hd, ch = n - head * hm_hd;
           off = (((size_t)bb * (N / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
 // than the tiled kernel (2 workgroups per CU, 48 MFMAs per barrier) and stays there.
 bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
   // (K = 64: the patch-embedding GEMM of the Swin stem, act 0 / no residual only)
-  return (K == 192 || K == 256 || K == 64) && N % 8 == 0 && N >= 128 && N <= 1536 && M >= 128 * 256 && hm_hd % 64 == 0;
+  return (K == 192 || K == 256 || K == 64) && N % 8 == 0 && N >= 128 && N <= 1536 && M >= 128 * 256 && hm_hd % 8 == 0;
 }
 
 template <class T, int KS, int ACT>

@@ -60,6 +60,7 @@ struct Geom4 {
   signed char win[kMaxM][kL][4];       // per (head, level): offsets (pixels of that level) in [x lo, x hi] x [y lo, y hi] are staged
   const float* vcounts;                // [B][L][2] valid pixels (w, h) of every level, fp32
   unsigned queue_off;                  // LDS byte offset of the fix-up queues (behind the largest pass)
+  int head_major;                      // value map [B][M][S][32] (a head's rows contiguous) instead of [B][S][M][32]
 };
 
 // ---- region geometry along one axis (n pixels, R regions): pixel x belongs to region r iff (x + 0.5) / n in [r / R, (r + 1) / R)
@@ -148,6 +149,12 @@ __device__ __forceinline__ void acc_h2(float& lo, float& hi, h2 h) {
   const unsigned u = __builtin_bit_cast(unsigned, h);
   asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(u));
   asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi) : "v"(u));
+}
+// one LDS-DMA piece: 16 B per lane from (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset) to the
+// wave-uniform LDS address `lds_addr` + lane * 16 (M0 is written in the statement that reads it)
+__device__ __forceinline__ void lds_dma16(const unsigned char* src, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds_addr)
+               : "memory", "m0");
 }
 __device__ __forceinline__ int floor_i(float v) {   // floor + float -> int in one instruction
   int d;
@@ -252,9 +259,18 @@ __device__ __forceinline__ void gather(float (&acc)[8], const Prep (&pp)[NLV], c
   constexpr int NS = 4 * NLV, NB = DEPTH + 1;
   f16x8 rows[NB][4];
   unsigned wA[NB], wB[NB];
+  // DPP hazard: a VGPR written by a vector instruction may be read by a DPP instruction only two wait states later.  The
+  // compiler inserts them for its own DPP forms but cannot see inside quad_bcast_add's inline assembly, and the addresses
+  // may have been written by the instruction right before (preparation directly in front of the gather: measured wrong
+  // results without this).  One s_nop per gather, tied to the address registers so that nothing moves across it.
+  unsigned adr[NLV];
+#pragma unroll
+  for (int i = 0; i < NLV; ++i) adr[i] = pp[i].ad;
+  if (NLV == 1) asm volatile("s_nop 1" : "+v"(adr[0]));
+  else asm volatile("s_nop 1" : "+v"(adr[0]), "+v"(adr[NLV - 1]));
   auto fetch = [&](int s_, int buf) {
     const int o = s_ & 3, i = s_ >> 2;
-    const unsigned a0 = quad_bcast_add(pp[i].ad, o, lds_lane);
+    const unsigned a0 = quad_bcast_add(adr[i], o, lds_lane);
     const unsigned a1 = a0 + lv[LV0 + i].pitch;
     wA[buf] = quad_bcast_u(pp[i].w01, o);
     wB[buf] = quad_bcast_u(pp[i].w23, o);
@@ -414,7 +430,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
   const int tid = threadIdx.x;
   const int wave = uni(tid >> 6), lane = tid & 63, sub = lane & 3, pl = lane >> 2;
   const int M = g.M;
-  const unsigned pix_bytes = (unsigned)M * kRow;
+  // one pixel of one head = 64 bytes; consecutive pixels of a head are 64 B apart in the head-major map (a staged window
+  // row is ONE contiguous run: a DMA instruction reads 8 whole 128-byte lines), M * 64 B apart in the op's own layout
+  // (16 half lines per DMA instruction)
+  const unsigned pix_bytes = g.head_major ? kRow : (unsigned)M * kRow;
 
   // ---- wave-uniform geometry -> scalar registers ----
   const TileId t0 = decode_tile(xcd_tile(blockIdx.x, gridDim.x), g);
@@ -481,7 +500,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
   }
   const int n_it = total > wave * 16 ? (total - wave * 16 + kPairs - 1) / kPairs : 0;   // <= kMaxIt (host-checked)
 
-  const unsigned char* vhead = reinterpret_cast<const unsigned char*>(value) + ((size_t)t.b * g.S * M + t.m) * kRow + sub * 16;
+  const unsigned char* vhead0 = reinterpret_cast<const unsigned char*>(value) +
+                                (g.head_major ? ((size_t)t.b * M + t.m) * g.S : (size_t)t.b * g.S * M + t.m) * kRow;   // (uniform)
+  const unsigned char* vhead = vhead0 + sub * 16;
   const unsigned char* prow = reinterpret_cast<const unsigned char*>(packed) + (size_t)t.b * g.S * packed_stride * 2 +
                               (t.m * 64 + sub * 16) * 2;
 
@@ -570,25 +591,32 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
   auto run_pass = [&](auto lv0_c, auto nlv_c) {
     constexpr int LV0 = decltype(lv0_c)::value, NLV = decltype(nlv_c)::value;
     if (LV0 > 0 && !(kAbl & 16)) __syncthreads();   // every wave is done reading the previous pass's rows
-    // -- the pass's windows -> LDS (LDS-DMA, 16 B per lane; cells outside the image are the zero border) --
+    // -- the pass's windows -> LDS, ROW-WISE: a wave takes window rows y = wave, wave + kWaves, ...; one LDS-DMA instruction
+    // moves 16 pixels of the row (4 lanes x 16 B per pixel = its 64-byte head slice) from a wave-uniform 64-bit base in
+    // SGPRs + a per-lane constant offset to the uniform LDS address of the row's chunk (+ 16 B per lane): no per-lane row /
+    // column arithmetic (the piece-linear walk of rounds 2-4 spent ~14 vector instructions per DMA on a division).  Cells
+    // outside the image -- the zero border -- are written by ds_write instead.
 #pragma unroll
     for (int i = 0; i < NLV; ++i) {
       const Lv& v = lv[LV0 + i];
-      const int n = v.pw * v.ph * 4;   // 16-byte pieces
-      const float inv = __builtin_amdgcn_rcpf((float)v.pw);
-      for (int e0 = wave * 64; e0 < ((kAbl & 2) ? 0 : n); e0 += T) {
-        const int e = e0 + lane;
-        const int row = e >> 2;
-        const int y = (int)(((float)row + 0.5f) * inv);
-        const int gx = v.px0 + (row - y * v.pw), gy = v.py0 + y;
-        const bool inside = (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H;
-        if (e < n) {
-          if (inside) {
-            const unsigned char* gp = vhead + (size_t)((unsigned)(v.start + gy * v.W + gx) * pix_bytes);   // (e & 3 == sub: e0 % 64 == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(smem + (v.base - lds0) + (size_t)e0 * 16), 16, 0, 0);
-          } else {
-            *reinterpret_cast<u32x4*>(smem + (v.base - lds0) + (size_t)e * 16) = u32x4{0u, 0u, 0u, 0u};
+      const int px_l = lane >> 2;                                      // pixel of the chunk this lane serves
+      const unsigned voff = (unsigned)px_l * pix_bytes + (unsigned)sub * 16;
+      const int chunks = (v.pw + 15) >> 4;
+      for (int y = wave; y < ((kAbl & 2) ? 0 : v.ph); y += kWaves) {
+        const int gy = v.py0 + y;
+        const bool row_in = (unsigned)gy < (unsigned)v.H;              // (uniform)
+        for (int c = 0; c < chunks; ++c) {
+          const int x0 = 16 * c;                                       // window column of lane 0's pixel
+          const unsigned dst = (v.base - lds0) + (unsigned)(y * v.pw + x0) * kRow;
+          const int gx = v.px0 + x0 + px_l;
+          const bool mine = x0 + px_l < v.pw;
+          const bool col_in = (unsigned)gx < (unsigned)v.W;
+          if (row_in) {
+            if (mine && col_in)
+              lds_dma16(vhead0 + (ptrdiff_t)(v.start + gy * v.W + v.px0 + x0) * (ptrdiff_t)pix_bytes, voff, lds0 + dst);
+            if (mine && !col_in) *reinterpret_cast<u32x4*>(smem + dst + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+          } else if (mine) {
+            *reinterpret_cast<u32x4*>(smem + dst + lane * 16) = u32x4{0u, 0u, 0u, 0u};
           }
         }
       }
@@ -637,7 +665,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
       f16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (_Float16)acc[it][j];
-      *reinterpret_cast<f16x8*>(orow + (size_t)((unsigned)qs[it] * pix_bytes)) = o;
+      *reinterpret_cast<f16x8*>(orow + (size_t)((unsigned)qs[it] * ((unsigned)M * kRow))) = o;   // out is [B, S, M, 32] in either case
     }
 }
 
@@ -726,7 +754,7 @@ inline Plan4 plan4(const int64_t* shapes, int64_t S, int M, int L, int P, const 
 
 int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void* packed, int64_t packed_stride,
             const float* vcounts, int64_t B, int64_t S, int M, int D, int L, int P, const signed char* win, int region_w,
-            int region_h, int threads, int variant, void* out) {
+            int region_h, int threads, int variant, int head_major, void* out) {
   if (!value || !shapes || !packed || !vcounts || !win || !out) return CODETR_E_BADARG;
   if (B <= 0 || S <= 0 || M <= 0 || L <= 0 || P <= 0) return CODETR_E_BADARG;
   if (D != 32) return CODETR_E_UNSUPPORTED;
@@ -740,6 +768,7 @@ int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void
   const int64_t blocks = B * pl.g.RX * pl.g.RY * M;
   if (blocks >= (1 << 22)) return CODETR_E_UNSUPPORTED;
   pl.g.vcounts = vcounts;
+  pl.g.head_major = head_major ? 1 : 0;
   typedef void (*Kern)(const _Float16*, const _Float16*, _Float16*, const Geom4, const int);
   // variant = kernel build (same results): 0 the default -- four waves per SIMD, rows one step ahead, preparation under the
   // DMA; 1: rows two steps ahead, preparation right before each gather; 2: three waves per SIMD (168 registers: three
@@ -780,11 +809,12 @@ extern "C" {
 int codetr_msda_encoder_forward_packed_f16(void* stream, const void* value_dev, const int64_t* level_shapes_host,
                                            const void* packed_dev, int64_t packed_row_stride, const float* valid_counts_dev,
                                            int64_t B, int64_t S, int M, int D, int L, int P, const int8_t* windows_host,
-                                           int region_w, int region_h, int threads, int variant, void* out_dev) {
+                                           int region_w, int region_h, int threads, int variant, int value_head_major,
+                                           void* out_dev) {
   if (variant < 0 || variant > 7) return CODETR_E_BADARG;
   return launch4(static_cast<hipStream_t>(stream), value_dev, level_shapes_host, packed_dev, packed_row_stride,
                  valid_counts_dev, B, S, M, D, L, P, reinterpret_cast<const signed char*>(windows_host), region_w, region_h,
-                 threads, variant, out_dev);
+                 threads, variant, value_head_major, out_dev);
 }
 
 int64_t codetr_msda_encoder_packed_lds_bytes(const int64_t* level_shapes_host, int M, int L, int P, const int8_t* windows_host,

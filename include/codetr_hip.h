@@ -211,6 +211,8 @@ int64_t codetr_msda_encoder_lds_bytes(const int64_t *level_shapes_host, int M, i
  *                     window on a coarse level keeps the whole level resident.
  *   region_w/region_h region of a workgroup in pixels of the finest level; threads: 256 | 512 per workgroup.  A region may
  *                     hold at most 3 * threads / 4 queries (CODETR_E_UNSUPPORTED otherwise).
+ *   value_head_major  0: value_dev is the op's [B, S, M, D]; 1: [B, M, S, D] (each head's map contiguous, what
+ *                     codetr_linear_* writes with hm_head_dim = D): a staged window row is then one contiguous run.
  *   variant           kernel build, same results: bit 0 = the first fix-up round's rows are requested before the gather
  *                     loop of their iteration; bit 1 (256 threads only) = three waves per SIMD (168 registers; meant for
  *                     three workgroups of <= 53 KiB per CU instead of four of <= 40 KiB).
@@ -223,7 +225,7 @@ int codetr_msda_encoder_forward_packed_f16(void *stream, const void *value_dev, 
                                            const void *packed_dev, int64_t packed_row_stride,
                                            const float *valid_counts_dev, int64_t B, int64_t S, int M, int D, int L, int P,
                                            const int8_t *windows_host, int region_w, int region_h, int threads,
-                                           int variant, void *out_dev);
+                                           int variant, int value_head_major, void *out_dev);
 int64_t codetr_msda_encoder_packed_lds_bytes(const int64_t *level_shapes_host, int M, int L, int P,
                                              const int8_t *windows_host, int region_w, int region_h, int threads);
 int codetr_msda_pack_projection_index(int M, int L, int P, int32_t *idx_host);

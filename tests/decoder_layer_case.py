@@ -61,9 +61,17 @@ def state_dict(dec, reg):
 def memory_and_masks(seed=SEED):
     """memory [1, S, 256] (fp16-representable), padding mask [1, S] (the last 10 % of rows and columns of every level),
     valid ratios [1, L, 2] fp32, level shapes / start indices"""
-    S = sum(h * w for h, w in SHAPES)
     g = torch.Generator().manual_seed(seed + 2)
-    memory = torch.randn(1, S, C, generator=g).half().float()
+    # a SMOOTH random field per level (a coarse grid of 1/8 the resolution, bilinearly upsampled, + 5 % white noise), like a
+    # feature map: with white-noise memory a sampling position that moves by the fp16 rounding of an offset (0.2-0.5 pixel
+    # for boxes that span the image) changes the sampled value by O(1), and the comparison measures that instead of the kernel
+    levels = []
+    for h, w in SHAPES:
+        coarse = torch.randn(1, C, h // 8 + 2, w // 8 + 2, generator=g)
+        fine = torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=True)
+        fine = fine + 0.05 * torch.randn(1, C, h, w, generator=g)
+        levels.append(fine.flatten(2).transpose(1, 2))
+    memory = torch.cat(levels, 1).contiguous().half().float()
     masks, vr = [], []
     for h, w in SHAPES:
         vh, vw = int(round(0.9 * h)), int(round(0.9 * w))

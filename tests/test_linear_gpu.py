@@ -140,6 +140,24 @@ def test_linear_head_major_output():
     assert torch.equal(y_hm, y_rm.view(B, S, Hh, hd).permute(0, 2, 1, 3))
 
 
+def test_linear_head_major_output_large_short_k():
+    """the same at the encoder's value-projection shape class (>= 32 k rows, K = 256: the X-stationary kernel, which since
+    round 5 writes 32-wide column blocks -- the encoder MSDA's head-major value map [B, M, S, 32]) incl. a row mask"""
+    from codetr import _cabi, hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, S, K, Hh, hd = 2, 20000, 256, 8, 32
+    x = torch.randn(B, S, K, device=DEV, generator=g).half()
+    w = (torch.randn(Hh * hd, K, device=DEV, generator=g) / 16).half()
+    b = torch.randn(Hh * hd, device=DEV, generator=g).half()
+    mask = torch.rand(B, S, device=DEV, generator=g) < 0.2
+    assert _cabi.linear_variant(B * S, Hh * hd, K, None, False, hd) == "xs"
+    y_rm = hip_ops.linear(x, w, b, row_mask=mask)
+    y_hm = hip_ops.linear(x, w, b, row_mask=mask, head_major=hd)
+    assert y_hm.shape == (B, Hh, S, hd)
+    assert torch.equal(y_hm, y_rm.view(B, S, Hh, hd).permute(0, 2, 1, 3))
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,bias,act,res", [
     (600, 256, 13824, False, None, False),   # the neck's extra 3x3/s2 level over unfolded patches (1920x1280 input)

@@ -82,15 +82,18 @@ def _expect(value, off, logits, counts, shapes, rows=None):
                                           loc.numpy(), w.numpy())
 
 
-def _run(shapes, value, off, logits, counts, cfg, windows):
+def _run(shapes, value, off, logits, counts, cfg, windows, variant=0, head_major=False):
     from codetr import _cabi
 
     threads, region, _ = CFGS[cfg]
     B, S = off.shape[:2]
     out = torch.full((B, S, M * D), float("nan"), dtype=torch.float16, device=DEV)
     before = _cabi.CALLS["msda_encoder_packed"]
-    ok = _cabi.msda_encoder_packed(value.to(DEV), shapes, _pack(off, logits).to(DEV), P, windows, counts.to(DEV), region,
-                                   threads, out)
+    v = value.to(DEV)
+    if head_major:
+        v = v.permute(0, 2, 1, 3).contiguous()
+    ok = _cabi.msda_encoder_packed(v, shapes, _pack(off, logits).to(DEV), P, windows, counts.to(DEV), region, threads, out,
+                                   variant, head_major)
     torch.cuda.synchronize()
     assert ok and _cabi.CALLS["msda_encoder_packed"] == before + 1, "the packed encoder kernel did not take the shape"
     return out.float().cpu().numpy()
@@ -140,6 +143,19 @@ def test_windows_change_speed_not_results(cfg):
             "mixed": [[(-1, 1, -1, 1), (-9, 9, -9, 9), (0, 0, 0, 0), (-127, 127, -127, 127), (-2, 30, -30, 2)]] * M}
     for name, w in wins.items():
         _check(_run(PYR_ODD, value, off, logits, counts, cfg, w), expect, name)
+
+
+@pytest.mark.parametrize("variant", range(8))
+@pytest.mark.parametrize("head_major", [False, True], ids=["op_layout", "head_major"])
+def test_every_kernel_build_and_both_value_layouts(variant, head_major):
+    """the eight builds behind `variant` (rows one / two / three steps ahead, preparation under the DMA or in front of each
+    gather, three waves per SIMD, fix-up prefetch) and the head-major value map: same results; offsets partly beyond the
+    windows so that the fix-up path runs in every build"""
+    value, off, logits, counts, S = _inputs(PYR_ODD, 2, 3.0, seed=300 + variant)
+    expect = _expect(value, off, logits, counts, PYR_ODD)
+    for cfg in CFGS:
+        _check(_run(PYR_ODD, value, off, logits, counts, cfg, _halo(3), variant, head_major), expect,
+               f"{cfg} variant {variant} head_major {head_major}")
 
 
 def test_non_finite_offsets_drop_the_sample_like_the_reference_gate():

@@ -22,11 +22,12 @@ def main():
     ap.add_argument("--passes", type=int, default=3, help="3: three-pass kernel, 1: single pass")
     ap.add_argument("--counts", type=int, default=0, help="1: reference points computed in fp32 from valid counts")
     ap.add_argument("--v4", type=int, default=0, help="1: the round-5 packed kernel (codetr_msda_encoder_forward_packed_f16)")
-    ap.add_argument("--threads", type=int, default=256)
-    ap.add_argument("--region", default="16x8")
+    ap.add_argument("--threads", type=int, default=512)
+    ap.add_argument("--region", default="16x16")
     ap.add_argument("--budget", type=int, default=0, help="LDS bytes per workgroup (default 40 KiB x 256 / threads ... see code)")
     ap.add_argument("--cap", type=float, default=40.0, help="largest window margin in pixels")
-    ap.add_argument("--variant", type=int, default=0, help="v4 kernel build: bit 0 fix-up prefetch, bit 1 three waves per SIMD")
+    ap.add_argument("--hm", type=int, default=1, help="1: head-major value map [B, M, S, D]")
+    ap.add_argument("--variant", type=int, default=6, help="v4 kernel build: bit 0 fix-up prefetch, bit 1 three waves per SIMD")
     a = ap.parse_args()
     from codetr import _cabi, hip_ops
 
@@ -73,7 +74,7 @@ def main():
     if a.v4:
         hip_ops.MSDA_V4_THREADS = a.threads
         hip_ops.MSDA_V4_REGION = tuple(int(v) for v in a.region.split("x"))
-        hip_ops.MSDA_V4_LDS_BUDGET = a.budget if a.budget else (40 * 1024 if a.threads == 256 else 80 * 1024)
+        hip_ops.MSDA_V4_LDS_BUDGET = a.budget if a.budget else (40 * 1024 if a.threads == 256 else 64 * 1024)
         hip_ops.MSDA_V4_MARGIN_CAP = a.cap
         hip_ops.MSDA_V4_VARIANT = a.variant
         idx = torch.tensor(_cabi.msda_pack_projection_index(M, L, P), device=dev)
@@ -81,7 +82,8 @@ def main():
         packed[..., idx < 0] = 0
         packed = packed.contiguous()
         win = hip_ops.msda_encoder_windows_packed(bias.reshape(-1), shapes, M, L, P)
-        enc = lambda: hip_ops.msda_encoder_packed(value, shapes, packed, P, win, counts)  # noqa: E731
+        vhm = value.permute(0, 2, 1, 3).contiguous() if a.hm else None
+        enc = lambda: hip_ops.msda_encoder_packed(vhm if a.hm else value, shapes, packed, P, win, counts, bool(a.hm))  # noqa: E731
         print("v4 windows head 0/1:", win[0], win[1], "lds",
               _cabi.msda_encoder_packed_lds_bytes(shapes, M, P, win, hip_ops.MSDA_V4_REGION, a.threads))
     elif win is not None:
@@ -96,7 +98,7 @@ def main():
     print(f"batch {B} noise {a.noise} halo {hip_ops.MSDA_HALO}: encoder kernel {t_enc:8.1f} us "
           f"({alg / t_enc / 1e6:6.2f} TB/s algorithmic)   general fused {t_gen:8.1f} us   identical: {same} "
           f"rel L2 vs general {rel:.2e}  windows {'bias' if a.windows else 'halo'} passes {a.passes} counts {a.counts}"
-          + (f"  v4 threads {a.threads} region {a.region} cap {a.cap} variant {a.variant} budget {hip_ops.MSDA_V4_LDS_BUDGET}" if a.v4 else ""))
+          + (f"  v4 threads {a.threads} region {a.region} cap {a.cap} variant {a.variant} hm {a.hm} budget {hip_ops.MSDA_V4_LDS_BUDGET}" if a.v4 else ""))
 
 
 if __name__ == "__main__":
