@@ -223,7 +223,7 @@ def msda_roofline(B, H, W, dtype, device, iters=30):
     nbytes = msda_algorithmic_bytes(B, S, S, e=value.element_size())
     achieved = nbytes / avg_s / 1e9
     return {
-        "kernel": "msda_tiled_kernel<F16,4> (encoder call, Nq=S=%d, batch %d)" % (S, B),
+        "kernel": "msda_tiled_kernel<%s,4> (encoder call, Nq=S=%d, batch %d)" % ("BF16" if dtype == torch.bfloat16 else "F16", S, B),
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
         "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg_s * 1e6, 1),
@@ -294,7 +294,8 @@ def kernel_rooflines(model, images, masks, device):
     pl = pmc.get("linear_kernel", {})
     traffic = pl["hbm_bytes_per_forward"] / len(prof) if "hbm_bytes_per_forward" in pl else pl.get("hbm_bytes_per_launch")
     out["roofline"] = {
-        "kernel": "linear_kernel / linear_256_kernel / linear_xs_kernel <f16> (all %d launches of one forward)" % len(prof),
+        "kernel": "linear_sk_kernel / linear_kernel / linear_256_kernel / linear_xs_kernel (16-bit operands of the run's "
+                  "dtype, fp32 accumulation; all %d launches of one forward)" % len(prof),
         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic,
@@ -874,7 +875,7 @@ def main():
                     torch.cuda.synchronize(device)
                     by_size["%dx%d" % (rw, rh)] = {"error": repr(e)}
             out["latency_batch1_by_size"] = by_size
-            if dtype == torch.float16:   # (fp16 and fp8 runs)
+            if dtype in (torch.float16, torch.bfloat16):   # (fp16, fp8 and bf16 runs: every kernel has both 16-bit forms)
                 nb = max(1, a.batch // max(1, nstreams))
                 xi, xm = images[:nb].contiguous(), masks[:nb].contiguous()
                 out.update(kernel_rooflines(model, xi, xm, device))

@@ -51,6 +51,9 @@ SIGNATURES = {
     "codetr_msda_encoder_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32]),
     "codetr_msda_encoder_forward_packed_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
                                                       _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "codetr_msda_encoder_forward_packed_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
+                                                       _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "codetr_linear_bf16_f16out": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32]),
     "codetr_msda_encoder_packed_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32]),
     "codetr_msda_pack_projection_index": (_i32, [_i32, _i32, _i32, _vp]),
     "codetr_mx_scale_bytes": (_i64, [_i64, _i64]),
@@ -112,6 +115,7 @@ SIGNATURES = {
     "codetr_decoder_layer_supported": (_i32, [_i32] * 7),
     "codetr_decoder_layer_blob_halfs": (_i64, [_i32] * 4),
     "codetr_decoder_layer_f16": (_i32, [_vp] * 18 + [_i64, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, ctypes.c_float]),
+    "codetr_decoder_layer_bf16": (_i32, [_vp] * 18 + [_i64, _i64, _i64, _i32, _i32, _i32, ctypes.c_float, ctypes.c_float]),
     "codetr_layernorm_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_float]),
     "codetr_groupnorm_tokens_workspace_bytes": (_i64, [_i64, _i64, _i64]),
@@ -635,6 +639,24 @@ def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points,
     return True
 
 
+def linear_bf16_f16out(x2d, weight, bias, out2d, row_mask=None, hm_rows=0, hm_head_dim=0) -> bool:
+    """bf16 x [M,K] @ bf16 w [N,K]^T (+ bias) -> FP16 out [M,N] (row mask / head-major destination as `linear`): the value
+    projection of a bf16 model in front of the packed encoder MSDA kernel.  False when the library has no kernel for the
+    shape (the X-stationary kernel's: K in {192, 256}, >= 32 768 rows)."""
+    M, K = x2d.shape
+    N = weight.shape[0]
+    rc = load().codetr_linear_bf16_f16out(current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(),
+                                          bias.data_ptr() if bias is not None else None,
+                                          row_mask.data_ptr() if row_mask is not None else None, out2d.data_ptr(), M, N, K,
+                                          hm_rows, hm_head_dim)
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "codetr_linear_bf16_f16out")
+    CALLS["linear"] += 1
+    CALLS["linear_xs"] += 1
+    return True
+
+
 def msda_encoder_packed_lds_bytes(level_shapes, M, num_points, windows, region, threads) -> int:
     """LDS bytes per workgroup of codetr_msda_encoder_forward_packed_f16 (negative: CODETR_E_* code)"""
     L = len(level_shapes)
@@ -666,7 +688,9 @@ def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_
         B, S, M, D = value.shape
     L = len(level_shapes)
     shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
-    rc = lib.codetr_msda_encoder_forward_packed_f16(
+    fn = (lib.codetr_msda_encoder_forward_packed_bf16 if packed.dtype == torch.bfloat16
+          else lib.codetr_msda_encoder_forward_packed_f16)   # (bf16: packed / out bf16, the value map fp16 -- see the header)
+    rc = fn(
         current_stream_ptr(value.device), value.data_ptr(), shapes, packed.data_ptr(), packed.shape[-1],
         valid_counts.data_ptr(), B, S, M, D, L, num_points, _windows_array(windows, M, L), int(region[0]), int(region[1]),
         int(threads), int(variant), 1 if head_major else 0, out.data_ptr())
@@ -708,14 +732,14 @@ def decoder_layer_blob_halfs(which, num_levels, num_points, hidden) -> int:
 
 def decoder_layer(x, attn, qpos, ref, vr32, value, shapes, starts, tail_w, pos_w, head_w, final_norm, x_out, ref_out,
                   qpos_out, qk_out, v_out, B, Nq, S, L, P, hidden, eps, temperature):
-    """one launch of codetr_decoder_layer_f16 (include/codetr_hip.h); tensors or None, see the header for the roles"""
+    """one launch of codetr_decoder_layer_{f16,bf16} (include/codetr_hip.h); tensors or None, see the header for the roles"""
     CALLS["decoder_layer"] += 1
     p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-    rc = load().codetr_decoder_layer_f16(current_stream_ptr(x.device), p(x), p(attn), p(qpos), p(ref), p(vr32), p(value),
-                                         p(shapes), p(starts), p(tail_w), p(pos_w), p(head_w), p(final_norm), p(x_out),
-                                         p(ref_out), p(qpos_out), p(qk_out), p(v_out), B, Nq, S, L, P, hidden, float(eps),
-                                         float(temperature))
-    check(rc, "codetr_decoder_layer_f16")
+    fn = load().codetr_decoder_layer_bf16 if x.dtype == torch.bfloat16 else load().codetr_decoder_layer_f16
+    rc = fn(current_stream_ptr(x.device), p(x), p(attn), p(qpos), p(ref), p(vr32), p(value),
+            p(shapes), p(starts), p(tail_w), p(pos_w), p(head_w), p(final_norm), p(x_out),
+            p(ref_out), p(qpos_out), p(qk_out), p(v_out), B, Nq, S, L, P, hidden, float(eps), float(temperature))
+    check(rc, "codetr_decoder_layer")
 
 
 def linear_xadd_supported(M, N, K, dtype) -> bool:

@@ -745,7 +745,31 @@ _SWITCH_DEFAULTS.update({"MSDA_V4": True, "MSDA_V4_THREADS": 512, "MSDA_V4_REGIO
 
 
 def msda_encoder_packed_supported(dtype, head_dim, num_levels, num_points):
-    return MSDA_V4 and MSDA_ENCODER and dtype == torch.float16 and head_dim == 32 and num_levels == 5 and num_points == 4
+    return (MSDA_V4 and MSDA_ENCODER and dtype in (torch.float16, torch.bfloat16) and head_dim == 32 and num_levels == 5
+            and num_points == 4)
+
+
+def value_projection_f16(x, weight, bias, row_mask, head_dim):
+    """bf16 model: the encoder MSDA's value projection with an FP16, head-major result [B, M, S, head_dim] (the packed
+    kernel's value map is fp16 whatever the model's type).  None when the library has no kernel for the shape."""
+    _gpu(x, "value_projection_f16")
+    if not (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 3):
+        return None
+    B, S, K = x.shape
+    N = weight.shape[0]
+    x2 = x.reshape(-1, K)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    mk = None
+    if row_mask is not None:
+        mk = row_mask.reshape(-1)
+        if mk.dtype != torch.bool and mk.dtype != torch.uint8:
+            mk = mk != 0
+        mk = mk.contiguous()
+    out = torch.empty((B * S, N), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        ok = _cabi.linear_bf16_f16out(x2, w, bias, out, mk, S, int(head_dim))
+    return out.view(B, N // head_dim, S, head_dim) if ok else None
 
 
 def msda_packed_projection(w_off, b_off, w_aw, b_aw, num_heads, num_levels, num_points):
@@ -821,7 +845,9 @@ def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_
     if not (valid_counts is not None and valid_counts.dtype == torch.float32 and valid_counts.is_contiguous()
             and valid_counts.shape == (B, len(level_shapes), 2) and packed.shape[:2] == (B, S) and packed.is_contiguous()):
         return None
-    out = torch.empty((B, S, M * D), dtype=value.dtype, device=value.device)
+    if value.dtype != torch.float16 or packed.dtype not in (torch.float16, torch.bfloat16):
+        return None
+    out = torch.empty((B, S, M * D), dtype=packed.dtype, device=value.device)
     ok = [True]
 
     def run():

@@ -162,17 +162,25 @@ class MultiScaleDeformableAttention(nn.Module):
             # window row is one contiguous run), the (offsets | logits) projection the lane-major packed rows (its weight
             # rows permuted once; two 16-byte loads per lane).  Padding mask folded into the value GEMM (reference :173-176).
             hm = hip_ops.MSDA_V4_HEAD_MAJOR and self.value_proj.in_features % 64 == 0
-            v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask,
-                               head_major=hd if hm else None)
-            if not hm:
-                v = v.view(B, S, H, -1)
-            Wp, bp = self._packed_projection()
-            packed = (hip_ops.linear_xadd(query, pos_in_gemm, Wp, bp) if pos_in_gemm is not None
-                      else hip_ops.linear(query, Wp, bp))
-            out = hip_ops.msda_encoder_packed(v, host_shapes, packed, P, self._encoder_windows_packed(host_shapes), counts, hm)
+            if value.dtype == torch.bfloat16:
+                # bf16 model: the kernel's value map is FP16 (packed-half blend; the projection's fp32 accumulators keep
+                # three more mantissa bits than a bf16 store), head-major; offsets / logits / output stay bf16
+                v = hip_ops.value_projection_f16(value, self.value_proj.weight, self.value_proj.bias, key_padding_mask, hd)
+                hm = True
+            else:
+                v = hip_ops.linear(value, self.value_proj.weight, self.value_proj.bias, row_mask=key_padding_mask,
+                                   head_major=hd if hm else None)
+                if not hm:
+                    v = v.view(B, S, H, -1)
+            out = None
+            if v is not None:
+                Wp, bp = self._packed_projection()
+                packed = (hip_ops.linear_xadd(query, pos_in_gemm, Wp, bp) if pos_in_gemm is not None
+                          else hip_ops.linear(query, Wp, bp))
+                out = hip_ops.msda_encoder_packed(v, host_shapes, packed, P, self._encoder_windows_packed(host_shapes), counts, hm)
             if out is not None:
                 return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
-            if hm:
+            if v is not None and hm and v.dtype == value.dtype:
                 value_projected = v.permute(0, 2, 1, 3).reshape(B, S, -1)   # (declined shape: the general kernel's layout)
         # value projection with the padding mask folded into the GEMM epilogue (reference :173-176)
         if value_projected is not None:

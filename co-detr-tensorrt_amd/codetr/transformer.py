@@ -186,7 +186,7 @@ class DinoTransformerDecoder(nn.Module):
                 return None
             params += [p for p in layer.parameters()] + [p for p in reg_branches[lid].parameters()]
         params += list(self.ref_point_head.parameters()) + list(self.norm.parameters())
-        if any(p.dtype != torch.float16 or not p.is_cuda for p in params):
+        if any(p.dtype != params[0].dtype or not p.is_cuda for p in params) or params[0].dtype not in (torch.float16, torch.bfloat16):
             return None
         M, L, P, F = geo
         if not _cabi.decoder_layer_supported(C, M, L, P, F, 4, C // 2):
@@ -270,7 +270,7 @@ class DinoTransformerDecoder(nn.Module):
         out = query
         vr = None   # (only the ATen formulation below needs the tiled valid ratios)
         v_all = self._project_values(value, key_padding_mask)
-        if (query.is_cuda and query.dtype == torch.float16 and reference_points.shape[-1] == 4
+        if (query.is_cuda and query.dtype in (torch.float16, torch.bfloat16) and reference_points.shape[-1] == 4
                 and reference_points.dtype == query.dtype and getattr(valid_ratios, "_codetr_f32", None) is not None
                 and hip_ops.MSDA_FP32_REF and not torch.is_grad_enabled() and self._fused_inputs_ok(query, kw)):
             blobs = self._fused_weights(reg_branches)

@@ -70,9 +70,21 @@ constexpr int kMaxL = 8;
 #endif
 constexpr int kDepth = CODETR_DEC_DEPTH;       // weight fragments (1 KB each) a wave keeps in flight: 256 KB per workgroup
 
+// Element type of activations and weights.  The kernel is written against `f16` / `f16x8` / `f16x4` and one MFMA wrapper;
+// decoder_layer_bf16.hip compiles this same source with CODETR_DEC_BF16 defined: bf16 storage, v_mfma_f32_16x16x32_bf16,
+// the same fp32 arithmetic everywhere in between (LayerNorms, softmax, sampling geometry, the fp32 blend of the gather),
+// entry point codetr_decoder_layer_bf16.  The pure-host queries exist once, in the fp16 translation unit.
+#ifdef CODETR_DEC_BF16
+typedef __bf16 f16;
+typedef __bf16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 f16x4 __attribute__((ext_vector_type(4)));
+#define CODETR_DEC_ENTRY codetr_decoder_layer_bf16
+#else
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define CODETR_DEC_ENTRY codetr_decoder_layer_f16
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -219,7 +231,11 @@ __device__ __forceinline__ void prime(Stream& c, std::integer_sequence<int, Is..
   (issue<S, Is>(c), ...);
 }
 
+#ifdef CODETR_DEC_BF16
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#else
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#endif
 
 // one product of the schedule: acc[t] += W(tile wave + 8 t) . X^T over 8 k-steps, every consumed fragment replaced by
 // the one kDepth further down the stream
@@ -813,6 +829,7 @@ bool dims_ok(int num_heads, int head_dim, int L, int P, int hidden, int ref_dim,
 
 extern "C" {
 
+#ifndef CODETR_DEC_BF16
 #ifdef CODETR_DEC_STAMPS
 int codetr_decoder_layer_debug_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dec_stamps), sizeof(unsigned long long) * 32);
@@ -837,7 +854,9 @@ int64_t codetr_decoder_layer_blob_halfs(int which, int num_levels, int num_point
   }
 }
 
-int codetr_decoder_layer_f16(void* stream, const void* x_dev, const void* attn_dev, const void* qpos_dev, const void* ref_dev,
+#endif   // !CODETR_DEC_BF16
+
+int CODETR_DEC_ENTRY(void* stream, const void* x_dev, const void* attn_dev, const void* qpos_dev, const void* ref_dev,
                              const float* valid_ratios32_dev, const void* value_dev, const int64_t* spatial_shapes_dev,
                              const int64_t* level_start_dev, const void* tail_w_dev, const void* pos_w_dev,
                              const void* head_w_dev, const void* final_norm_dev, void* x_out_dev, void* ref_out_dev,

@@ -28,6 +28,7 @@
 // Requirements: K % 64 == 0, row pitches == K / N (dense row-major), 16-byte aligned bases.
 // M and N are arbitrary (edge tiles clamp their loads and mask their stores).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -983,8 +984,8 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
 // per wave, activation, fp16 image of the wave's 32 x 32 piece in its private LDS region, row-wise read-back,
 // residual (requested before the MFMAs) / row mask, 16-B stores.  X is read from HBM exactly once, Y written once,
 // W (<= 1.2 MB) comes from L2.
-template <class T, int KS, int ACT, bool HAS_RES>
-__global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __restrict__ X,
+template <class T, int KS, int ACT, bool HAS_RES, class OT = T>   // OT: storage type of Y (bf16 operands -> fp16 output: the
+__global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __restrict__ X,   // encoder MSDA's value map)
                                                         const unsigned short* __restrict__ X2,
                                                         const unsigned short* __restrict__ LNG,
                                                         const unsigned short* __restrict__ LNB, float ln_eps,
@@ -1139,7 +1140,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
               float x = bias ? T::to_f32(sBias[n + e]) : 0.f;
               if (ACT == 1) x = x < 0.f ? 0.f : x;
               if (ACT == 2) x = gelu_erf(x);
-              v[e] = (short)T::from_f32(x);
+              v[e] = (short)OT::from_f32(x);
             }
           } else if (mk) {
             v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -1227,7 +1228,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
           v[r] = x;
         }
         *reinterpret_cast<s16x4*>(my_stage + (mt * 16 + l15) * kXsPitch + ((c & 1) * CN + nt * 16 + grp * 4) * 2) =
-            T::pack4(v);
+            OT::pack4(v);
       }
   }
   // the last pair (one chunk if nchunks is odd)
@@ -1249,7 +1250,7 @@ bool xs_applicable(int64_t M, int64_t N, int64_t K, int hm_hd) {
   return (K == 192 || K == 256 || K == 64) && N % 8 == 0 && N >= 128 && N <= 1536 && M >= 128 * 256 && hm_hd % 8 == 0;
 }
 
-template <class T, int KS, int ACT>
+template <class T, int KS, int ACT, class OT = T>
 int launch_xs_res(hipStream_t st, const void* X, const void* W, const void* bias, const void* R, void* Y,
                   const void* mask, int M, int N, int hm_rows, int hm_hd, const void* X2 = nullptr,
                   const void* LNG = nullptr, const void* LNB = nullptr, float ln_eps = 0.f) {
@@ -1263,8 +1264,10 @@ int launch_xs_res(hipStream_t st, const void* X, const void* W, const void* bias
   auto r = static_cast<const unsigned short*>(R);
   auto y = static_cast<unsigned short*>(Y);
   auto mk = static_cast<const unsigned char*>(mask);
-  if (R) hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true>), grid, block, 0, st, x, x2, lg, lb, ln_eps, w, b, r, y, mk, M, N, hm_rows, hm_hd);
-  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false>), grid, block, 0, st, x, x2, lg, lb, ln_eps, w, b, r, y, mk, M, N, hm_rows, hm_hd);
+  if (R && std::is_same<T, OT>::value)
+    hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, true, T>), grid, block, 0, st, x, x2, lg, lb, ln_eps, w, b, r, y, mk, M, N, hm_rows, hm_hd);
+  else if (R) return CODETR_E_UNSUPPORTED;   // (a residual is added in the operands' type)
+  else hipLaunchKernelGGL((linear_xs_kernel<T, KS, ACT, false, OT>), grid, block, 0, st, x, x2, lg, lb, ln_eps, w, b, r, y, mk, M, N, hm_rows, hm_hd);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -1402,6 +1405,21 @@ int codetr_linear_bf16(void* stream, const void* x_dev, const void* w_dev, const
                        int64_t K, int act, int64_t hm_rows, int hm_head_dim) {
   return launch<BFloatT>(static_cast<hipStream_t>(stream), x_dev, w_dev, bias_dev, residual_dev, y_dev, row_mask_dev,
                          M, N, K, act, hm_rows, hm_head_dim);
+}
+
+int codetr_linear_bf16_f16out(void* stream, const void* x_dev, const void* w_dev, const void* bias_dev,
+                              const void* row_mask_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int64_t hm_rows,
+                              int hm_head_dim) {
+  if (!x_dev || !w_dev || !y_dev || M <= 0 || N <= 0 || K <= 0) return CODETR_E_BADARG;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if ((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(w_dev) | reinterpret_cast<uintptr_t>(y_dev)) & 15) return CODETR_E_BADARG;
+  if (hm_head_dim != 0 || hm_rows != 0) {
+    if (hm_head_dim <= 0 || hm_rows <= 0 || hm_head_dim % 8 != 0 || N % hm_head_dim != 0 || M % hm_rows != 0) return CODETR_E_UNSUPPORTED;
+  }
+  if (!xs_applicable(M, N, K, hm_head_dim) || K == 64) return CODETR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (K == 192) return launch_xs_res<BFloatT, 6, 0, HalfT>(st, x_dev, w_dev, bias_dev, nullptr, y_dev, row_mask_dev, (int)M, (int)N, (int)hm_rows, hm_head_dim);
+  return launch_xs_res<BFloatT, 8, 0, HalfT>(st, x_dev, w_dev, bias_dev, nullptr, y_dev, row_mask_dev, (int)M, (int)N, (int)hm_rows, hm_head_dim);
 }
 
 const char* codetr_linear_variant(int64_t M, int64_t N, int64_t K, int act, int has_residual, int hm_head_dim) {

@@ -162,6 +162,29 @@ __device__ __forceinline__ int floor_i(float v) {   // floor + float -> int in o
   return d;
 }
 
+// Storage type of the packed projection and of the output (the staged VALUE map is fp16 in either case: the blend runs on
+// packed halves, and gfx950 has no packed bf16 FMA -- a bf16 model's value projection writes fp16, three mantissa bits
+// more than bf16, through codetr_linear_bf16_f16out)
+struct EF16 {
+  __device__ static float lo(unsigned u) { return (float)as_h2(u)[0]; }
+  __device__ static float hi(unsigned u) { return (float)as_h2(u)[1]; }
+  __device__ static u32x4 pack8(const float (&a)[8]) {
+    return u32x4{pack_h2(a[0], a[1]), pack_h2(a[2], a[3]), pack_h2(a[4], a[5]), pack_h2(a[6], a[7])};
+  }
+};
+struct EBF16 {
+  __device__ static float lo(unsigned u) { return __uint_as_float(u << 16); }
+  __device__ static float hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+  __device__ static unsigned pk(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+  }
+  __device__ static u32x4 pack8(const float (&a)[8]) {
+    return u32x4{pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7])};
+  }
+};
+
 // What a wave keeps about one level (all wave-uniform: SGPRs)
 struct Lv {
   int W, H, start;           // level size, first pixel inside S
@@ -202,14 +225,15 @@ struct Smp {
   float lw, lh;
   int x0, y0;
 };
+template <class ET>
 __device__ __forceinline__ Smp sample_at(const Lv& v, float bx, float by, unsigned o2) {
   Smp s;
   // reference: loc = ref_k + off / (W, H); im = loc * (W, H) - 0.5 with ref_k = centre / (vr_q size_q) * vr_k and
   // vr * size = valid pixel count  ->  im = (centre / vc_q) * vc_k - 0.5 + off          (transformer.py:280-305, cu:241-247)
   // (fmaxf: a NaN coordinate becomes a huge negative one -> outside every window and outside the gate: the sample is
   // dropped, as by the reference's comparisons)
-  const float w_im = fmaxf(fmaf(bx, v.vcx, -0.5f) + h_lo(o2), -3.0e38f);
-  const float h_im = fmaxf(fmaf(by, v.vcy, -0.5f) + h_hi(o2), -3.0e38f);
+  const float w_im = fmaxf(fmaf(bx, v.vcx, -0.5f) + ET::lo(o2), -3.0e38f);
+  const float h_im = fmaxf(fmaf(by, v.vcy, -0.5f) + ET::hi(o2), -3.0e38f);
   s.lw = __builtin_amdgcn_fractf(w_im);
   s.lh = __builtin_amdgcn_fractf(h_im);
   s.x0 = floor_i(w_im);
@@ -230,14 +254,14 @@ struct Prep {
   unsigned ad, w01, w23;
 };
 
-template <int LV0, int NLV>
+template <class ET, int LV0, int NLV>
 __device__ __forceinline__ bool prepare(Prep (&pp)[NLV], const Lv (&lv)[kL], const float (&aw)[kL], const unsigned (&o2)[kL],
                                         float bx, float by) {
   bool allok = true;
 #pragma unroll
   for (int i = 0; i < NLV; ++i) {
     const Lv& v = lv[LV0 + i];
-    const Smp s = sample_at(v, bx, by, o2[LV0 + i]);
+    const Smp s = sample_at<ET>(v, bx, by, o2[LV0 + i]);
     const unsigned dx = (unsigned)(s.x0 - v.px0), dy = (unsigned)(s.y0 - v.py0);
     const bool ok = dx <= (unsigned)v.xspan && dy <= (unsigned)v.yspan;   // all four corners are staged (or zero border)
     const float a = aw[LV0 + i];
@@ -309,7 +333,7 @@ __device__ __forceinline__ void gather(float (&acc)[8], const Prep (&pp)[NLV], c
 // (16-byte records in LDS), and added from global memory by the pair's four lanes, kQ records per round.  Two halves so
 // that the first round's global loads can fly under the iteration's gather loop (PRE): begin() = re-derive, queue, request
 // the rows of round 0; end() = blend them, then further rounds while some pair has records left.
-template <int LV0, int NLV>
+template <class ET, int LV0, int NLV>
 struct Fix {
   u32x4 rec[NLV];
   unsigned bad;
@@ -368,7 +392,7 @@ struct Fix {
 #pragma unroll
     for (int i = 0; i < NLV; ++i) {
       const Lv& v = lv[LV0 + i];
-      const Smp s = sample_at(v, bx, by, o2[LV0 + i]);
+      const Smp s = sample_at<ET>(v, bx, by, o2[LV0 + i]);
       const unsigned dx = (unsigned)(s.x0 - v.px0), dy = (unsigned)(s.y0 - v.py0);
       const bool ok = dx <= (unsigned)v.xspan && dy <= (unsigned)v.yspan;
       // cu:249: h_im > -1 && w_im > -1 && h_im < H && w_im < W  <=>  floor in [-1, size - 1]
@@ -404,11 +428,11 @@ struct Fix {
 };
 
 // the same in one piece (no prefetch): every round = queue, request, blend
-template <int LV0, int NLV>
+template <class ET, int LV0, int NLV>
 __device__ __forceinline__ void fixup(float (&acc)[8], const Lv (&lv)[kL], const float (&aw)[kL], const unsigned (&o2)[kL],
                                       float bx, float by, u32x4* __restrict__ queue, const unsigned char* __restrict__ vhead,
                                       const unsigned pix_bytes, const int sub) {
-  Fix<LV0, NLV> fx;
+  Fix<ET, LV0, NLV> fx;
   fx.derive(lv, aw, o2, bx, by, sub);
   for (int base = 0; __builtin_amdgcn_ballot_w64(fx.cnt > base) != 0; base += kQ) {
     fx.push(queue, base, sub);
@@ -418,10 +442,10 @@ __device__ __forceinline__ void fixup(float (&acc)[8], const Lv (&lv)[kL], const
 }
 
 // LDS: [staged rows of ONE pass | fix-up queues (T / 4 pairs x kQ x 16 B)]
-template <int T, int WPE, bool PRE, int DEPTH = 1, bool AHEAD = true>
+template <class ET, int T, int WPE, bool PRE, int DEPTH = 1, bool AHEAD = true>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void msda_encoder_v4_kernel(
-    const _Float16* __restrict__ value, const _Float16* __restrict__ packed, _Float16* __restrict__ out, const Geom4 g,
-    const int packed_stride) {
+    const _Float16* __restrict__ value, const unsigned short* __restrict__ packed, unsigned short* __restrict__ out,
+    const Geom4 g, const int packed_stride) {
   constexpr unsigned kRow = 64;
   constexpr int kWaves = Cfg<T>::kWaves, kPairs = Cfg<T>::kPairs;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -566,7 +590,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
     o2[it][2] = rawA[it][2];
     o2[it][3] = rawA[it][3];
     o2[it][4] = rawB[it][0];
-    const float lg[kL] = {h_lo(rawB[it][1]), h_hi(rawB[it][1]), h_lo(rawB[it][2]), h_hi(rawB[it][2]), h_lo(rawB[it][3])};
+    const float lg[kL] = {ET::lo(rawB[it][1]), ET::hi(rawB[it][1]), ET::lo(rawB[it][2]), ET::hi(rawB[it][2]), ET::lo(rawB[it][3])};
     float mx = lg[0];
 #pragma unroll
     for (int k = 1; k < kL; ++k) mx = fmaxf(mx, lg[k]);
@@ -630,7 +654,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
 #pragma unroll
       for (int i = 0; i < NLV; ++i) pp[it][i] = Prep{lv[LV0 + i].base, 0u, 0u};
       if (AHEAD && it < n_it && !(kAbl & 8)) {
-        const bool ok = prepare<LV0, NLV>(pp[it], lv, aw[it], o2[it], bx[it], by[it]);
+        const bool ok = prepare<ET, LV0, NLV>(pp[it], lv, aw[it], o2[it], bx[it], by[it]);
         clean[it] = __builtin_amdgcn_ballot_w64(!ok) == 0;
       }
     }
@@ -640,17 +664,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
     for (int it = 0; it < kMaxIt; ++it)
       if (it < n_it && !(kAbl & 4)) {
         if (!AHEAD && !(kAbl & 8)) {
-          const bool ok = prepare<LV0, NLV>(pp[it], lv, aw[it], o2[it], bx[it], by[it]);
+          const bool ok = prepare<ET, LV0, NLV>(pp[it], lv, aw[it], o2[it], bx[it], by[it]);
           clean[it] = __builtin_amdgcn_ballot_w64(!ok) == 0;
         }
         if constexpr (PRE) {
-          Fix<LV0, NLV> fx;
+          Fix<ET, LV0, NLV> fx;
           if (!clean[it]) fx.begin(lv, aw[it], o2[it], bx[it], by[it], queue, vhead, pix_bytes, sub);
           gather<LV0, NLV, DEPTH>(acc[it], pp[it], lv, lds_lane);
           if (!clean[it]) fx.end(acc[it], queue, vhead, pix_bytes, sub);
         } else {
           gather<LV0, NLV, DEPTH>(acc[it], pp[it], lv, lds_lane);
-          if (!clean[it]) fixup<LV0, NLV>(acc[it], lv, aw[it], o2[it], bx[it], by[it], queue, vhead, pix_bytes, sub);
+          if (!clean[it]) fixup<ET, LV0, NLV>(acc[it], lv, aw[it], o2[it], bx[it], by[it], queue, vhead, pix_bytes, sub);
         }
       }
   };
@@ -662,10 +686,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
 #pragma unroll
   for (int it = 0; it < kMaxIt; ++it)
     if (it < n_it && (it * kWaves + wave) * 16 + pl < total) {
-      f16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (_Float16)acc[it][j];
-      *reinterpret_cast<f16x8*>(orow + (size_t)((unsigned)qs[it] * ((unsigned)M * kRow))) = o;   // out is [B, S, M, 32] in either case
+      const u32x4 o = ET::pack8(acc[it]);
+      *reinterpret_cast<u32x4*>(orow + (size_t)((unsigned)qs[it] * ((unsigned)M * kRow))) = o;   // out is [B, S, M, 32] in either case
     }
 }
 
@@ -752,6 +774,7 @@ inline Plan4 plan4(const int64_t* shapes, int64_t S, int M, int L, int P, const 
   return pl;
 }
 
+template <class ET>
 int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void* packed, int64_t packed_stride,
             const float* vcounts, int64_t B, int64_t S, int M, int D, int L, int P, const signed char* win, int region_w,
             int region_h, int threads, int variant, int head_major, void* out) {
@@ -769,24 +792,24 @@ int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void
   if (blocks >= (1 << 22)) return CODETR_E_UNSUPPORTED;
   pl.g.vcounts = vcounts;
   pl.g.head_major = head_major ? 1 : 0;
-  typedef void (*Kern)(const _Float16*, const _Float16*, _Float16*, const Geom4, const int);
+  typedef void (*Kern)(const _Float16*, const unsigned short*, unsigned short*, const Geom4, const int);
   // variant = kernel build (same results): 0 the default -- four waves per SIMD, rows one step ahead, preparation under the
   // DMA; 1: rows two steps ahead, preparation right before each gather; 2: three waves per SIMD (168 registers: three
   // workgroups of <= 53 KB per CU); 3: three waves + the first fix-up round requested before the gather; 4 / 5: three waves,
   // rows two / three steps ahead; 6: as 0 with the preparation right before each gather; 7: three waves, fix-up prefetch,
   // rows two steps ahead.  (512 threads: the three-wave builds do not exist, 2-5 and 7 map to four waves.)
   static const Kern kerns[2][8] = {
-      {msda_encoder_v4_kernel<256, 4, false, 1, true>, msda_encoder_v4_kernel<256, 4, false, 2, false>,
-       msda_encoder_v4_kernel<256, 3, false, 1, true>, msda_encoder_v4_kernel<256, 3, true, 1, true>,
-       msda_encoder_v4_kernel<256, 3, false, 2, true>, msda_encoder_v4_kernel<256, 3, false, 3, true>,
-       msda_encoder_v4_kernel<256, 4, false, 1, false>, msda_encoder_v4_kernel<256, 3, true, 2, true>},
-      {msda_encoder_v4_kernel<512, 4, false, 1, true>, msda_encoder_v4_kernel<512, 4, false, 2, false>,
-       msda_encoder_v4_kernel<512, 4, false, 1, true>, msda_encoder_v4_kernel<512, 4, true, 1, true>,
-       msda_encoder_v4_kernel<512, 4, false, 2, true>, msda_encoder_v4_kernel<512, 4, false, 3, true>,
-       msda_encoder_v4_kernel<512, 4, false, 1, false>, msda_encoder_v4_kernel<512, 4, true, 2, true>}};
+      {msda_encoder_v4_kernel<ET, 256, 4, false, 1, true>, msda_encoder_v4_kernel<ET, 256, 4, false, 2, false>,
+       msda_encoder_v4_kernel<ET, 256, 3, false, 1, true>, msda_encoder_v4_kernel<ET, 256, 3, true, 1, true>,
+       msda_encoder_v4_kernel<ET, 256, 3, false, 2, true>, msda_encoder_v4_kernel<ET, 256, 3, false, 3, true>,
+       msda_encoder_v4_kernel<ET, 256, 4, false, 1, false>, msda_encoder_v4_kernel<ET, 256, 3, true, 2, true>},
+      {msda_encoder_v4_kernel<ET, 512, 4, false, 1, true>, msda_encoder_v4_kernel<ET, 512, 4, false, 2, false>,
+       msda_encoder_v4_kernel<ET, 512, 4, false, 1, true>, msda_encoder_v4_kernel<ET, 512, 4, true, 1, true>,
+       msda_encoder_v4_kernel<ET, 512, 4, false, 2, true>, msda_encoder_v4_kernel<ET, 512, 4, false, 3, true>,
+       msda_encoder_v4_kernel<ET, 512, 4, false, 1, false>, msda_encoder_v4_kernel<ET, 512, 4, true, 2, true>}};
   const Kern kern = kerns[threads == 512][variant & 7];
   {
-    static std::atomic<uint32_t> done[64];   // > 64 KB of dynamic LDS: the attribute is per (device, function)
+    static std::atomic<uint32_t> done[64];   // > 64 KB of dynamic LDS: the attribute is per (device, function); one table per ET
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done[0].store(0);
     const uint32_t bit = 1u << ((threads == 512 ? 8 : 0) + (variant & 7));
@@ -797,7 +820,7 @@ int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)threads), pl.lds, st, static_cast<const _Float16*>(value),
-                     static_cast<const _Float16*>(packed), static_cast<_Float16*>(out), pl.g, (int)packed_stride);
+                     static_cast<const unsigned short*>(packed), static_cast<unsigned short*>(out), pl.g, (int)packed_stride);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -812,9 +835,20 @@ int codetr_msda_encoder_forward_packed_f16(void* stream, const void* value_dev, 
                                            int region_w, int region_h, int threads, int variant, int value_head_major,
                                            void* out_dev) {
   if (variant < 0 || variant > 7) return CODETR_E_BADARG;
-  return launch4(static_cast<hipStream_t>(stream), value_dev, level_shapes_host, packed_dev, packed_row_stride,
-                 valid_counts_dev, B, S, M, D, L, P, reinterpret_cast<const signed char*>(windows_host), region_w, region_h,
-                 threads, variant, value_head_major, out_dev);
+  return launch4<EF16>(static_cast<hipStream_t>(stream), value_dev, level_shapes_host, packed_dev, packed_row_stride,
+                       valid_counts_dev, B, S, M, D, L, P, reinterpret_cast<const signed char*>(windows_host), region_w,
+                       region_h, threads, variant, value_head_major, out_dev);
+}
+
+int codetr_msda_encoder_forward_packed_bf16(void* stream, const void* value_f16_dev, const int64_t* level_shapes_host,
+                                            const void* packed_dev, int64_t packed_row_stride, const float* valid_counts_dev,
+                                            int64_t B, int64_t S, int M, int D, int L, int P, const int8_t* windows_host,
+                                            int region_w, int region_h, int threads, int variant, int value_head_major,
+                                            void* out_dev) {
+  if (variant < 0 || variant > 7) return CODETR_E_BADARG;
+  return launch4<EBF16>(static_cast<hipStream_t>(stream), value_f16_dev, level_shapes_host, packed_dev, packed_row_stride,
+                        valid_counts_dev, B, S, M, D, L, P, reinterpret_cast<const signed char*>(windows_host), region_w,
+                        region_h, threads, variant, value_head_major, out_dev);
 }
 
 int64_t codetr_msda_encoder_packed_lds_bytes(const int64_t* level_shapes_host, int M, int L, int P, const int8_t* windows_host,

@@ -226,6 +226,15 @@ int codetr_msda_encoder_forward_packed_f16(void *stream, const void *value_dev, 
                                            const float *valid_counts_dev, int64_t B, int64_t S, int M, int D, int L, int P,
                                            const int8_t *windows_host, int region_w, int region_h, int threads,
                                            int variant, int value_head_major, void *out_dev);
+/* The same for a bf16 model: packed projection and output are bf16, the VALUE MAP IS FP16 (value_f16_dev; written by
+ * codetr_linear_bf16_f16out): the blend runs on packed halves either way -- gfx950 has no packed bf16 FMA -- and an fp16
+ * value map keeps three more mantissa bits of the projection's fp32 accumulators than a bf16 one would.  Offsets and logits
+ * are widened exactly; the result is rounded to bf16 once. */
+int codetr_msda_encoder_forward_packed_bf16(void *stream, const void *value_f16_dev, const int64_t *level_shapes_host,
+                                            const void *packed_dev, int64_t packed_row_stride,
+                                            const float *valid_counts_dev, int64_t B, int64_t S, int M, int D, int L, int P,
+                                            const int8_t *windows_host, int region_w, int region_h, int threads,
+                                            int variant, int value_head_major, void *out_dev);
 int64_t codetr_msda_encoder_packed_lds_bytes(const int64_t *level_shapes_host, int M, int L, int P,
                                              const int8_t *windows_host, int region_w, int region_h, int threads);
 int codetr_msda_pack_projection_index(int M, int L, int P, int32_t *idx_host);
@@ -316,6 +325,14 @@ int codetr_linear_f16(void *stream, const void *x_dev, const void *w_dev, const 
 int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                        const void *residual_dev, const void *row_mask_dev, void *y_dev, int64_t M, int64_t N,
                        int64_t K, int act, int64_t hm_rows, int hm_head_dim);
+/* bf16 operands, FP16 output (no activation, no residual; row mask and head-major destination as above): the value
+ * projection in front of codetr_msda_encoder_forward_packed_bf16, whose staged value map is fp16 whatever the model's
+ * type (its blend runs on packed halves; gfx950 has no packed bf16 FMA).  fp32 accumulators rounded once to fp16 -- three
+ * more mantissa bits than the bf16 store they replace.  Large short-K problems only (the X-stationary kernel: K in
+ * {192, 256}, M >= 32 768, 128 <= N <= 1536); CODETR_E_UNSUPPORTED otherwise. */
+int codetr_linear_bf16_f16out(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                              const void *row_mask_dev, void *y_dev, int64_t M, int64_t N, int64_t K,
+                              int64_t hm_rows, int hm_head_dim);
 
 /* Which of the three kernels behind codetr_linear_* serves a (16-byte aligned) problem: "tile128" (128x128 tiles, the
  * general kernel), "tile256" (256x256 tiles, one workgroup per CU), "xs" (X-stationary short-K kernel) or
@@ -714,6 +731,15 @@ int codetr_decoder_layer_supported(int embed_dims, int num_heads, int num_levels
                                    int pos_feat);
 int64_t codetr_decoder_layer_blob_halfs(int which, int num_levels, int num_points, int hidden);
 int codetr_decoder_layer_f16(void *stream, const void *x_dev, const void *attn_dev, const void *qpos_dev,
+                             const void *ref_dev, const float *valid_ratios32_dev, const void *value_dev,
+                             const int64_t *spatial_shapes_dev, const int64_t *level_start_dev, const void *tail_w_dev,
+                             const void *pos_w_dev, const void *head_w_dev, const void *final_norm_dev, void *x_out_dev,
+                             void *ref_out_dev, void *qpos_out_dev, void *qk_out_dev, void *v_out_dev, int64_t B,
+                             int64_t Nq, int64_t S, int num_levels, int num_points, int hidden, float ln_eps,
+                             float temperature);
+/* bf16 twin: bf16 activations / weights / outputs, v_mfma_f32_16x16x32_bf16, the same fp32 arithmetic in between (the
+ * same source compiled with bf16 storage, csrc/decoder_layer_bf16.hip). */
+int codetr_decoder_layer_bf16(void *stream, const void *x_dev, const void *attn_dev, const void *qpos_dev,
                              const void *ref_dev, const float *valid_ratios32_dev, const void *value_dev,
                              const int64_t *spatial_shapes_dev, const int64_t *level_start_dev, const void *tail_w_dev,
                              const void *pos_w_dev, const void *head_w_dev, const void *final_norm_dev, void *x_out_dev,

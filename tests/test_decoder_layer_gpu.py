@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _decoder(layers, seed=0, levels=5):
+def _decoder(layers, seed=0, levels=5, dtype=torch.float16):
     from codetr.transformer import DinoTransformerDecoder, build_MLP
 
     torch.manual_seed(seed)
@@ -37,18 +37,18 @@ def _decoder(layers, seed=0, levels=5):
         dec.norm.weight.add_(1.0)
         for r in reg:
             r[4].weight.mul_(0.2)
-    return dec.to(DEV).half().eval(), reg.to(DEV).half().eval()
+    return dec.to(DEV).to(dtype).eval(), reg.to(DEV).to(dtype).eval()
 
 
-def _inputs(B, Nq, shapes, seed=5, masked=True):
+def _inputs(B, Nq, shapes, seed=5, masked=True, dtype=torch.float16):
     g = torch.Generator(device=DEV).manual_seed(seed)
     S = sum(h * w for h, w in shapes)
-    query = torch.randn(B, Nq, 256, device=DEV, generator=g).half()
-    memory = torch.randn(B, S, 256, device=DEV, generator=g).half()
+    query = torch.randn(B, Nq, 256, device=DEV, generator=g).to(dtype)
+    memory = torch.randn(B, S, 256, device=DEV, generator=g).to(dtype)
     mask = (torch.rand(B, S, device=DEV, generator=g) < 0.1) if masked else None
-    ref = (torch.randn(B, Nq, 4, device=DEV, generator=g) * 1.5).half()
+    ref = (torch.randn(B, Nq, 4, device=DEV, generator=g) * 1.5).to(dtype)
     vr32 = (0.6 + 0.4 * torch.rand(B, len(shapes), 2, device=DEV, generator=g)).float()
-    vr = vr32.half()
+    vr = vr32.to(dtype)
     vr._codetr_f32 = vr32
     ss = torch.tensor(shapes, dtype=torch.int64, device=DEV)
     ls = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
@@ -93,6 +93,25 @@ def test_one_launch_per_layer_matches_the_separate_launches(B, Nq, layers, level
     assert rel < 1e-3 * (1 + layers), rel     # measured: 2.3e-3 after 6 layers, 1e-3 after 2
     assert float(d.abs().max()) < 0.06 * max(1, layers // 2)
     assert float((ref_f.float() - ref_u.float()).abs().max()) < 0.02 * layers
+
+
+def test_bf16_one_launch_per_layer_matches_the_separate_launches():
+    """codetr_decoder_layer_bf16 (the same source compiled with bf16 storage): same launch counts as fp16, and as close to
+    the separate bf16 launches as 8 mantissa bits allow (different summation order; a bf16 ulp is 2^-8)"""
+    from codetr import _cabi
+
+    layers = 3
+    dec, reg = _decoder(layers, seed=7, dtype=torch.bfloat16)
+    inp = _inputs(2, 300, PYR, seed=8, dtype=torch.bfloat16)
+    before = dict(_cabi.CALLS)
+    out_f, ref_f = _run(dec, reg, inp, True)
+    assert _cabi.CALLS["decoder_layer"] == before["decoder_layer"] + layers + 1
+    assert _cabi.CALLS["layernorm"] == before["layernorm"]
+    out_u, ref_u = _run(dec, reg, inp, False)
+    assert out_f.dtype == torch.bfloat16 and torch.isfinite(out_f.float()).all() and torch.isfinite(ref_f.float()).all()
+    rel = float((out_f.float() - out_u.float()).norm() / out_u.float().norm())
+    assert rel < 8e-3 * (1 + layers), rel
+    assert float((ref_f.float() - ref_u.float()).abs().max()) < 0.15 * layers
 
 
 def test_against_fp32_formulation_of_the_reference():

@@ -158,6 +158,25 @@ def test_linear_head_major_output_large_short_k():
     assert torch.equal(y_hm, y_rm.view(B, S, Hh, hd).permute(0, 2, 1, 3))
 
 
+def test_value_projection_bf16_operands_fp16_head_major_output():
+    """codetr_linear_bf16_f16out (the bf16 model's value projection in front of the packed encoder MSDA kernel): bf16
+    x / w / bias, fp32 accumulation, ONE rounding to fp16, head-major [B, M, S, 32] destination, masked rows zero"""
+    from codetr import hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(6)
+    B, S, K, Hh, hd = 2, 20000, 256, 8, 32
+    x = torch.randn(B, S, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(Hh * hd, K, device=DEV, generator=g) / 16).bfloat16()
+    b = torch.randn(Hh * hd, device=DEV, generator=g).bfloat16()
+    mask = torch.rand(B, S, device=DEV, generator=g) < 0.2
+    y = hip_ops.value_projection_f16(x, w, b, mask, hd)
+    assert y is not None and y.dtype == torch.float16 and y.shape == (B, Hh, S, hd)
+    ref = (x.float() @ w.float().t() + b.float()).masked_fill(mask[..., None], 0.0).view(B, S, Hh, hd).permute(0, 2, 1, 3)
+    err = (y.float() - ref).abs()
+    assert bool((err <= 2.0 ** -10 * ref.abs() + 1e-3 * 2.0 ** -10 * 64 + K * 2.0 ** -22).all()), float(err.max())   # 1 fp16 ulp
+    assert hip_ops.value_projection_f16(x[:, :100], w, b, None, hd) is None      # too few rows for the short-K kernel
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,bias,act,res", [
     (600, 256, 13824, False, None, False),   # the neck's extra 3x3/s2 level over unfolded patches (1920x1280 input)

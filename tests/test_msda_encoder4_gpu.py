@@ -158,6 +158,32 @@ def test_every_kernel_build_and_both_value_layouts(variant, head_major):
                f"{cfg} variant {variant} head_major {head_major}")
 
 
+@pytest.mark.parametrize("cfg", list(CFGS))
+@pytest.mark.parametrize("head_major", [False, True], ids=["op_layout", "head_major"])
+def test_bf16_model_packed_projection_and_output_fp16_value_map(cfg, head_major):
+    """codetr_msda_encoder_forward_packed_bf16: offsets / logits arrive as bf16 and the result leaves as bf16; the value
+    map is fp16 (the header says why).  Oracle on the bf16-rounded offsets / logits and the fp16 value map; tolerance =
+    the output's own bf16 rounding (half an ulp = 2^-9 relative) on top of the packed blend's: rtol 1e-2 / atol 2e-3 and
+    relative L2 <= 3e-3."""
+    from codetr import _cabi
+
+    value, off, logits, counts, S = _inputs(PYR_ODD, 2, 3.0, seed=555)
+    off, logits = off.bfloat16(), logits.bfloat16()
+    expect = _expect(value, off.float(), logits.float(), counts, PYR_ODD)
+    threads, region, _ = CFGS[cfg]
+    B = 2
+    out = torch.full((B, S, M * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    v = value.to(DEV)
+    if head_major:
+        v = v.permute(0, 2, 1, 3).contiguous()
+    assert _cabi.msda_encoder_packed(v, PYR_ODD, _pack(off, logits).to(DEV), P, _halo(3), counts.to(DEV), region, threads, out,
+                                     6, head_major)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    np.testing.assert_allclose(got, expect, rtol=1e-2, atol=2e-3)
+    assert np.linalg.norm(got - expect) / np.linalg.norm(expect) <= 3e-3
+
+
 def test_non_finite_offsets_drop_the_sample_like_the_reference_gate():
     """NaN / inf sampling offsets fail cu:249's comparisons: the sample contributes nothing, the other 19 do"""
     value, off, logits, counts, S = _inputs(PYR_ODD, 1, 1.5, seed=9)
