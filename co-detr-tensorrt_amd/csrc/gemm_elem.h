@@ -40,12 +40,16 @@ struct BFloatT {
   using frag = bf16x8;
   __device__ static f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
   __device__ static float to_f32(unsigned short bits) { return __uint_as_float(((unsigned)bits) << 16); }
+  // (the hardware converter: v_cvt_pk_bf16_f32, round to nearest even, quiet NaN)
   __device__ static unsigned short from_f32(float v) {
-    unsigned u = __float_as_uint(v);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    const __bf16 h = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, h);
   }
-  __device__ static unsigned pack2(float lo, float hi) { return (unsigned)from_f32(lo) | ((unsigned)from_f32(hi) << 16); }
+  __device__ static unsigned pack2(float lo, float hi) {
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const bf16x2v h = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, h);
+  }
 };
 
 // nn.GELU (erf form) = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): the sign of erf

@@ -34,10 +34,9 @@ struct LnHalf {
 };
 struct LnBf16 {
   __device__ static float up(short b) { return __uint_as_float(((unsigned)(unsigned short)b) << 16); }
-  __device__ static short down(float v) {
-    unsigned u = __float_as_uint(v);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (short)((u >> 16) | 0x40);
-    return (short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  __device__ static short down(float v) {   // v_cvt_pk_bf16_f32 (round to nearest even, quiet NaN)
+    const __bf16 h = (__bf16)v;
+    return __builtin_bit_cast(short, h);
   }
 };
 

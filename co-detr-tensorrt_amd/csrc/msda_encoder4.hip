@@ -43,7 +43,10 @@ constexpr int kMaxM = 16;     // heads with a staged window of their own
 constexpr int kMaxIt = 3;     // iterations (16 queries each) per wave
 constexpr int kQ = 2;         // fix-up records per (query, head) pair and queue round
 constexpr int kMaxLds = 160 * 1024;
-constexpr int kBand = 4;      // region rows per band of the tile walk (see decode_tile)
+#ifndef MSDA4_BAND
+#define MSDA4_BAND 4
+#endif
+constexpr int kBand = MSDA4_BAND;   // region rows per band of the tile walk (see decode_tile; 2 / 8 measured: profiles/r05_msda_encoder4_sweep.txt)
 #ifndef MSDA4_ABL
 #define MSDA4_ABL 0           // timing experiments only (tools/micro/build_variant.sh): parts compiled out, WRONG results
 #endif
