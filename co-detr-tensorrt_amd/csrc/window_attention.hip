@@ -246,7 +246,9 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
         if (MASK) regk = *reinterpret_cast<const unsigned*>(ldsR + key0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = s[kt][r] * scale_log2e + (float)bv[r] * log2e;
+          // (bias * log2e + score * scale: the 16-bit bias goes into the fused multiply-add directly -- v_fma_mix_f32 --
+          // instead of a conversion, a multiply and an fma)
+          float v = fmaf((float)bv[r], log2e, s[kt][r] * scale_log2e);
           if (MASK && (int)((regk >> (8 * r)) & 0xff) != tq.region) v -= 100.0f * log2e;
           if ((N % 16 != 0) && key0 + r >= N) v = -INFINITY;
           s[kt][r] = v;
@@ -259,8 +261,15 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // ---- exp, row sum, pack P^T as MFMA B fragments ----
-    float sum = 0.f;
+    // The row sums come from the matrix pipe (8 % busy in this kernel, the vector pipe is the bound): one more MFMA per
+    // 32-key step with an all-ones A operand gives D[i][query] = sum over the keys of P^T[key][query] for every i -- the sum
+    // of exactly the rounded probabilities that multiply V, in this lane's own query column.  Replaces an add per score
+    // and two cross-lane reductions per query tile.
     V8 pf[KS];
+    V8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (E)1.0f;
+    f32x4 rs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -269,16 +278,13 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = 0.f;
-          if (kt < NT) {
-            p = __builtin_amdgcn_exp2f(s[kt][r] - mx);  // v_exp_f32; argument <= 0
-            sum += p;
-          }
+          if (kt < NT) p = __builtin_amdgcn_exp2f(s[kt][r] - mx);  // v_exp_f32; argument <= 0
           pf[ks][h * 4 + r] = (E)p;
         }
       }
+      rs = ET::mfma(ones, pf[ks], rs);
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    const float sum = rs[0];
     // ---- O^T = V^T . P^T : D[i = channel][j = query] ----
     f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
