@@ -2,7 +2,7 @@
 # Round evidence run (on the GPU box, through gpurun): bench lines, kernel traces at 8 images / 1 image per step, PMC
 # passes (each in its own run, never with a trace).  Writes only small folded files under gpurun_out/final/.
 #   tools/collect_profiles.sh <tag>      e.g. r04
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
 if [ -z "$SKIP_BENCH" ]; then

@@ -5,12 +5,15 @@
 set -e
 cd "$(dirname "$0")/../.."
 mkdir -p tools/micro/_bin
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Ico-detr-tensorrt_amd/csrc -Wno-inline-asm -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form"
+# (compiler, flags and the probed LLVM option of the product build: make -s print-*)
+MK=co-detr-tensorrt_amd/csrc
+HIPCC=$(make -s -C $MK print-hipcc)
+FLAGS="$(make -s -C $MK print-flags) -Ico-detr-tensorrt_amd/csrc $(make -s -C $MK print-vgprform)"
 OTHERS=$(ls co-detr-tensorrt_amd/csrc/_obj/*.o | grep -v decoder_layer.o | grep -v amdgcn)
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
-  ( /opt/rocm/bin/hipcc $FLAGS $defs -c co-detr-tensorrt_amd/csrc/decoder_layer.hip -o tools/micro/_bin/dec_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/micro/_bin/libcodetr_dec_$name.so tools/micro/_bin/dec_$name.o $OTHERS ) &
+  ( $HIPCC $FLAGS $defs -c co-detr-tensorrt_amd/csrc/decoder_layer.hip -o tools/micro/_bin/dec_$name.o &&
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o tools/micro/_bin/libcodetr_dec_$name.so tools/micro/_bin/dec_$name.o $OTHERS ) &
 done
 wait
 ls -la tools/micro/_bin/libcodetr_dec_*.so
