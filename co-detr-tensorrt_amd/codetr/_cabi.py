@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -50,9 +50,9 @@ SIGNATURES = {
                                                     _i32, _i32, _vp, _i32, _vp]),
     "codetr_msda_encoder_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32]),
     "codetr_msda_encoder_forward_packed_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
-                                                      _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+                                                      _vp, _i32, _i32, _i32, _i32, _vp]),
     "codetr_msda_encoder_forward_packed_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
-                                                       _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+                                                       _vp, _i32, _i32, _i32, _i32, _vp]),
     "codetr_linear_bf16_f16out": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32]),
     "codetr_msda_encoder_packed_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32]),
     "codetr_msda_pack_projection_index": (_i32, [_i32, _i32, _i32, _vp]),
@@ -677,7 +677,7 @@ def msda_pack_projection_index(M, L, P):
 
 
 def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_counts, region, threads, out,
-                        variant=0, head_major=False) -> bool:
+                        head_major=False) -> bool:
     """Round-5 encoder kernel: value [B,S,M,32] fp16 ([B,M,S,32] with head_major); packed [B,S,>=64 M] fp16 (lane-major packed projection);
     valid_counts [B,L,2] fp32; windows [M][L][4]; region (w, h) in finest-level pixels; threads 256 | 512.  Returns
     False when the library reports the shape as unsupported, raises on any other error."""
@@ -693,7 +693,7 @@ def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_
     rc = fn(
         current_stream_ptr(value.device), value.data_ptr(), shapes, packed.data_ptr(), packed.shape[-1],
         valid_counts.data_ptr(), B, S, M, D, L, num_points, _windows_array(windows, M, L), int(region[0]), int(region[1]),
-        int(threads), int(variant), 1 if head_major else 0, out.data_ptr())
+        int(threads), 1 if head_major else 0, out.data_ptr())
     if rc == E_UNSUPPORTED:
         return False
     check(rc, "codetr_msda_encoder_forward_packed_f16")

@@ -738,9 +738,8 @@ MSDA_V4_REGION = (16, 16)      # region of a workgroup, pixels of the finest lev
 MSDA_V4_LDS_BUDGET = 64 * 1024   # bytes per workgroup
 MSDA_V4_MARGIN_CAP = 40.0      # pixels: windows grow up to this margin around a head's bias points within the LDS budget
 MSDA_V4_HEAD_MAJOR = True      # value projection writes [B, M, S, 32] for the packed encoder kernel
-MSDA_V4_VARIANT = 6            # kernel build (include/codetr_hip.h): 6 = rows one step ahead, preparation in front of each gather
 _SWITCH_DEFAULTS.update({"MSDA_V4": True, "MSDA_V4_THREADS": 512, "MSDA_V4_REGION": (16, 16),
-                         "MSDA_V4_LDS_BUDGET": 64 * 1024, "MSDA_V4_MARGIN_CAP": 40.0, "MSDA_V4_VARIANT": 6,
+                         "MSDA_V4_LDS_BUDGET": 64 * 1024, "MSDA_V4_MARGIN_CAP": 40.0,
                          "MSDA_V4_HEAD_MAJOR": True})
 
 
@@ -852,7 +851,7 @@ def msda_encoder_packed(value, level_shapes, packed, num_points, windows, valid_
 
     def run():
         ok[0] = _cabi.msda_encoder_packed(value.contiguous(), level_shapes, packed, num_points, windows, valid_counts,
-                                          MSDA_V4_REGION, MSDA_V4_THREADS, out, MSDA_V4_VARIANT, head_major)
+                                          MSDA_V4_REGION, MSDA_V4_THREADS, out, head_major)
 
     with torch.cuda.device(value.device):
         _timed("msda_fused", {"B": B, "S": S, "Nq": S, "M": M, "D": D, "L": len(level_shapes), "P": num_points},

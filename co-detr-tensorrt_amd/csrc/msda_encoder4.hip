@@ -20,8 +20,9 @@
 //     validity arithmetic: floor + fract + subtract + compare, 2 instructions for the LDS address, 9 for the weights.
 //     Everything else -- samples outside the windows, outside the image, non-finite -- takes the fix-up path, which
 //     re-derives the sample with the reference's full gate / corner logic and reads its rows from global memory.
-//   * PREPARATION UNDER THE DMA.  The addresses / weights of a pass are computed for all of a wave's iterations while
-//     the pass's windows are in flight (LDS-DMA), not after the wait.
+//   * ROW-WISE STAGING from a head-major value map [B][M][S][32] (the value projection writes it that way): a wave takes
+//     window rows, one LDS-DMA instruction moves 16 pixels of a row -- 1 KiB contiguous, 8 whole 128-byte lines -- from a
+//     scalar base; 512 threads on a 16 x 16 region re-stage half as much halo per query as 256 on 16 x 8.
 //   * reference points in fp32 from the valid pixel counts (as v3's CREF form): centre * vc_k / vc_q - 0.5 + offset.
 // Numerics: as v3 -- fp16 corner weights (bilinear x attention), 8-term fp16 chains added into fp32 accumulators; tested
 // against the fp64 oracle at the reference's half tolerance (tests/test_msda_encoder4_gpu.py).
@@ -280,10 +281,10 @@ __device__ __forceinline__ bool prepare(Prep (&pp)[NLV], const Lv (&lv)[kL], con
 }
 
 // gather of one iteration: 4 * NLV sample slots, one per step; rows of step s + 1 requested before the arithmetic of step s
-template <int LV0, int NLV, int DEPTH>
+template <int LV0, int NLV>
 __device__ __forceinline__ void gather(float (&acc)[8], const Prep (&pp)[NLV], const Lv (&lv)[kL], const unsigned lds_lane) {
   using LV = const __attribute__((address_space(3))) f16x8*;
-  constexpr int NS = 4 * NLV, NB = DEPTH + 1;
+  constexpr int NS = 4 * NLV, DEPTH = 1, NB = DEPTH + 1;   // (rows two / three steps ahead measured slower: registers)
   f16x8 rows[NB][4];
   unsigned wA[NB], wB[NB];
   // DPP hazard: a VGPR written by a vector instruction may be read by a DPP instruction only two wait states later.  The
@@ -333,9 +334,9 @@ __device__ __forceinline__ void gather(float (&acc)[8], const Prep (&pp)[NLV], c
 }
 
 // samples the windows do not serve: re-derived with the reference's gate / corner logic (cu:52-71, 249), queued per pair
-// (16-byte records in LDS), and added from global memory by the pair's four lanes, kQ records per round.  Two halves so
-// that the first round's global loads can fly under the iteration's gather loop (PRE): begin() = re-derive, queue, request
-// the rows of round 0; end() = blend them, then further rounds while some pair has records left.
+// (16-byte records in LDS), and added from global memory by the pair's four lanes, kQ records per round (requesting the
+// first round's rows before the gather loop needs 20 more live registers: 91 spills at four waves per SIMD, and level at
+// three -- profiles/r05_msda_encoder4_sweep.txt; not kept).
 template <class ET, int LV0, int NLV>
 struct Fix {
   u32x4 rec[NLV];
@@ -412,25 +413,9 @@ struct Fix {
     bad |= dpp_u<kXor1>(bad);
     cnt = __builtin_popcount(bad);
   }
-  __device__ __forceinline__ void begin(const Lv (&lv)[kL], const float (&aw)[kL], const unsigned (&o2)[kL], float bx, float by,
-                                        u32x4* __restrict__ queue, const unsigned char* __restrict__ vhead,
-                                        const unsigned pix_bytes, const int sub) {
-    derive(lv, aw, o2, bx, by, sub);
-    push(queue, 0, sub);
-    request(queue, 0, vhead, pix_bytes);
-  }
-  __device__ __forceinline__ void end(float (&acc)[8], u32x4* __restrict__ queue, const unsigned char* __restrict__ vhead,
-                                      const unsigned pix_bytes, const int sub) {
-    blend(acc, 0);
-    for (int base = kQ; __builtin_amdgcn_ballot_w64(cnt > base) != 0; base += kQ) {
-      push(queue, base, sub);
-      request(queue, base, vhead, pix_bytes);
-      blend(acc, base);
-    }
-  }
 };
 
-// the same in one piece (no prefetch): every round = queue, request, blend
+// every round = queue, request, blend
 template <class ET, int LV0, int NLV>
 __device__ __forceinline__ void fixup(float (&acc)[8], const Lv (&lv)[kL], const float (&aw)[kL], const unsigned (&o2)[kL],
                                       float bx, float by, u32x4* __restrict__ queue, const unsigned char* __restrict__ vhead,
@@ -445,8 +430,8 @@ __device__ __forceinline__ void fixup(float (&acc)[8], const Lv (&lv)[kL], const
 }
 
 // LDS: [staged rows of ONE pass | fix-up queues (T / 4 pairs x kQ x 16 B)]
-template <class ET, int T, int WPE, bool PRE, int DEPTH = 1, bool AHEAD = true>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void msda_encoder_v4_kernel(
+template <class ET, int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_encoder_v4_kernel(
     const _Float16* __restrict__ value, const unsigned short* __restrict__ packed, unsigned short* __restrict__ out,
     const Geom4 g, const int packed_stride) {
   constexpr unsigned kRow = 64;
@@ -648,37 +633,24 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
         }
       }
     }
-    // -- addresses / weights of the pass for every iteration: under the DMA (AHEAD), or each right before its gather --
-    Prep pp[kMaxIt][NLV];
-    bool clean[kMaxIt];
-#pragma unroll
-    for (int it = 0; it < kMaxIt; ++it) {
-      clean[it] = true;
-#pragma unroll
-      for (int i = 0; i < NLV; ++i) pp[it][i] = Prep{lv[LV0 + i].base, 0u, 0u};
-      if (AHEAD && it < n_it && !(kAbl & 8)) {
-        const bool ok = prepare<ET, LV0, NLV>(pp[it], lv, aw[it], o2[it], bx[it], by[it]);
-        clean[it] = __builtin_amdgcn_ballot_w64(!ok) == 0;
-      }
-    }
     if (!(kAbl & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(kAbl & 16)) __syncthreads();
+    // -- per iteration: addresses / weights of the pass (right in front of their gather: computed for all iterations under
+    // the DMA they cost 12 more live registers and 6 spills at the 128-register budget, and measured 3-5 % slower -- the DMA's
+    // latency is covered by the other workgroup of the CU either way), the gather, then the samples the windows do not serve
 #pragma unroll
     for (int it = 0; it < kMaxIt; ++it)
       if (it < n_it && !(kAbl & 4)) {
-        if (!AHEAD && !(kAbl & 8)) {
-          const bool ok = prepare<ET, LV0, NLV>(pp[it], lv, aw[it], o2[it], bx[it], by[it]);
-          clean[it] = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        Prep pp[NLV];
+#pragma unroll
+        for (int i = 0; i < NLV; ++i) pp[i] = Prep{lv[LV0 + i].base, 0u, 0u};
+        bool clean = true;
+        if (!(kAbl & 8)) {
+          const bool ok = prepare<ET, LV0, NLV>(pp, lv, aw[it], o2[it], bx[it], by[it]);
+          clean = __builtin_amdgcn_ballot_w64(!ok) == 0;
         }
-        if constexpr (PRE) {
-          Fix<ET, LV0, NLV> fx;
-          if (!clean[it]) fx.begin(lv, aw[it], o2[it], bx[it], by[it], queue, vhead, pix_bytes, sub);
-          gather<LV0, NLV, DEPTH>(acc[it], pp[it], lv, lds_lane);
-          if (!clean[it]) fx.end(acc[it], queue, vhead, pix_bytes, sub);
-        } else {
-          gather<LV0, NLV, DEPTH>(acc[it], pp[it], lv, lds_lane);
-          if (!clean[it]) fixup<ET, LV0, NLV>(acc[it], lv, aw[it], o2[it], bx[it], by[it], queue, vhead, pix_bytes, sub);
-        }
+        gather<LV0, NLV>(acc[it], pp, lv, lds_lane);
+        if (!clean) fixup<ET, LV0, NLV>(acc[it], lv, aw[it], o2[it], bx[it], by[it], queue, vhead, pix_bytes, sub);
       }
   };
   run_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -780,7 +752,7 @@ inline Plan4 plan4(const int64_t* shapes, int64_t S, int M, int L, int P, const 
 template <class ET>
 int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void* packed, int64_t packed_stride,
             const float* vcounts, int64_t B, int64_t S, int M, int D, int L, int P, const signed char* win, int region_w,
-            int region_h, int threads, int variant, int head_major, void* out) {
+            int region_h, int threads, int head_major, void* out) {
   if (!value || !shapes || !packed || !vcounts || !win || !out) return CODETR_E_BADARG;
   if (B <= 0 || S <= 0 || M <= 0 || L <= 0 || P <= 0) return CODETR_E_BADARG;
   if (D != 32) return CODETR_E_UNSUPPORTED;
@@ -796,26 +768,12 @@ int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void
   pl.g.vcounts = vcounts;
   pl.g.head_major = head_major ? 1 : 0;
   typedef void (*Kern)(const _Float16*, const unsigned short*, unsigned short*, const Geom4, const int);
-  // variant = kernel build (same results): 0 the default -- four waves per SIMD, rows one step ahead, preparation under the
-  // DMA; 1: rows two steps ahead, preparation right before each gather; 2: three waves per SIMD (168 registers: three
-  // workgroups of <= 53 KB per CU); 3: three waves + the first fix-up round requested before the gather; 4 / 5: three waves,
-  // rows two / three steps ahead; 6: as 0 with the preparation right before each gather; 7: three waves, fix-up prefetch,
-  // rows two steps ahead.  (512 threads: the three-wave builds do not exist, 2-5 and 7 map to four waves.)
-  static const Kern kerns[2][8] = {
-      {msda_encoder_v4_kernel<ET, 256, 4, false, 1, true>, msda_encoder_v4_kernel<ET, 256, 4, false, 2, false>,
-       msda_encoder_v4_kernel<ET, 256, 3, false, 1, true>, msda_encoder_v4_kernel<ET, 256, 3, true, 1, true>,
-       msda_encoder_v4_kernel<ET, 256, 3, false, 2, true>, msda_encoder_v4_kernel<ET, 256, 3, false, 3, true>,
-       msda_encoder_v4_kernel<ET, 256, 4, false, 1, false>, msda_encoder_v4_kernel<ET, 256, 3, true, 2, true>},
-      {msda_encoder_v4_kernel<ET, 512, 4, false, 1, true>, msda_encoder_v4_kernel<ET, 512, 4, false, 2, false>,
-       msda_encoder_v4_kernel<ET, 512, 4, false, 1, true>, msda_encoder_v4_kernel<ET, 512, 4, true, 1, true>,
-       msda_encoder_v4_kernel<ET, 512, 4, false, 2, true>, msda_encoder_v4_kernel<ET, 512, 4, false, 3, true>,
-       msda_encoder_v4_kernel<ET, 512, 4, false, 1, false>, msda_encoder_v4_kernel<ET, 512, 4, true, 2, true>}};
-  const Kern kern = kerns[threads == 512][variant & 7];
+  const Kern kern = threads == 512 ? msda_encoder_v4_kernel<ET, 512> : msda_encoder_v4_kernel<ET, 256>;
   {
     static std::atomic<uint32_t> done[64];   // > 64 KB of dynamic LDS: the attribute is per (device, function); one table per ET
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done[0].store(0);
-    const uint32_t bit = 1u << ((threads == 512 ? 8 : 0) + (variant & 7));
+    const uint32_t bit = threads == 512 ? 2u : 1u;
     if (!(done[dev].load(std::memory_order_acquire) & bit)) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
       if (e != hipSuccess) return (int)e;
@@ -835,23 +793,19 @@ extern "C" {
 int codetr_msda_encoder_forward_packed_f16(void* stream, const void* value_dev, const int64_t* level_shapes_host,
                                            const void* packed_dev, int64_t packed_row_stride, const float* valid_counts_dev,
                                            int64_t B, int64_t S, int M, int D, int L, int P, const int8_t* windows_host,
-                                           int region_w, int region_h, int threads, int variant, int value_head_major,
-                                           void* out_dev) {
-  if (variant < 0 || variant > 7) return CODETR_E_BADARG;
+                                           int region_w, int region_h, int threads, int value_head_major, void* out_dev) {
   return launch4<EF16>(static_cast<hipStream_t>(stream), value_dev, level_shapes_host, packed_dev, packed_row_stride,
                        valid_counts_dev, B, S, M, D, L, P, reinterpret_cast<const signed char*>(windows_host), region_w,
-                       region_h, threads, variant, value_head_major, out_dev);
+                       region_h, threads, value_head_major, out_dev);
 }
 
 int codetr_msda_encoder_forward_packed_bf16(void* stream, const void* value_f16_dev, const int64_t* level_shapes_host,
                                             const void* packed_dev, int64_t packed_row_stride, const float* valid_counts_dev,
                                             int64_t B, int64_t S, int M, int D, int L, int P, const int8_t* windows_host,
-                                            int region_w, int region_h, int threads, int variant, int value_head_major,
-                                            void* out_dev) {
-  if (variant < 0 || variant > 7) return CODETR_E_BADARG;
+                                            int region_w, int region_h, int threads, int value_head_major, void* out_dev) {
   return launch4<EBF16>(static_cast<hipStream_t>(stream), value_f16_dev, level_shapes_host, packed_dev, packed_row_stride,
                         valid_counts_dev, B, S, M, D, L, P, reinterpret_cast<const signed char*>(windows_host), region_w,
-                        region_h, threads, variant, value_head_major, out_dev);
+                        region_h, threads, value_head_major, out_dev);
 }
 
 int64_t codetr_msda_encoder_packed_lds_bytes(const int64_t* level_shapes_host, int M, int L, int P, const int8_t* windows_host,

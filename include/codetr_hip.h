@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 41
+#define CODETR_HIP_ABI_VERSION 42
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -213,9 +213,6 @@ int64_t codetr_msda_encoder_lds_bytes(const int64_t *level_shapes_host, int M, i
  *                     hold at most 3 * threads / 4 queries (CODETR_E_UNSUPPORTED otherwise).
  *   value_head_major  0: value_dev is the op's [B, S, M, D]; 1: [B, M, S, D] (each head's map contiguous, what
  *                     codetr_linear_* writes with hm_head_dim = D): a staged window row is then one contiguous run.
- *   variant           kernel build, same results: bit 0 = the first fix-up round's rows are requested before the gather
- *                     loop of their iteration; bit 1 (256 threads only) = three waves per SIMD (168 registers; meant for
- *                     three workgroups of <= 53 KiB per CU instead of four of <= 40 KiB).
  * Samples outside the windows are added from global memory with the reference's gate / corner logic: windows change
  * speed, never results beyond the rounding of the packed blend (same tolerance statement as the _win entry).
  * codetr_msda_encoder_packed_lds_bytes: LDS bytes per workgroup such a launch needs, or a negative CODETR_E_* code.
@@ -225,7 +222,7 @@ int codetr_msda_encoder_forward_packed_f16(void *stream, const void *value_dev, 
                                            const void *packed_dev, int64_t packed_row_stride,
                                            const float *valid_counts_dev, int64_t B, int64_t S, int M, int D, int L, int P,
                                            const int8_t *windows_host, int region_w, int region_h, int threads,
-                                           int variant, int value_head_major, void *out_dev);
+                                           int value_head_major, void *out_dev);
 /* The same for a bf16 model: packed projection and output are bf16, the VALUE MAP IS FP16 (value_f16_dev; written by
  * codetr_linear_bf16_f16out): the blend runs on packed halves either way -- gfx950 has no packed bf16 FMA -- and an fp16
  * value map keeps three more mantissa bits of the projection's fp32 accumulators than a bf16 one would.  Offsets and logits
@@ -234,7 +231,7 @@ int codetr_msda_encoder_forward_packed_bf16(void *stream, const void *value_f16_
                                             const void *packed_dev, int64_t packed_row_stride,
                                             const float *valid_counts_dev, int64_t B, int64_t S, int M, int D, int L, int P,
                                             const int8_t *windows_host, int region_w, int region_h, int threads,
-                                            int variant, int value_head_major, void *out_dev);
+                                            int value_head_major, void *out_dev);
 int64_t codetr_msda_encoder_packed_lds_bytes(const int64_t *level_shapes_host, int M, int L, int P,
                                              const int8_t *windows_host, int region_w, int region_h, int threads);
 int codetr_msda_pack_projection_index(int M, int L, int P, int32_t *idx_host);

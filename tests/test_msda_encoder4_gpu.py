@@ -82,7 +82,7 @@ def _expect(value, off, logits, counts, shapes, rows=None):
                                           loc.numpy(), w.numpy())
 
 
-def _run(shapes, value, off, logits, counts, cfg, windows, variant=0, head_major=False):
+def _run(shapes, value, off, logits, counts, cfg, windows, head_major=False):
     from codetr import _cabi
 
     threads, region, _ = CFGS[cfg]
@@ -93,7 +93,7 @@ def _run(shapes, value, off, logits, counts, cfg, windows, variant=0, head_major
     if head_major:
         v = v.permute(0, 2, 1, 3).contiguous()
     ok = _cabi.msda_encoder_packed(v, shapes, _pack(off, logits).to(DEV), P, windows, counts.to(DEV), region, threads, out,
-                                   variant, head_major)
+                                   head_major)
     torch.cuda.synchronize()
     assert ok and _cabi.CALLS["msda_encoder_packed"] == before + 1, "the packed encoder kernel did not take the shape"
     return out.float().cpu().numpy()
@@ -145,17 +145,15 @@ def test_windows_change_speed_not_results(cfg):
         _check(_run(PYR_ODD, value, off, logits, counts, cfg, w), expect, name)
 
 
-@pytest.mark.parametrize("variant", range(8))
 @pytest.mark.parametrize("head_major", [False, True], ids=["op_layout", "head_major"])
-def test_every_kernel_build_and_both_value_layouts(variant, head_major):
-    """the eight builds behind `variant` (rows one / two / three steps ahead, preparation under the DMA or in front of each
-    gather, three waves per SIMD, fix-up prefetch) and the head-major value map: same results; offsets partly beyond the
-    windows so that the fix-up path runs in every build"""
-    value, off, logits, counts, S = _inputs(PYR_ODD, 2, 3.0, seed=300 + variant)
+@pytest.mark.parametrize("seed", [300, 301, 302])
+def test_both_value_layouts(seed, head_major):
+    """the op's [B, S, M, D] value map and the head-major [B, M, S, D] one the product's value projection writes: same
+    results; offsets partly beyond the windows so that the fix-up path runs"""
+    value, off, logits, counts, S = _inputs(PYR_ODD, 2, 3.0, seed=seed)
     expect = _expect(value, off, logits, counts, PYR_ODD)
     for cfg in CFGS:
-        _check(_run(PYR_ODD, value, off, logits, counts, cfg, _halo(3), variant, head_major), expect,
-               f"{cfg} variant {variant} head_major {head_major}")
+        _check(_run(PYR_ODD, value, off, logits, counts, cfg, _halo(3), head_major), expect, f"{cfg} head_major {head_major}")
 
 
 @pytest.mark.parametrize("cfg", list(CFGS))
@@ -177,7 +175,7 @@ def test_bf16_model_packed_projection_and_output_fp16_value_map(cfg, head_major)
     if head_major:
         v = v.permute(0, 2, 1, 3).contiguous()
     assert _cabi.msda_encoder_packed(v, PYR_ODD, _pack(off, logits).to(DEV), P, _halo(3), counts.to(DEV), region, threads, out,
-                                     6, head_major)
+                                     head_major)
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()
     np.testing.assert_allclose(got, expect, rtol=1e-2, atol=2e-3)

@@ -6,7 +6,7 @@ at their measured-best defaults, and this tool patches them from the OUTSIDE bef
     python tools/ab_host_routes.py --list
 
 Switch names: hip_ops.{LN_GEMM, XADD, XADD_MIN_ROWS, MERGE_LN, MSDA_ENCODER, MSDA_HALO, MSDA_WINDOWS, MSDA_PASSES,
-MSDA_FP32_REF, MSDA_V4, FP8_MIN_TILES}, transformer.{DEC_FUSED, DEC_VPROJ}, multi_scale_deformable_attention.HEAD_MAJOR_VALUE."""
+MSDA_FP32_REF, MSDA_V4 (+ _THREADS, _REGION, _LDS_BUDGET, _MARGIN_CAP, _HEAD_MAJOR), FP8_MIN_TILES}, transformer.{DEC_FUSED, DEC_VPROJ}, multi_scale_deformable_attention.HEAD_MAJOR_VALUE."""
 import argparse
 import os
 import runpy

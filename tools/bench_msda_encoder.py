@@ -27,7 +27,6 @@ def main():
     ap.add_argument("--budget", type=int, default=0, help="LDS bytes per workgroup (default 40 KiB x 256 / threads ... see code)")
     ap.add_argument("--cap", type=float, default=40.0, help="largest window margin in pixels")
     ap.add_argument("--hm", type=int, default=1, help="1: head-major value map [B, M, S, D]")
-    ap.add_argument("--variant", type=int, default=6, help="v4 kernel build: bit 0 fix-up prefetch, bit 1 three waves per SIMD")
     a = ap.parse_args()
     from codetr import _cabi, hip_ops
 
@@ -76,7 +75,6 @@ def main():
         hip_ops.MSDA_V4_REGION = tuple(int(v) for v in a.region.split("x"))
         hip_ops.MSDA_V4_LDS_BUDGET = a.budget if a.budget else (40 * 1024 if a.threads == 256 else 64 * 1024)
         hip_ops.MSDA_V4_MARGIN_CAP = a.cap
-        hip_ops.MSDA_V4_VARIANT = a.variant
         idx = torch.tensor(_cabi.msda_pack_projection_index(M, L, P), device=dev)
         packed = proj[..., idx.clamp_min(0)].clone()
         packed[..., idx < 0] = 0
@@ -98,7 +96,7 @@ def main():
     print(f"batch {B} noise {a.noise} halo {hip_ops.MSDA_HALO}: encoder kernel {t_enc:8.1f} us "
           f"({alg / t_enc / 1e6:6.2f} TB/s algorithmic)   general fused {t_gen:8.1f} us   identical: {same} "
           f"rel L2 vs general {rel:.2e}  windows {'bias' if a.windows else 'halo'} passes {a.passes} counts {a.counts}"
-          + (f"  v4 threads {a.threads} region {a.region} cap {a.cap} variant {a.variant} hm {a.hm} budget {hip_ops.MSDA_V4_LDS_BUDGET}" if a.v4 else ""))
+          + (f"  v4 threads {a.threads} region {a.region} cap {a.cap} hm {a.hm} budget {hip_ops.MSDA_V4_LDS_BUDGET}" if a.v4 else ""))
 
 
 if __name__ == "__main__":
