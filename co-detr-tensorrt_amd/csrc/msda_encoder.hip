@@ -50,9 +50,7 @@ constexpr int kMaxL = 8;
 constexpr int kMaxM = 16;      // heads with a staged window of their own
 constexpr int kMetaInts = 28;  // per level: 7 x 16 B (see region_geometry)
 constexpr int kMaxLds = 160 * 1024;
-constexpr int kPad = 64;       // one row slot in front of and behind the staged rows (see process_v2)
-constexpr int kQueue = 4;      // v2: fix-up records per (query, head) pair and pass
-constexpr int kPre = 2;        // v2: fix-up rounds whose global loads fly under the gather loop
+constexpr int kPad = 64;       // one row slot in front of and behind the staged rows (see pass_v3)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -620,7 +618,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // =====================================================================================================================
-// v2 (fp16, num_levels == 5, num_points == 4: the model's shape).  Same staging, different gather:
+// Packed-half gather (fp16, num_levels == 5, num_points == 4: the model's shape) -- round 3.  Its single-pass kernel ("v2")
+// was deleted in round 5 (the round-5 kernel of msda_encoder4.hip serves every 5 x 4 pyramid); the three-pass form below ("v3")
+// stays as the A/B baseline behind hip_ops.MSDA_V4 = False.  What the packed form does:
 //   * the blend runs on packed halves: per step (2 points = 8 corner rows) a lane multiplies its 8 channels of each
 //     row by the corner's weight with v_pk_fma_f16 (2 MACs per instruction; the fp32 v_fma_mix_f32 blend issues at
 //     the same ~4.4 cycles per instruction per SIMD for ONE MAC: tools/micro/valu_rates.hip) into an 8-term fp16
@@ -670,306 +670,6 @@ __device__ __forceinline__ int med3_i(int a, int b, int c) {
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-
-template <class TR, int DEPTH, int KPRE, bool SCHED, int ABL = 0>
-__device__ __forceinline__ void process_v2(const Raw<TR, 5>& raw, const int q, const bool valid,
-                                           const int* __restrict__ s_meta, const unsigned char* __restrict__ patch,
-                                           u32x4* __restrict__ queue, const unsigned char* __restrict__ vimg,
-                                           const unsigned pix_bytes, typename TR::storage* __restrict__ out,
-                                           const size_t out_row, const EncGeom& g, const int sub) {
-  using V = typename TR::vec;
-  constexpr int K = 5;
-  constexpr unsigned kRow = 64;
-  const unsigned lane_byte = (unsigned)sub * 16;
-  const int M = g.M;
-  // -- softmax over the pair's 20 logits (quad reductions) --
-  float pw_[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) pw_[k] = TR::to_f32(raw.w[k]);
-  float mx = pw_[0];
-#pragma unroll
-  for (int k = 1; k < K; ++k) mx = fmaxf(mx, pw_[k]);
-  mx = fmaxf(mx, dpp_f<kXor2>(mx));
-  mx = fmaxf(mx, dpp_f<kXor1>(mx));
-  float sum = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    pw_[k] = __expf(pw_[k] - mx);
-    sum += pw_[k];
-  }
-  sum += dpp_f<kXor2>(sum);
-  sum += dpp_f<kXor1>(sum);
-  const float inv = __builtin_amdgcn_rcpf(sum);   // (1 ulp; the weights are rounded to fp16 next)
-
-  // -- own points (point `sub` of every level) -> LDS row addresses, packed weights, out-of-window flags --
-  unsigned ad0[K], ad1[K], mw01[K], mw23[K], rw01[K], rw23[K], hw[K];
-  unsigned bad = 0;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (ABL & 4) {   // timing experiment: no sample preparation
-      ad0[k] = ad1[k] = (unsigned)((q + k) & 255) * 64u;
-      mw01[k] = mw23[k] = rw01[k] = rw23[k] = 0x2c002c00u;
-      hw[k] = 0;
-      continue;
-    }
-    const int* mt = s_meta + k * kMetaInts;
-    const i32x4_t mA = *reinterpret_cast<const i32x4_t*>(mt + 16);  // 1/W, 1/H (float bits), x lo, x hi
-    const i32x4_t mB = *reinterpret_cast<const i32x4_t*>(mt + 20);  // y lo, y hi, row pitch, address constant
-    const int H = g.H[k], W = g.W[k];
-    const float Hf = (float)H, Wf = (float)W;
-    const float x = fmaf(TR::to_f32(raw.o[k].a), __int_as_float(mA[0]), TR::to_f32(raw.r[k].a));
-    const float y = fmaf(TR::to_f32(raw.o[k].b), __int_as_float(mA[1]), TR::to_f32(raw.r[k].b));
-    const float h_im = fmaf(y, Hf, -0.5f);
-    const float w_im = fmaf(x, Wf, -0.5f);
-    const bool gate = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;  // cu:249
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const float lh = h_im - hf, lw = w_im - wf;
-    const int h0 = gate ? (int)hf : 0, w0 = gate ? (int)wf : 0;
-    const float aw = gate ? pw_[k] * inv : 0.f;
-    // corners outside the image carry no weight (cu:52-71)
-    const float wy0 = hf >= 0.f ? (1.f - lh) * aw : 0.f, wy1 = hf + 1.f < Hf ? lh * aw : 0.f;
-    const float wx0 = wf >= 0.f ? 1.f - lw : 0.f, wx1 = wf + 1.f < Wf ? lw : 0.f;
-    rw01[k] = pack_h2(wy0 * wx0, wy0 * wx1);
-    rw23[k] = pack_h2(wy1 * wx0, wy1 * wx1);
-    const int tx = med3_i(w0, mA[2], mA[3]), ty = med3_i(h0, mB[0], mB[1]);
-    const bool isbad = gate && !(tx == w0 && ty == h0);
-    mw01[k] = isbad ? 0u : rw01[k];
-    mw23[k] = isbad ? 0u : rw23[k];
-    hw[k] = ((unsigned)h0 << 16) | ((unsigned)w0 & 0xffffu);
-    const int xo = tx * (int)kRow + mB[3];
-    ad0[k] = (unsigned)(max(ty, 0) * mB[2] + xo);
-    ad1[k] = (unsigned)(min(ty + 1, H - 1) * mB[2] + xo);
-    bad |= isbad ? 1u << (sub + 4 * k) : 0u;
-  }
-  bad |= dpp_u<kXor2>(bad);
-  bad |= dpp_u<kXor1>(bad);
-  const int cnt = __builtin_popcount(bad);
-
-  // the owner lanes append their out-of-window points [base, base + kQueue) of the pair to its queue
-  auto push = [&](int base) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int pt = sub + 4 * k;
-      if ((bad >> pt) & 1u) {
-        const int pos = __builtin_popcount(bad & ((1u << pt) - 1u)) - base;
-        if ((unsigned)pos < (unsigned)kQueue) queue[pos] = u32x4{hw[k], (unsigned)k, rw01[k], rw23[k]};
-      }
-    }
-  };
-  struct Fix {
-    V rows[4];
-    u32x4 rec;
-  };
-  auto fix_issue = [&](Fix& f, int j, bool act) {
-    if (act) {
-      f.rec = queue[j];
-      const int* mt = s_meta + (int)f.rec[1] * kMetaInts;
-      const int H = mt[0], W = mt[1];
-      const unsigned st = (unsigned)mt[2];
-      const int h0 = (int)(short)(f.rec[0] >> 16), w0 = (int)(short)(f.rec[0] & 0xffffu);
-      const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
-      const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
-      const unsigned char* vb = vimg + lane_byte;
-      f.rows[0] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h0c * W + w0c)) * pix_bytes));
-      f.rows[1] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h0c * W + w1c)) * pix_bytes));
-      f.rows[2] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h1c * W + w0c)) * pix_bytes));
-      f.rows[3] = *reinterpret_cast<const V*>(vb + (size_t)((st + (unsigned)(h1c * W + w1c)) * pix_bytes));
-    }
-  };
-  float acc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  auto fix_apply = [&](const Fix& f, bool act) {
-    if (act) {
-      const h2 a = as_h2(f.rec[2]), b = as_h2(f.rec[3]);
-      const float w[4] = {(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(w[c], TR::to_f32(f.rows[c][j]), acc[j]);
-    }
-  };
-
-  push(0);
-  Fix pre[KPRE > 0 ? KPRE : 1];
-#pragma unroll
-  for (int j = 0; j < KPRE; ++j) fix_issue(pre[j], j, j < cnt);
-
-  // -- gather loop: 10 steps of 2 points; the rows of step s + 1 are requested before the arithmetic of step s --
-  {
-    constexpr int NS = 2 * K, NB = DEPTH + 1;
-    V rows[NB][2][4];
-    unsigned wA[NB][2], wB[NB][2];
-    auto fetch = [&](int s_, int buf) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int pt = 2 * s_ + u, o = pt & 3, k = pt >> 2;
-        const unsigned a0 = quad_bcast_add(ad0[k], o, lane_byte), a1 = quad_bcast_add(ad1[k], o, lane_byte);
-        wA[buf][u] = quad_bcast_u(mw01[k], o);
-        wB[buf][u] = quad_bcast_u(mw23[k], o);
-        if (ABL & 1) {   // timing experiment: no LDS reads
-          const _Float16 c0 = (_Float16)(int)(a0 >> 6), c1 = (_Float16)(int)(a1 >> 6);
-          rows[buf][u][0] = rows[buf][u][1] = V{c0, c0, c0, c0, c0, c0, c0, c0};
-          rows[buf][u][2] = rows[buf][u][3] = V{c1, c1, c1, c1, c1, c1, c1, c1};
-          continue;
-        }
-        rows[buf][u][0] = *reinterpret_cast<const V*>(patch + a0);
-        rows[buf][u][1] = *reinterpret_cast<const V*>(patch + a0 + kRow);
-        rows[buf][u][2] = *reinterpret_cast<const V*>(patch + a1);
-        rows[buf][u][3] = *reinterpret_cast<const V*>(patch + a1 + kRow);
-      }
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) fetch(d, d);
-#pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_) {
-      const int b = s_ % NB;
-      if (s_ + DEPTH < NS) fetch(s_ + DEPTH, (s_ + DEPTH) % NB);
-      h2 h[4];
-      if (ABL & 2) {   // timing experiment: no blend (one add per row keeps the reads alive)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int cr = 0; cr < 4; ++cr) acc[cr + 4 * u] += (float)rows[b][u][cr][0] * __uint_as_float(wA[b][u] ^ wB[b][u]);
-        continue;
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const h2 a = as_h2(wA[b][u]), c = as_h2(wB[b][u]);
-        const h2 w4[4] = {h2{a[0], a[0]}, h2{a[1], a[1]}, h2{c[0], c[0]}, h2{c[1], c[1]}};
-#pragma unroll
-        for (int cr = 0; cr < 4; ++cr) {
-          const V r = rows[b][u][cr];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const h2 v = {r[2 * j], r[2 * j + 1]};
-            h[j] = (u == 0 && cr == 0) ? v * w4[cr] : __builtin_elementwise_fma(v, w4[cr], h[j]);
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc_h2(acc[2 * j], acc[2 * j + 1], h[j]);
-      if (SCHED) __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
-#pragma unroll
-  for (int j = 0; j < KPRE; ++j) fix_apply(pre[j], j < cnt);
-  if (__builtin_amdgcn_ballot_w64(cnt > KPRE) != 0) {  // rare: more out-of-window points than prefetched rounds
-    for (int base = 0; __builtin_amdgcn_ballot_w64(cnt > base) != 0; base += kQueue) {
-      if (base > 0) push(base);
-      for (int j = base == 0 ? KPRE : 0; j < kQueue; ++j) {
-        const bool act = base + j < cnt;
-        if (__builtin_amdgcn_ballot_w64(act) == 0) break;
-        Fix f;
-        fix_issue(f, j, act);
-        fix_apply(f, act);
-      }
-    }
-  }
-
-  if (valid) {
-    V packed;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) packed[j] = TR::from_f32(acc[j]);
-    *reinterpret_cast<V*>(reinterpret_cast<unsigned char*>(out) + (out_row + (size_t)q * M) * kRow + lane_byte) = packed;
-  }
-}
-
-// LDS: [pad 64 B | staged rows | pad 64 B | fix-up queues 4 KB | geometry table]
-template <class TR, int DEPTH, int KPRE, bool SCHED, int ABL>
-__device__ __forceinline__ void encoder_v2_body(
-    const typename TR::storage* __restrict__ value, const typename TR::storage* __restrict__ offs,
-    const typename TR::storage* __restrict__ logits, const typename TR::storage* __restrict__ ref,
-    typename TR::storage* __restrict__ out, const EncGeom& g, const int off_stride, const int logit_stride) {
-  using S = typename TR::storage;
-  constexpr unsigned kRow = 64;
-  constexpr int KMAX = 5;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* patch = smem + kPad;
-  u32x4* queues = reinterpret_cast<u32x4*>(smem + 2 * kPad + (size_t)g.rows_cap * kRow);
-  int* s_meta = reinterpret_cast<int*>(queues + (kThreads / 4) * kQueue);
-
-  const int tid = threadIdx.x;
-  const int L = KMAX, P = 4, M = g.M;
-  const int wave = tid >> 6, lane = tid & 63, sub = lane & 3, pl = lane >> 2;
-  const unsigned pix_bytes = (unsigned)M * kRow;
-
-  const TileId t = decode_tile(xcd_tile(blockIdx.x, gridDim.x), g);
-  region_geometry(s_meta, g, t, tid);
-  const int total = s_meta[kMaxL * kMetaInts];
-  const int n_it = total > wave * 16 ? (total - wave * 16 + 63) >> 6 : 0;
-
-  const size_t row0 = (size_t)t.b * g.S;
-  Raw<TR, KMAX> raws[kAhead];
-  int qs[kAhead];
-#pragma unroll
-  for (int a = 0; a < kAhead; ++a) {
-    qs[a] = 0;
-    if (a < n_it) {
-      const int sl = (a * 4 + wave) * 16 + pl;
-      qs[a] = slot_query(s_meta, L, sl < total ? sl : total - 1);
-      load_raw<TR, KMAX, true>(raws[a], offs, logits, ref, row0 + qs[a], t.m, sub, L, P, off_stride, logit_stride);
-    }
-  }
-
-  const unsigned char* vimg = reinterpret_cast<const unsigned char*>(value) + (size_t)t.b * g.S * M * kRow + t.m * kRow;
-  for (int l = 0; l < ((ABL & 8) ? 0 : L); ++l) {
-    const int* mt = s_meta + l * kMetaInts;
-    const int W = mt[1], pw = mt[5];
-    const int n = pw * mt[6] * 4;  // 16-byte pieces
-    const float inv = __frcp_rn((float)pw);
-    const unsigned src0 = (unsigned)(mt[2] + mt[4] * W + mt[3]) * pix_bytes + (unsigned)(lane & 3) * 16;
-    unsigned char* dst0 = patch + (size_t)mt[7] * kRow;
-    for (int e0 = wave * 64; e0 < n; e0 += kThreads) {
-      const int row = (e0 + lane) >> 2;
-      if (e0 + lane < n) {
-        const int y = (int)(((float)row + 0.5f) * inv);
-        const unsigned char* gp = vimg + (src0 + (unsigned)(y * (W - pw) + row) * pix_bytes);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                         (__attribute__((address_space(3))) void*)(dst0 + (size_t)e0 * 16), 16, 0, 0);
-      }
-    }
-  }
-  // the slots in front of the first and behind the last staged row are read with zero weight (x0 = -1, x1 = W):
-  // they must hold finite values
-  if (tid < 8) {
-    const int* mt = s_meta + (L - 1) * kMetaInts;
-    const unsigned end = (unsigned)(mt[7] + mt[5] * mt[6]) * kRow;
-    *reinterpret_cast<u32x4*>(tid < 4 ? smem + tid * 16 : patch + end + (tid - 4) * 16) = u32x4{0u, 0u, 0u, 0u};
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  u32x4* queue = queues + (size_t)(wave * 16 + pl) * kQueue;
-  const size_t out_row = row0 * M + t.m;
-  for (int it = 0; it < n_it; ++it) {
-    const bool valid = (it * 4 + wave) * 16 + pl < total;
-    const Raw<TR, KMAX> raw = raws[0];
-    const int q = qs[0];
-#pragma unroll
-    for (int a = 0; a + 1 < kAhead; ++a) {
-      raws[a] = raws[a + 1];
-      qs[a] = qs[a + 1];
-    }
-    if (it + kAhead < n_it) {
-      const int sl = ((it + kAhead) * 4 + wave) * 16 + pl;
-      qs[kAhead - 1] = slot_query(s_meta, L, sl < total ? sl : total - 1);
-      load_raw<TR, KMAX, true>(raws[kAhead - 1], offs, logits, ref, row0 + qs[kAhead - 1], t.m, sub, L, P, off_stride,
-                               logit_stride);
-    }
-    process_v2<TR, DEPTH, KPRE, SCHED, ABL>(raw, q, valid, s_meta, patch, queue, vimg, pix_bytes, out, out_row, g, sub);
-  }
-}
-
-template <class TR, int DEPTH = 1, int KPRE = kPre, bool SCHED = true, int ABL = 0>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void msda_encoder_v2_kernel(
-    const typename TR::storage* __restrict__ value, const typename TR::storage* __restrict__ offs,
-    const typename TR::storage* __restrict__ logits, const typename TR::storage* __restrict__ ref,
-    typename TR::storage* __restrict__ out, const EncGeom g, const int off_stride, const int logit_stride) {
-  encoder_v2_body<TR, DEPTH, KPRE, SCHED, ABL>(value, offs, logits, ref, out, g, off_stride, logit_stride);
-}
-// three workgroups per CU (<= 53 KB of LDS each, <= 168 registers)
 
 // =====================================================================================================================
 // v3 (fp16, 5 levels x 4 points): v2's packed-half gather, restructured for OCCUPANCY.
@@ -1282,7 +982,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
 // LDS bytes the kernels need for these windows (0: not representable), and the geometry for the launch
 struct EncPlan {
   EncGeom g;
-  size_t lds_v1, lds_v2, lds_v3;   // bytes per workgroup of the generic / packed single-pass / three-pass kernels
+  size_t lds_v1, lds_v3;   // bytes per workgroup of the generic single-pass / the three-pass kernel
   int rows_cap3;                    // v3: the largest pass
   int rc;
 };
@@ -1369,7 +1069,6 @@ inline EncPlan plan_encoder(const int64_t* shapes, int64_t S, int M, int L, int 
   g.slots_cap = slots;
   pl.rows_cap3 = rows_cap3;
   pl.lds_v1 = 2 * kPad + (size_t)rows_cap * 64 + kMetaStride * sizeof(int);
-  pl.lds_v2 = pl.lds_v1 + (size_t)(kThreads / 4) * kQueue * 16;
   pl.lds_v3 = 2 * kPad + (size_t)rows_cap3 * 64 + kMetaStride * sizeof(int) + (size_t)(kThreads / 4) * kQ3 * 16;
   pl.rc = 0;
   return pl;
@@ -1399,13 +1098,11 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
   // experiments build this file with -DMSDA_ENC_ABLATE, which reads its knobs through tools/micro/diag_env.h.)
 #ifdef MSDA_ENC_ABLATE
   static const int ablate = diag_env_int("CODETR_MSDA_ENC_ABLATE", 0);
-  static const int v2_cfg = diag_env_int("CODETR_MSDA_V2_CFG", 0);
 #else
   constexpr int ablate = 0;
-  constexpr int v2_cfg = 0;
 #endif
   constexpr int band_env = kBand;
-  constexpr bool static_env = true, v2_env = true;
+  constexpr bool static_env = true;
   g.band = band_env < 1 ? 1 : (band_env > 64 ? 64 : band_env);
   if (passes == 3) {   // three-pass kernel: fp16, 5 levels x 4 points, regions of <= 64 * kMaxIt queries
     if (!std::is_same<TR, F16>::value || P != 4 || L != 5 || g.slots_cap > 64 * kMaxIt || pl.lds_v3 > (size_t)kMaxLds ||
@@ -1431,51 +1128,29 @@ int launch_encoder(hipStream_t st, const void* value, const int64_t* shapes, con
     const hipError_t err3 = hipGetLastError();
     return err3 == hipSuccess ? 0 : (int)err3;
   }
-  const bool v2 = std::is_same<TR, F16>::value && P == 4 && L == 5 && v2_env;
-  const size_t lds = v2 ? pl.lds_v2 : pl.lds_v1;
+  const size_t lds = pl.lds_v1;
   if (lds > (size_t)kMaxLds) return CODETR_E_UNSUPPORTED;
   const int kmax5 = L * P <= 20;
   auto kern = P == 4 ? (kmax5 ? (L == 5 && static_env ? msda_encoder_kernel<TR, 5, true, true> : msda_encoder_kernel<TR, 5, true>)
                               : msda_encoder_kernel<TR, 8, true>)
                      : (kmax5 ? msda_encoder_kernel<TR, 5, false> : msda_encoder_kernel<TR, 8, false>);
-  typedef void (*V2Fn)(const _Float16*, const _Float16*, const _Float16*, const _Float16*, _Float16*, const EncGeom, const int, const int);
-  V2Fn v2fn = msda_encoder_v2_kernel<F16>;
-#ifdef MSDA_ENC_ABLATE   // timing experiments only: WRONG results
-  switch (v2_cfg) {
-    case 101: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 1>; break;
-    case 102: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 2>; break;
-    case 103: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 3>; break;
-    case 104: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 4>; break;
-    case 108: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 8>; break;
-    case 107: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 7>; break;
-    case 115: v2fn = msda_encoder_v2_kernel<F16, 1, kPre, true, 15>; break;
-    default: break;
-  }
-#endif
-  const void* kfn = v2 ? reinterpret_cast<const void*>(v2fn) : reinterpret_cast<const void*>(kern);
+  const void* kfn = reinterpret_cast<const void*>(kern);
   // > 64 KB of dynamic LDS needs the attribute on the CURRENT device's function object: remembered per (device, kernel)
   // -- a process-wide "already set" flag would skip it when the process moves to a second GPU
   {
     static std::atomic<uint32_t> done[64];  // bit = kernel instantiation, index = device ordinal
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done[0].store(0);
-    const uint32_t bit = v2 ? 1u << (16 + v2_cfg % 8)
-                            : 1u << (kmax5 + 2 * (P == 4) + 4 * (P == 4 && L == 5 && static_env) + 8 * std::is_same<TR, BF16>::value);
+    const uint32_t bit = 1u << (kmax5 + 2 * (P == 4) + 4 * (P == 4 && L == 5 && static_env) + 8 * std::is_same<TR, BF16>::value);
     if (!(done[dev].load(std::memory_order_acquire) & bit)) {
       const hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
       if (e != hipSuccess) return (int)e;
       done[dev].fetch_or(bit, std::memory_order_release);
     }
   }
-  if (v2)
-    hipLaunchKernelGGL(v2fn, dim3((unsigned)blocks), dim3(kThreads), lds, st,
-                       static_cast<const _Float16*>(value), static_cast<const _Float16*>(offs),
-                       static_cast<const _Float16*>(logits), static_cast<const _Float16*>(ref),
-                       static_cast<_Float16*>(out), g, (int)off_stride, (int)logit_stride);
-  else
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, st, static_cast<const ST*>(value),
-                       static_cast<const ST*>(offs), static_cast<const ST*>(logits), static_cast<const ST*>(ref),
-                       static_cast<ST*>(out), g, (int)off_stride, (int)logit_stride, ablate);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, st, static_cast<const ST*>(value),
+                     static_cast<const ST*>(offs), static_cast<const ST*>(logits), static_cast<const ST*>(ref),
+                     static_cast<ST*>(out), g, (int)off_stride, (int)logit_stride, ablate);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -1553,7 +1228,7 @@ int64_t codetr_msda_encoder_lds_bytes(const int64_t* level_shapes_host, int M, i
   const EncPlan pl = plan_encoder(level_shapes_host, S, M, L, P, reinterpret_cast<const signed char*>(windows_host));
   if (pl.rc != 0) return pl.rc;
   if (variant == 3) return L == 5 && P == 4 && pl.g.slots_cap <= 64 * kMaxIt ? (int64_t)pl.lds_v3 : (int64_t)CODETR_E_UNSUPPORTED;
-  return (int64_t)(variant == 2 && P == 4 && L == 5 ? pl.lds_v2 : pl.lds_v1);
+  return (int64_t)pl.lds_v1;   // (variant 2, the round-3 single-pass packed kernel, is gone: its shapes take the generic one)
 }
 
 }  // extern "C"

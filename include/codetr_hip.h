@@ -163,7 +163,8 @@ int codetr_msda_encoder_forward_bf16(void *stream, const void *value_dev, const 
  *                     (-h, h, -h, h).  A trained head's offsets lean one way (the reference initialises head m along
  *                     the angle 2 pi m / M, multi_scale_deformable_attention.py:90-115): the host derives the windows
  *                     from sampling_offsets.bias so that the same LDS covers more of what the head actually samples.
- *   passes            1: all levels staged at once (<= 80 KiB per workgroup keeps two per CU);
+ *   passes            1: all levels staged at once (<= 80 KiB per workgroup keeps two per CU), the general kernel's fp32
+ *                     arithmetic: bit-identical to codetr_msda_fused_forward_*;
  *                     3: fp16, L == 5, P == 4 only (CODETR_E_UNSUPPORTED otherwise): levels {0}, {1, 2}, {3, 4} staged
  *                     one pass after the other, accumulators kept in registers -- <= 40 KiB and <= 128 registers per
  *                     workgroup, four per CU, wider windows in the same LDS.
@@ -178,8 +179,8 @@ int codetr_msda_encoder_forward_bf16(void *stream, const void *value_dev, const 
  * are added in fp32): within rtol 1e-2 / atol 1e-3 of the fp64 oracle (the reference's own half tolerance,
  * tests/test_multi_scale_deformable_attention.py:62, 363-364), not
  * bit-identical to codetr_msda_fused_forward_f16.
- * codetr_msda_encoder_lds_bytes: LDS bytes per workgroup a launch would need (variant 1: generic single pass, 2: packed
- * single pass, 3: three passes), or a negative CODETR_E_* code. */
+ * codetr_msda_encoder_lds_bytes: LDS bytes per workgroup a launch would need (variant 1 or 2: the single-pass kernel -- the
+ * packed single-pass form of round 3 was deleted in round 5 --, 3: three passes), or a negative CODETR_E_* code. */
 int codetr_msda_encoder_forward_win_f16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
                                         const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
                                         int64_t logits_row_stride, const void *ref_dev, const float *valid_counts_dev,
