@@ -42,7 +42,10 @@ namespace {
 constexpr int kL = 5, kP = 4;
 constexpr int kMaxM = 16;     // heads with a staged window of their own
 constexpr int kMaxIt = 3;     // iterations (16 queries each) per wave
-constexpr int kQ = 2;         // fix-up records per (query, head) pair and queue round
+#ifndef MSDA4_KQ
+#define MSDA4_KQ 2
+#endif
+constexpr int kQ = MSDA4_KQ;  // fix-up records per (query, head) pair and queue round
 constexpr int kMaxLds = 160 * 1024;
 #ifndef MSDA4_BAND
 #define MSDA4_BAND 4
