@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -54,6 +54,8 @@ SIGNATURES = {
     "codetr_msda_encoder_forward_packed_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
                                                        _vp, _i32, _i32, _i32, _i32, _vp]),
     "codetr_linear_bf16_f16out": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32]),
+    "codetr_encoder_projections_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32]),
+    "codetr_encoder_projections_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32]),
     "codetr_msda_encoder_packed_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32]),
     "codetr_msda_pack_projection_index": (_i32, [_i32, _i32, _i32, _vp]),
     "codetr_mx_scale_bytes": (_i64, [_i64, _i64]),
@@ -152,7 +154,7 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "msda_encoder_packed": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
-         "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0,
+         "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0, "encoder_projections": 0,
          "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0, "ffn_fp8": 0, "decoder_layer": 0}
 
 
@@ -654,6 +656,33 @@ def linear_bf16_f16out(x2d, weight, bias, out2d, row_mask=None, hm_rows=0, hm_he
     check(rc, "codetr_linear_bf16_f16out")
     CALLS["linear"] += 1
     CALLS["linear_xs"] += 1
+    return True
+
+
+def encoder_projections(x2d, pos2d, w_cat, bias_cat, row_mask, value_out, packed_out, hm_rows=0, hm_head_dim=0) -> bool:
+    """ONE launch: value_out = x @ w_cat[:Nv]^T + b[:Nv] (row mask, head-major destination as `linear`; FP16 for a bf16
+    model) and packed_out [M, Np] = (x + pos) @ w_cat[Nv:]^T + b[Nv:] (include/codetr_hip.h codetr_encoder_projections_*).
+    Nv = value_out.numel() / M, Np = packed_out.shape[1].  False when the library declines the shape."""
+    lib = load()
+    M, K = x2d.shape
+    Np = packed_out.shape[1]
+    Nv = w_cat.shape[0] - Np
+    if x2d.dtype == torch.bfloat16:
+        fn, vt = lib.codetr_encoder_projections_bf16, torch.float16
+    else:
+        fn, vt = lib.codetr_encoder_projections_f16, torch.float16
+    if (x2d.dtype not in (torch.float16, torch.bfloat16) or value_out.dtype != vt or packed_out.dtype != x2d.dtype
+            or pos2d.dtype != x2d.dtype or w_cat.dtype != x2d.dtype or bias_cat.dtype != x2d.dtype
+            or value_out.numel() != M * Nv or pos2d.shape != x2d.shape):
+        raise ValueError("encoder_projections: operand types / shapes")
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), pos2d.data_ptr(), w_cat.data_ptr(), bias_cat.data_ptr(),
+            row_mask.data_ptr() if row_mask is not None else None, value_out.data_ptr(), packed_out.data_ptr(), M, Nv, Np, K,
+            hm_rows, hm_head_dim)
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "codetr_encoder_projections")
+    CALLS["linear"] += 1
+    CALLS["encoder_projections"] += 1
     return True
 
 

@@ -178,9 +178,11 @@ def linear_ln(x, norm_weight, norm_bias, eps, weight, bias=None, act=None):
 
 
 XADD = True   # route switch: False = `query + query_pos` as its own kernel / FFN output
-# Below this many rows the 256-tile GEMM on a stored `query + query_pos` wins over the X-stationary kernel with the add
-# folded in (measured: one 1920x1280 image, 204 600 rows, +0.09 ms per forward; four images -0.35 ms)
-XADD_MIN_ROWS = 400000
+# Rows from which `query + query_pos` is added inside the X-stationary kernel's operand load.  Until the encoder's two
+# projections became one launch (encoder_projections) the 256-tile GEMM on a stored sum won below 400 000 rows (one
+# 1920x1280 image: +0.09 ms per forward with the add folded in); with the one-launch form the fold wins at every size the
+# kernel takes (one 1920x1280 image 13.14 -> 13.07 ms, one 1152x768 image 7.18 -> 7.15 ms), so the threshold is 0.
+XADD_MIN_ROWS = 0
 
 
 def linear_xadd_supported(x, x_add, weight):
@@ -634,7 +636,7 @@ MSDA_FP32_REF = True    # False = reference points read in the model dtype
 MSDA_LDS_BUDGET = {1: 80 * 1024, 3: 40 * 1024}   # bytes per workgroup: two / four workgroups per CU share 160 KiB
 
 
-_SWITCH_DEFAULTS = {"LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 400000, "MERGE_LN": True, "MSDA_ENCODER": True,
+_SWITCH_DEFAULTS = {"LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
                     "MSDA_HALO": 4, "MSDA_WINDOWS": True, "MSDA_PASSES": 3, "MSDA_FP32_REF": True, "FP8_MIN_TILES": 96}
 
 
@@ -738,9 +740,10 @@ MSDA_V4_REGION = (16, 16)      # region of a workgroup, pixels of the finest lev
 MSDA_V4_LDS_BUDGET = 64 * 1024   # bytes per workgroup
 MSDA_V4_MARGIN_CAP = 40.0      # pixels: windows grow up to this margin around a head's bias points within the LDS budget
 MSDA_V4_HEAD_MAJOR = True      # value projection writes [B, M, S, 32] for the packed encoder kernel
+ENC_PROJ_FUSED = True          # value projection and packed (offsets | logits) projection as ONE launch (x, pos read once)
 _SWITCH_DEFAULTS.update({"MSDA_V4": True, "MSDA_V4_THREADS": 512, "MSDA_V4_REGION": (16, 16),
                          "MSDA_V4_LDS_BUDGET": 64 * 1024, "MSDA_V4_MARGIN_CAP": 40.0,
-                         "MSDA_V4_HEAD_MAJOR": True})
+                         "MSDA_V4_HEAD_MAJOR": True, "ENC_PROJ_FUSED": True})
 
 
 def msda_encoder_packed_supported(dtype, head_dim, num_levels, num_points):
@@ -769,6 +772,51 @@ def value_projection_f16(x, weight, bias, row_mask, head_dim):
     with torch.cuda.device(x.device):
         ok = _cabi.linear_bf16_f16out(x2, w, bias, out, mk, S, int(head_dim))
     return out.view(B, N // head_dim, S, head_dim) if ok else None
+
+
+def encoder_projections(x, pos, w_cat, b_cat, row_mask, n_value, head_dim):
+    """The encoder self-attention's value projection and packed (offsets | logits) projection as ONE launch
+    (include/codetr_hip.h codetr_encoder_projections_*; reference multi_scale_deformable_attention.py:161-182 with
+    value = query): value = x @ w_cat[:n_value]^T + b (rows where row_mask is True zeroed), returned head-major
+    [B, n_value / head_dim, S, head_dim] in FP16 (fp16 and bf16 models alike: the packed MSDA kernel's value map), and
+    packed [B, S, Np] = (x + pos) @ w_cat[n_value:]^T + b in x's type.  None where the library declines the shape (the
+    caller then runs the two GEMMs)."""
+    _gpu(x, "encoder_projections")
+    if not (ENC_PROJ_FUSED and x.dim() == 3 and x.dtype in (torch.float16, torch.bfloat16) and pos is not None
+            and pos.shape == x.shape and pos.dtype == x.dtype and w_cat.dtype == x.dtype and not torch.is_grad_enabled()):
+        return None
+    B, S, K = x.shape
+    n_packed = w_cat.shape[0] - n_value
+    x2, p2 = x.reshape(-1, K), pos.reshape(-1, K)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    p2 = p2 if p2.is_contiguous() else p2.contiguous()
+    mk = None
+    if row_mask is not None:
+        mk = row_mask.reshape(-1)
+        if mk.dtype != torch.bool and mk.dtype != torch.uint8:
+            mk = mk != 0
+        mk = mk.contiguous()
+    value = torch.empty((B * S, n_value), dtype=torch.float16, device=x.device)
+    packed = torch.empty((B * S, n_packed), dtype=x.dtype, device=x.device)
+    ok = [False]
+
+    def launch():
+        ok[0] = _cabi.encoder_projections(x2, p2, w_cat, b_cat, mk, value, packed, S, int(head_dim))
+
+    with torch.cuda.device(x.device):
+        if LINEAR_PROFILE is None:
+            launch()
+        else:
+            st = torch.cuda.current_stream(x.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            launch()
+            e1.record(st)
+            if ok[0]:
+                LINEAR_PROFILE.append((e0, e1, 2.0 * B * S * (n_value + n_packed) * K, B * S, n_value + n_packed, K))
+    if not ok[0]:
+        return None
+    return value.view(B, n_value // head_dim, S, head_dim), packed.view(B, S, n_packed)
 
 
 def msda_packed_projection(w_off, b_off, w_aw, b_aw, num_heads, num_levels, num_points):

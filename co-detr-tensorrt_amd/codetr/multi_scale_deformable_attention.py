@@ -99,6 +99,18 @@ class MultiScaleDeformableAttention(nn.Module):
         return hip_ops.derived(ws, "_codetr_packed_proj", lambda: hip_ops.msda_packed_projection(
             *ws, self.num_heads, self.num_levels, self.num_points))
 
+    def _encoder_projections(self):
+        """value_proj and the packed (offsets | logits) projection as one [C + 64 M, C] weight + bias (value rows first):
+        the operand of the one-launch form (hip_ops.encoder_projections)"""
+        ws = (self.value_proj.weight, self.value_proj.bias, self.sampling_offsets.weight, self.sampling_offsets.bias,
+              self.attention_weights.weight, self.attention_weights.bias)
+
+        def build():
+            Wp, bp = hip_ops.msda_packed_projection(*ws[2:], self.num_heads, self.num_levels, self.num_points)
+            return torch.cat((ws[0], Wp), 0).contiguous(), torch.cat((ws[1], bp), 0).contiguous()
+
+        return hip_ops.derived(ws, "_codetr_enc_projections", build)
+
     def _encoder_windows_packed(self, host_shapes):
         key = ("_codetr_enc_windows_v4_" + "_".join(f"{int(h)}x{int(w)}" for h, w in host_shapes)
                + f"_{hip_ops.MSDA_V4_THREADS}_{hip_ops.MSDA_V4_REGION}_{hip_ops.MSDA_V4_LDS_BUDGET}_{hip_ops.MSDA_V4_MARGIN_CAP}")
@@ -162,6 +174,17 @@ class MultiScaleDeformableAttention(nn.Module):
             # window row is one contiguous run), the (offsets | logits) projection the lane-major packed rows (its weight
             # rows permuted once; two 16-byte loads per lane).  Padding mask folded into the value GEMM (reference :173-176).
             hm = hip_ops.MSDA_V4_HEAD_MAJOR and self.value_proj.in_features % 64 == 0
+            if (hm and pos_in_gemm is not None and value is query and hip_ops.ENC_PROJ_FUSED
+                    and self.value_proj.bias is not None and self.value_proj.out_features % 64 == 0):
+                # self-attention (value IS query): both projections in one launch, x and pos read once
+                Wc, bc = self._encoder_projections()
+                both = hip_ops.encoder_projections(query, pos_in_gemm, Wc, bc, key_padding_mask,
+                                                   self.value_proj.out_features, hd)
+                if both is not None:
+                    out = hip_ops.msda_encoder_packed(both[0], host_shapes, both[1], P,
+                                                      self._encoder_windows_packed(host_shapes), counts, True)
+                    if out is not None:
+                        return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
             if value.dtype == torch.bfloat16:
                 # bf16 model: the kernel's value map is FP16 (packed-half blend; the projection's fp32 accumulators keep
                 # three more mantissa bits than a bf16 store), head-major; offsets / logits / output stay bf16

@@ -987,7 +987,13 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
 // per wave, activation, fp16 image of the wave's 32 x 32 piece in its private LDS region, row-wise read-back,
 // residual (requested before the MFMAs) / row mask, 16-B stores.  X is read from HBM exactly once, Y written once,
 // W (<= 1.2 MB) comes from L2.
-template <class T, int KS, int ACT, bool HAS_RES, class OT = T>   // OT: storage type of Y (bf16 operands -> fp16 output: the
+//
+// SPLIT (the encoder's two projections of one token row as ONE launch -- reference multi_scale_deformable_attention.py:161-179:
+// value_proj(value) and sampling_offsets | attention_weights (query + query_pos), where value IS query): W holds N1 rows
+// applied to X and N - N1 rows applied to X + X2; the first N1 columns go to Y (type OT, row mask, optional head-major
+// layout), the others to Y2 (type T, row-major, N - N1 columns).  The kept fragments become X + X2 at chunk N1 / 32: X and
+// X2 are each read once for both products (two launches read X twice: 419 MB of 2.5 GB at four 1920x1280 images).
+template <class T, int KS, int ACT, bool HAS_RES, class OT = T, bool SPLIT = false>   // OT: storage type of Y (bf16 operands -> fp16 output: the
 __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __restrict__ X,   // encoder MSDA's value map)
                                                         const unsigned short* __restrict__ X2,
                                                         const unsigned short* __restrict__ LNG,
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
                                                         const unsigned short* __restrict__ R,
                                                         unsigned short* __restrict__ Y,
                                                         const unsigned char* __restrict__ row_mask, int M, int N, int hm_rows,
-                                                        int hm_hd) {
+                                                        int hm_hd, unsigned short* __restrict__ Y2 = nullptr, int N1 = 0) {
   constexpr int K = KS * 32, CH = K / 8;          // 16-byte chunks per row
   constexpr int CN = 32;                          // output columns per W chunk
   constexpr int kChunkBytes = CN * K * 2;         // 12 / 16 / 24 KiB
@@ -1015,6 +1021,8 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
   const int l15 = lane & 15, grp = lane >> 4;
   const int m0 = (int)xcd_tile(blockIdx.x, gridDim.x) * 128 + wave * 32;
   const int nchunks = (N + CN - 1) / CN;
+  const int Ny = SPLIT ? N1 : N;                  // columns of Y (SPLIT: the others are Y2's)
+  const int c1 = SPLIT ? N1 / CN : 0;             // first chunk of the second product
 
   // LDS-DMA of one W chunk (32 rows x K, kPieces pieces of 4 KiB): piece q covers rows (q * 256 + tid) / CH.  Inline
   // assembly with a wave-uniform base and a per-thread byte offset (see lds_dma16s): no vector arithmetic per piece but
@@ -1050,7 +1058,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
       xf[mt][ks] = *reinterpret_cast<const typename T::frag*>(X + (size_t)m * K + ks * 32 + grp * 8);
     // optional second input, added element-wise on the way in (x + x2 rounded to T, the fp16 / bf16 add the host
     // would otherwise run as its own kernel: `query + query_pos` in front of the offsets | logits projection)
-    if (X2) {
+    if (X2 && !SPLIT) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const typename T::frag p = *reinterpret_cast<const typename T::frag*>(X2 + (size_t)m * K + ks * 32 + grp * 8);
@@ -1134,7 +1142,11 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
       const int m = m0 + ml;
       const int n = np + schunk * 8;
       s16x8 v = *reinterpret_cast<const s16x8*>(my_stage + ml * kXsPitch + schunk * 16);
-      if (m < M && n < N) {  // N % 8 == 0: a chunk of 8 columns is inside or outside as a whole
+      if (SPLIT && np >= N1) {   // (N1 % 64 == 0: a pair belongs to one of the two outputs)
+        if (m < M && n < N) *reinterpret_cast<s16x8*>(Y2 + (size_t)m * (N - N1) + (n - N1)) = v;
+        continue;
+      }
+      if (m < M && n < Ny) {  // N % 8 == 0: a chunk of 8 columns is inside or outside as a whole
         if (row_mask) {
           const unsigned char mk = (unsigned char)((row_states >> (8 * it)) & 0xffu);
           if (mk == 2) {
@@ -1154,11 +1166,11 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
           for (int e = 0; e < 8; ++e)
             v[e] = (short)T::from_f32(T::to_f32((unsigned short)v[e]) + T::to_f32((unsigned short)rr[it][e]));
         }
-        size_t off = (size_t)m * N + n;
+        size_t off = (size_t)m * Ny + n;
         if (hm_hd > 0) {  // column-block-major destination y[b][n / hm_hd][position][n % hm_hd] (hm_hd % 8 == 0: a lane's 8-column chunk lies inside one block)
           const int bb = m / hm_rows, pos = m - bb * hm_rows;
           const int head = n / hm_hd, ch = n - head * hm_hd;
-          off = (((size_t)bb * (N / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
+          off = (((size_t)bb * (Ny / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
         }
         *reinterpret_cast<s16x8*>(Y + off) = v;
       }
@@ -1187,6 +1199,23 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
       const int c2 = c + 2 < nchunks ? c + 2 : nchunks - 1;  // (past the end: a fetch nobody reads, same counts)
       const int s2 = slot == 0 ? 2 : slot - 1;               // the slot W[c-1] used
       stage_chunk(c2, lds + s2 * kChunkBytes);
+    }
+    if (SPLIT && c == c1) {
+      // the second product's operand: x + x2 rounded to T (exactly the separate add); its loads are the youngest vector
+      // memory operations and are waited for here, so the counted wait of the next chunk sees the W pieces only
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        int m = m0 + mt * 16 + l15;
+        m = m < M ? m : M - 1;
+        typename T::frag pf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          pf[ks] = *reinterpret_cast<const typename T::frag*>(X2 + (size_t)m * K + ks * 32 + grp * 8);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xf[mt][ks][e] = (typename T::elem)((float)xf[mt][ks][e] + (float)pf[ks][e]);
+      }
     }
     const unsigned char* sW = lds + slot * kChunkBytes;
     slot = slot == 2 ? 0 : slot + 1;
@@ -1231,7 +1260,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
           v[r] = x;
         }
         *reinterpret_cast<s16x4*>(my_stage + (mt * 16 + l15) * kXsPitch + ((c & 1) * CN + nt * 16 + grp * 4) * 2) =
-            OT::pack4(v);
+            (SPLIT && c >= c1) ? T::pack4(v) : OT::pack4(v);
       }
   }
   // the last pair (one chunk if nchunks is odd)
@@ -1370,9 +1399,47 @@ int launch_ln(hipStream_t st, const void* X, const void* G, const void* Bt, floa
 #undef CODETR_LN_CASE
 }
 
+// the encoder's two projections as one launch of the X-stationary kernel (SPLIT form): K = 256 only
+template <class T, class OT>
+int launch_split(hipStream_t st, const void* X, const void* X2, const void* W, const void* bias, const void* mask, void* Y,
+                 void* Y2, int64_t M, int64_t N1, int64_t N2, int64_t K, int64_t hm_rows, int hm_hd) {
+  if (!X || !X2 || !W || !Y || !Y2 || M <= 0 || N1 <= 0 || N2 <= 0 || K <= 0) return CODETR_E_BADARG;
+  if (M > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(W) |
+       reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Y2) | reinterpret_cast<uintptr_t>(bias)) & 15)
+    return CODETR_E_BADARG;
+  if (hm_hd != 0 || hm_rows != 0) {
+    if (hm_hd <= 0 || hm_rows <= 0 || hm_hd % 8 != 0 || N1 % hm_hd != 0 || M % hm_rows != 0) return CODETR_E_UNSUPPORTED;
+  }
+  if (K != 256 || N1 % 64 != 0 || N2 % 8 != 0 || N1 + N2 > 1536 || M < 128 * 256) return CODETR_E_UNSUPPORTED;
+  const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+  hipLaunchKernelGGL((linear_xs_kernel<T, 8, 0, false, OT, true>), grid, block, 0, st, static_cast<const unsigned short*>(X),
+                     static_cast<const unsigned short*>(X2), nullptr, nullptr, 0.f, static_cast<const unsigned short*>(W),
+                     static_cast<const unsigned short*>(bias), nullptr, static_cast<unsigned short*>(Y),
+                     static_cast<const unsigned char*>(mask), (int)M, (int)(N1 + N2), (int)hm_rows, hm_hd,
+                     static_cast<unsigned short*>(Y2), (int)N1);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
 }  // namespace
 
 extern "C" {
+
+int codetr_encoder_projections_f16(void* stream, const void* x_dev, const void* pos_dev, const void* w_dev,
+                                   const void* bias_dev, const void* row_mask_dev, void* value_dev, void* packed_dev,
+                                   int64_t M, int64_t N_value, int64_t N_packed, int64_t K, int64_t hm_rows, int hm_head_dim) {
+  return launch_split<HalfT, HalfT>(static_cast<hipStream_t>(stream), x_dev, pos_dev, w_dev, bias_dev, row_mask_dev,
+                                    value_dev, packed_dev, M, N_value, N_packed, K, hm_rows, hm_head_dim);
+}
+
+int codetr_encoder_projections_bf16(void* stream, const void* x_dev, const void* pos_dev, const void* w_dev,
+                                    const void* bias_dev, const void* row_mask_dev, void* value_f16_dev, void* packed_dev,
+                                    int64_t M, int64_t N_value, int64_t N_packed, int64_t K, int64_t hm_rows,
+                                    int hm_head_dim) {
+  return launch_split<BFloatT, HalfT>(static_cast<hipStream_t>(stream), x_dev, pos_dev, w_dev, bias_dev, row_mask_dev,
+                                      value_f16_dev, packed_dev, M, N_value, N_packed, K, hm_rows, hm_head_dim);
+}
 
 int codetr_linear_ln_f16(void* stream, const void* x_dev, const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps,
                          const void* w_dev, const void* bias_dev, void* y_dev, int64_t M, int64_t N, int64_t K, int act) {

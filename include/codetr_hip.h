@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 42
+#define CODETR_HIP_ABI_VERSION 43
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -331,6 +331,26 @@ int codetr_linear_bf16(void *stream, const void *x_dev, const void *w_dev, const
 int codetr_linear_bf16_f16out(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                               const void *row_mask_dev, void *y_dev, int64_t M, int64_t N, int64_t K,
                               int64_t hm_rows, int hm_head_dim);
+/* The encoder self-attention's two projections of one token row as ONE launch (reference
+ * codetr/multi_scale_deformable_attention.py:161-162 `query = query + query_pos`, :173-176 value_proj + masked_fill,
+ * :177-182 sampling_offsets | attention_weights; in the encoder `value` IS `query`):
+ *     value  [M, N_value]  = x @ W[:N_value]^T + b[:N_value]            rows with row_mask != 0 zeroed; head-major
+ *                            destination [M / hm_rows][N_value / hm_head_dim][hm_rows][hm_head_dim] if hm_head_dim != 0
+ *     packed [M, N_packed] = (x + pos) @ W[N_value:]^T + b[N_value:]    x + pos rounded to the operand type first, exactly
+ *                            as the separate add; row-major
+ * w_dev [N_value + N_packed, K] and bias_dev are the two layers' parameters concatenated (value rows first).  x and pos
+ * are each read once for both products -- as two launches x is read twice (419 MB of 2.5 GB at four 1920x1280 images)
+ * and the value projection pays its own prologue.  _bf16: operands, packed output bf16; the value map is FP16 (see
+ * codetr_linear_bf16_f16out).  X-stationary kernel: K == 256, N_value % 64 == 0, N_packed % 8 == 0, N_value + N_packed
+ * <= 1536, M >= 32 768, 16-byte aligned pointers; CODETR_E_UNSUPPORTED otherwise (the caller then launches the two GEMMs). */
+int codetr_encoder_projections_f16(void *stream, const void *x_dev, const void *pos_dev, const void *w_dev,
+                                   const void *bias_dev, const void *row_mask_dev, void *value_dev, void *packed_dev,
+                                   int64_t M, int64_t N_value, int64_t N_packed, int64_t K, int64_t hm_rows,
+                                   int hm_head_dim);
+int codetr_encoder_projections_bf16(void *stream, const void *x_dev, const void *pos_dev, const void *w_dev,
+                                    const void *bias_dev, const void *row_mask_dev, void *value_f16_dev,
+                                    void *packed_dev, int64_t M, int64_t N_value, int64_t N_packed, int64_t K,
+                                    int64_t hm_rows, int hm_head_dim);
 
 /* Which of the three kernels behind codetr_linear_* serves a (16-byte aligned) problem: "tile128" (128x128 tiles, the
  * general kernel), "tile256" (256x256 tiles, one workgroup per CU), "xs" (X-stationary short-K kernel) or

@@ -330,6 +330,59 @@ def _xadd_case(M, N, K, dtype, _cabi, hip_ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,S,masked", [(2, 20000, True), (1, 32768 + 77, False)])
+def test_encoder_projections_one_launch_matches_the_two_gemms(B, S, masked, dtype):
+    """codetr_encoder_projections_*: value = x W_v^T + b_v (row mask, head-major [B, 8, S, 32], FP16) and packed =
+    (x + pos) W_p^T + b_p from ONE launch of the X-stationary kernel.  Same kernel, same accumulation order as the two
+    launches it replaces -> bit-equal to them (value: codetr_linear_* head-major / codetr_linear_bf16_f16out; packed:
+    codetr_linear_xadd_*); and within one ulp of the fp32 products."""
+    from codetr import _cabi, hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(B * S)
+    K, Nv, Np, hd = 256, 256, 512, 32
+    x = torch.randn(B, S, K, device=DEV, generator=g).to(dtype)
+    pos = torch.randn(B, S, K, device=DEV, generator=g).to(dtype)
+    wv = (torch.randn(Nv, K, device=DEV, generator=g) / 16).to(dtype)
+    bv = torch.randn(Nv, device=DEV, generator=g).to(dtype)
+    wp = (torch.randn(Np, K, device=DEV, generator=g) / 16).to(dtype)
+    bp = torch.randn(Np, device=DEV, generator=g).to(dtype)
+    mask = (torch.rand(B, S, device=DEV, generator=g) < 0.2) if masked else None
+    wc, bc = torch.cat((wv, wp), 0).contiguous(), torch.cat((bv, bp), 0).contiguous()
+    hip_ops.XADD_MIN_ROWS, saved = 0, hip_ops.XADD_MIN_ROWS
+    try:
+        with torch.no_grad():
+            before = _cabi.CALLS["encoder_projections"]
+            both = hip_ops.encoder_projections(x, pos, wc, bc, mask, Nv, hd)
+            assert both is not None and _cabi.CALLS["encoder_projections"] == before + 1
+            value, packed = both
+            assert value.shape == (B, Nv // hd, S, hd) and value.dtype == torch.float16
+            assert packed.shape == (B, S, Np) and packed.dtype == dtype
+            if dtype == torch.float16:
+                v2 = hip_ops.linear(x, wv, bv, row_mask=mask, head_major=hd)
+            else:
+                v2 = hip_ops.value_projection_f16(x, wv, bv, mask, hd)
+            p2 = hip_ops.linear_xadd(x, pos, wp, bp)
+            assert torch.equal(value, v2)
+            assert torch.equal(packed, p2)
+            # fp32 products of the same operands
+            ref_v = x.float() @ wv.float().t() + bv.float()
+            if mask is not None:
+                ref_v = ref_v.masked_fill(mask[..., None], 0.0)
+            ref_v = ref_v.view(B, S, Nv // hd, hd).permute(0, 2, 1, 3)
+            err = (value.float() - ref_v).abs()
+            assert bool((err <= 2.0 ** -10 * ref_v.abs() + 1e-3 * 2.0 ** -10 * 64 + K * 2.0 ** -22).all()), float(err.max())
+            ref_p = (x + pos).float() @ wp.float().t() + bp.float()
+            ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+            err = (packed.float() - ref_p).abs()
+            assert bool((err <= ulp * ref_p.abs() + 1e-3 * ulp * 64 + K * 2.0 ** -22).all()), float(err.max())
+            # declined shapes: too few rows, a value width that is not a multiple of 64 columns
+            assert hip_ops.encoder_projections(x[:, :100], pos[:, :100], wc, bc, None, Nv, hd) is None
+            assert hip_ops.encoder_projections(x, pos, wc[32:].contiguous(), bc[32:].contiguous(), None, Nv - 32, hd) is None
+    finally:
+        hip_ops.XADD_MIN_ROWS = saved
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,act", [(40000, 576, 192, None), (32768 + 33, 768, 192, "gelu"), (33000, 256, 256, "relu")])
 def test_linear_ln_matches_layernorm_then_linear(M, N, K, act, dtype):
     """codetr_linear_ln_*: LayerNorm of the rows inside the short-K GEMM's operand load (Swin norm1 -> qkv, norm2 -> fc1)
