@@ -522,8 +522,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // whole 64-wide K tiles so that ~1.5 blocks per CU are in flight.  Returns 1 when a single pass is the better launch.
 int splitk_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), ktiles = K / 64;
-  if (tiles > 64 || K < 2048 || K % 64 != 0) return 1;
-  int64_t splits = (384 + tiles - 1) / tiles;
+  if (tiles > 128 || K < 2048 || K % 64 != 0) return 1;
+  // 65 ... 128 tiles (Swin stage-2 fc2 of a 608x608 image: 72 tiles x 48 k-tiles; stage-3 fc2 of a 1152x768 image: 84 x 96):
+  // as many whole passes over K as still fit one round of the chip
+  int64_t splits = tiles > 64 ? 256 / tiles : (384 + tiles - 1) / tiles;
   if (splits > ktiles / 4) splits = ktiles / 4;
   if (splits < 2) return 1;
   const int64_t kps = (ktiles + splits - 1) / splits;

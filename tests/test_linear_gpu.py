@@ -183,6 +183,8 @@ def test_value_projection_bf16_operands_fp16_head_major_output():
     (900, 256, 2048, True, None, True),      # decoder FFN down-projection + identity
     (77, 130, 4096, True, "relu", False),    # ragged M and N (scalar partial stores), K ranges of unequal length
     (128, 8, 2112, True, "gelu", True),      # 33 K tiles
+    (1444, 768, 3072, True, None, True),     # 65 ... 128 tiles: Swin stage-2 fc2 of one 608x608 image (72 tiles, 3 passes)
+    (864, 1536, 6144, True, None, True),     # Swin stage-3 fc2 of one 1152x768 image (84 tiles, 3 passes)
 ])
 def test_linear_splitk(M, N, K, bias, act, res, dtype):
     """Few output tiles + long K go through the two-pass split-K path (plan > 1) and match the fp32 reference."""
@@ -200,6 +202,9 @@ def test_linear_splitk_plan_and_row_mask():
 
     assert _cabi.linear_splitk_plan(204600, 256, 2048) == (1, 0)   # plenty of tiles: single pass
     assert _cabi.linear_splitk_plan(900, 256, 256) == (1, 0)       # short K
+    assert _cabi.linear_splitk_plan(1444, 768, 3072)[0] == 3       # 72 tiles: 3 x 72 = 216 blocks, one round of the chip
+    assert _cabi.linear_splitk_plan(2048, 1024, 4096)[0] == 2      # 128 tiles
+    assert _cabi.linear_splitk_plan(2176, 1024, 4096) == (1, 0)    # 136 tiles: single pass
     g = torch.Generator(device=DEV).manual_seed(2)
     x = torch.randn(300, 2048, device=DEV, generator=g).half()
     w = (torch.randn(64, 2048, device=DEV, generator=g) / 45).half()
