@@ -989,6 +989,12 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
 // per wave, activation, fp16 image of the wave's 32 x 32 piece in its private LDS region, row-wise read-back,
 // residual (requested before the MFMAs) / row mask, 16-B stores.  X is read from HBM exactly once, Y written once,
 // W (<= 1.2 MB) comes from L2.
+#ifdef CODETR_XS_STAMPS   // diagnostic build only (tools/micro/xs_stamps.hip): where wave 0 of every workgroup spends its cycles
+__device__ unsigned long long* g_xs_stamps = nullptr;
+#define XS_STAMP(i) xs_t[i] = __builtin_readcyclecounter()
+#else
+#define XS_STAMP(i)
+#endif
 //
 // SPLIT (the encoder's two projections of one token row as ONE launch -- reference multi_scale_deformable_attention.py:161-179:
 // value_proj(value) and sampling_offsets | attention_weights (query + query_pos), where value IS query): W holds N1 rows
@@ -1023,6 +1029,10 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
   const int l15 = lane & 15, grp = lane >> 4;
   const int m0 = (int)xcd_tile(blockIdx.x, gridDim.x) * 128 + wave * 32;
   const int nchunks = (N + CN - 1) / CN;
+#ifdef CODETR_XS_STAMPS
+  unsigned long long xs_t[8], xs_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long xs_start = __builtin_readcyclecounter(), xs_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int Ny = SPLIT ? N1 : N;                  // columns of Y (SPLIT: the others are Y2's)
   const int c1 = SPLIT ? N1 / CN : 0;             // first chunk of the second product
 
@@ -1188,20 +1198,28 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
   //   issue W[c+2] into the stage W[c-1] used
   //   32 x 32 outputs per wave: MFMAs, activation, fp16 image into the wave's staging region
   int slot = 0;  // ring slot of W[c]
+#ifdef CODETR_XS_STAMPS
+  const unsigned long long xs_loop = __builtin_readcyclecounter();
+#endif
   for (int c = 0; c < nchunks; ++c) {
+    XS_STAMP(0);
     wait_vmcnt_n<kPieces>();
+    XS_STAMP(1);
     __builtin_amdgcn_s_barrier();
+    XS_STAMP(2);
     const int n0 = c * CN;
     if (!(c & 1)) {
       if (c >= 2) flush_pair((c - 2) * CN);
     } else if (HAS_RES) {
       load_residual((c - 1) * CN);
     }
+    XS_STAMP(3);
     {
       const int c2 = c + 2 < nchunks ? c + 2 : nchunks - 1;  // (past the end: a fetch nobody reads, same counts)
       const int s2 = slot == 0 ? 2 : slot - 1;               // the slot W[c-1] used
       stage_chunk(c2, lds + s2 * kChunkBytes);
     }
+    XS_STAMP(4);
     if (SPLIT && c == c1) {
       // the second product's operand: x + x2 rounded to T (exactly the separate add); its loads are the youngest vector
       // memory operations and are waited for here, so the counted wait of the next chunk sees the W pieces only
@@ -1249,6 +1267,10 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
         for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = T::mfma(a[nt], xf[mt][ks], acc[nt][mt]);
     }
     // ---- chunk epilogue: this wave's 32 rows x 32 columns into its half of the staged pair ----
+#ifdef CODETR_XS_STAMPS
+    asm volatile("" ::"v"(acc[1][1][3]) : "memory");
+#endif
+    XS_STAMP(5);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -1264,6 +1286,12 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
         *reinterpret_cast<s16x4*>(my_stage + (mt * 16 + l15) * kXsPitch + ((c & 1) * CN + nt * 16 + grp * 4) * 2) =
             (SPLIT && c >= c1) ? T::pack4(v) : OT::pack4(v);
       }
+#ifdef CODETR_XS_STAMPS
+    asm volatile("" ::: "memory");
+    XS_STAMP(6);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xs_acc[i] += xs_t[i + 1] - xs_t[i];
+#endif
   }
   // the last pair (one chunk if nchunks is odd)
   {
@@ -1272,6 +1300,17 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
     flush_pair(np);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant fetches of the last two iterations
+#ifdef CODETR_XS_STAMPS
+  if (threadIdx.x == 0 && g_xs_stamps) {
+    unsigned long long* o = g_xs_stamps + 12 * (size_t)blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = xs_acc[i];
+    o[6] = xs_loop - xs_start;                       // prologue
+    o[7] = __builtin_readcyclecounter() - xs_start;  // whole workgroup
+    o[8] = xs_rt0;
+    o[9] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // The short-K kernel serves f16 / bf16, K in {192, 256}, N % 8 == 0 (16-byte row chunks), 128 <= N <= 1536 (bias in
