@@ -313,10 +313,14 @@ def kernel_rooflines(model, images, masks, device):
     }
     ffn = kprof.get("ffn_fused", [])
     if ffn:
-        fl = sum(4.0 * m["M"] * m["C"] * m["hidden"] for _, _, m in ffn)
+        fl = sum(4.0 * m["M"] * m["C"] * m["hidden"] + (2.0 * m["M"] * m["C"] * m["C"] if m.get("oproj") else 0.0)
+                 for _, _, m in ffn)
         t = sum(a.elapsed_time(b) for a, b, _ in ffn) * 1e-3
         out["roofline_ffn"] = {
-            "kernel": "ffn_fused_kernel<2> (%d encoder launches, M = %d)" % (len(ffn), ffn[0][2]["M"]),
+            "kernel": "ffn_fused_kernel<2> (%d encoder launches, M = %d%s)" % (
+                len(ffn), ffn[0][2]["M"],
+                "; the attention output projection + identity + norm1 inside: 2*M*256*256 flops more per launch"
+                if ffn[0][2].get("oproj") else ""),
             "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "traffic": pmc.get("ffn_fused", {}).get("hbm_bytes_per_launch"),

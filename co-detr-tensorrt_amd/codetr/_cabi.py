@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -137,6 +137,11 @@ SIGNATURES = {
     "codetr_ffn_relu_ln2_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float,
                                        _vp, _vp, ctypes.c_float, _vp, _vp]),
     "codetr_ffn_pack_w2_f16": (_i32, [_vp, _vp, _vp, _i64, _i64]),
+    "codetr_ffn_oproj_relu_ln2_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
+                                             ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp]),
+    "codetr_ffn_oproj_relu_ln2_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
+                                              ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp]),
+    "codetr_ffn_oproj_w1_index": (_i32, [_i64, _vp]),
     "codetr_ffn_fp8": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_float, ctypes.c_float,
                               _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
@@ -150,7 +155,7 @@ _lib = None
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
 CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
-         "sine_pos_tokens": 0, "ffn_fused": 0, "linear_splitk": 0, "linear_sk": 0, "mask_pyramid": 0,
+         "sine_pos_tokens": 0, "ffn_fused": 0, "ffn_oproj_fused": 0, "linear_splitk": 0, "linear_sk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "msda_encoder_packed": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
@@ -919,6 +924,37 @@ def ffn_fused(x2d, w1, b1, w2, b2, out2d, ln=None, pos2d=None, out_plus_pos2d=No
         pos2d.data_ptr() if pos2d is not None else None,
         out_plus_pos2d.data_ptr() if out_plus_pos2d is not None else None)
     check(rc, "codetr_ffn_relu_ln2")
+    return out2d
+
+
+def ffn_oproj_w1_index(C):
+    """column order of the first Linear's weight for ffn_oproj_fused (host list of C ints)"""
+    idx = (ctypes.c_int32 * C)()
+    rc = load().codetr_ffn_oproj_w1_index(C, ctypes.cast(idx, ctypes.c_void_p))
+    check(rc, "codetr_ffn_oproj_w1_index")
+    return list(idx)
+
+
+def ffn_oproj_fused(attn2d, wo, bo, identity2d, w1_perm, b1, w2_packed, b2, out2d, ln_in, ln, pos2d=None,
+                    out_plus_pos2d=None):
+    """out = LN(x1 + relu(x1 W1^T + b1) W2^T + b2), x1 = LN_in(identity + (attn Wo^T + bo)) -- the attention output
+    projection folded into the fused FFN (include/codetr_hip.h codetr_ffn_oproj_relu_ln2_*).  w1_perm: W1 with its columns
+    in ffn_oproj_w1_index order; w2_packed: ffn_pack_w2."""
+    CALLS["ffn_fused"] += 1
+    CALLS["ffn_oproj_fused"] += 1
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    gi, bi, epsi = ln_in if ln_in is not None else (None, None, 0.0)
+    lib = load()
+    fn = lib.codetr_ffn_oproj_relu_ln2_bf16 if attn2d.dtype == torch.bfloat16 else lib.codetr_ffn_oproj_relu_ln2_f16
+    rc = fn(
+        current_stream_ptr(attn2d.device), attn2d.data_ptr(), wo.data_ptr(), bo.data_ptr(), identity2d.data_ptr(),
+        w1_perm.data_ptr(), b1.data_ptr(), w2_packed.data_ptr(), b2.data_ptr(), out2d.data_ptr(), attn2d.shape[0],
+        attn2d.shape[1], w1_perm.shape[0],
+        gi.data_ptr() if gi is not None else None, bi.data_ptr() if bi is not None else None, float(epsi),
+        g.data_ptr() if g is not None else None, b.data_ptr() if b is not None else None, float(eps),
+        pos2d.data_ptr() if pos2d is not None else None,
+        out_plus_pos2d.data_ptr() if out_plus_pos2d is not None else None)
+    check(rc, "codetr_ffn_oproj_relu_ln2")
     return out2d
 
 

@@ -293,6 +293,42 @@ def ffn_fused(x, w1, b1, w2, b2, ln=None, pos=None, ln_in=None):
     return out.view(x.shape)
 
 
+FFN_OPROJ = True   # route switch: the encoder layer's attention output projection inside the fused FFN launch
+
+
+def ffn_oproj_fused(attn, wo, bo, identity, w1, b1, w2, b2, ln, pos=None, ln_in=None):
+    """The post-norm encoder layer from the attention output on, ONE launch (include/codetr_hip.h
+    codetr_ffn_oproj_relu_ln2_*):  x1 = LN_in(identity + (attn @ wo.T + bo));  y = LN(x1 + relu(x1 @ w1.T + b1) @ w2.T + b2);
+    with `pos` also y + pos (returns (y, y + pos)).  w1 / w2 are the plain nn.Linear weights (their kernel layouts are
+    cached on the tensors)."""
+    _gpu(attn, "ffn_oproj_fused")
+    C = attn.shape[-1]
+    a2, i2 = attn.reshape(-1, C), identity.reshape(-1, C)
+    a2 = a2 if a2.is_contiguous() else a2.contiguous()
+    i2 = i2 if i2.is_contiguous() else i2.contiguous()
+    if i2.shape != a2.shape or i2.dtype != a2.dtype:
+        raise ValueError("identity must match the attention output in shape and dtype")
+    out = torch.empty_like(a2)
+    p2 = out2 = None
+    if pos is not None:
+        p2 = pos.reshape(-1, C)
+        if p2.shape != a2.shape or p2.dtype != a2.dtype:
+            raise ValueError("pos must match x in shape and dtype")
+        p2 = p2 if p2.is_contiguous() else p2.contiguous()
+        out2 = torch.empty_like(a2)
+    w1p = derived((w1,), "_codetr_w1_oproj", lambda: w1.detach()[:, torch.tensor(
+        _cabi.ffn_oproj_w1_index(C), dtype=torch.long, device=w1.device)].contiguous())
+    woc = wo if wo.is_contiguous() else wo.contiguous()
+    if a2.shape[0] > 0:
+        with torch.cuda.device(attn.device):
+            _timed("ffn_fused", {"M": a2.shape[0], "C": C, "hidden": w1.shape[0], "oproj": True},
+                   lambda: _cabi.ffn_oproj_fused(a2, woc, bo, i2, w1p, b1, _packed_w2(w2), b2, out, ln_in, ln, p2, out2),
+                   attn.device)
+    if pos is not None:
+        return out.view(attn.shape), out2.view(attn.shape)
+    return out.view(attn.shape)
+
+
 def layer_norm(x, weight, bias, eps=1e-5):
     _gpu(x, "layer_norm")
     if _cabi.layernorm_supported(x, weight):
@@ -743,7 +779,7 @@ MSDA_V4_HEAD_MAJOR = True      # value projection writes [B, M, S, 32] for the p
 ENC_PROJ_FUSED = True          # value projection and packed (offsets | logits) projection as ONE launch (x, pos read once)
 _SWITCH_DEFAULTS.update({"MSDA_V4": True, "MSDA_V4_THREADS": 512, "MSDA_V4_REGION": (16, 16),
                          "MSDA_V4_LDS_BUDGET": 64 * 1024, "MSDA_V4_MARGIN_CAP": 40.0,
-                         "MSDA_V4_HEAD_MAJOR": True, "ENC_PROJ_FUSED": True})
+                         "MSDA_V4_HEAD_MAJOR": True, "ENC_PROJ_FUSED": True, "FFN_OPROJ": True})
 
 
 def msda_encoder_packed_supported(dtype, head_dim, num_levels, num_points):

@@ -27,6 +27,14 @@ from . import hip_ops
 HEAD_MAJOR_VALUE = False   # route switch (module attribute, patched by tools/ab_host_routes.py)
 
 
+class DeferredOutputProj:
+    """what forward_bf(defer_output_proj=True) returns when it leaves `output_proj(attn) + identity` to the caller"""
+    __slots__ = ("attn", "identity")
+
+    def __init__(self, attn, identity):
+        self.attn, self.identity = attn, identity
+
+
 class MultiScaleDeformableAttention(nn.Module):
     def __init__(
         self,
@@ -129,11 +137,13 @@ class MultiScaleDeformableAttention(nn.Module):
 
     # ------------------------------------------------------------------ batch-first core
     def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
-                   level_start_index, query_plus_pos=None, value_projected=None):
+                   level_start_index, query_plus_pos=None, value_projected=None, defer_output_proj=False):
         """query [B,Nq,C]; value [B,S,C]; returns output_proj(msda(...)) + identity, [B,Nq,C].
         query_plus_pos: `query + query_pos` if the caller already holds it.  value_projected [B,S,C]: this module's
         value_proj(value) with the padding mask applied, if the caller already computed it (the decoder projects the
-        memory for all its layers in one GEMM)."""
+        memory for all its layers in one GEMM).  defer_output_proj: where the packed encoder kernel served the call, return
+        DeferredOutputProj(attention output, identity) instead -- the caller folds `output_proj(.) + identity` into its next
+        kernel (transformer_layers.BaseTransformerLayer: the fused FFN)."""
         if not query.is_cuda:
             return self._forward_cpu(query if query_plus_pos is None else None, query_plus_pos, value, identity, query_pos,
                                      key_padding_mask, reference_points, spatial_shapes, value_projected)
@@ -184,6 +194,8 @@ class MultiScaleDeformableAttention(nn.Module):
                     out = hip_ops.msda_encoder_packed(both[0], host_shapes, both[1], P,
                                                       self._encoder_windows_packed(host_shapes), counts, True)
                     if out is not None:
+                        if defer_output_proj:
+                            return DeferredOutputProj(out.view(B, Nq, -1), identity)
                         return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
             if value.dtype == torch.bfloat16:
                 # bf16 model: the kernel's value map is FP16 (packed-half blend; the projection's fp32 accumulators keep
@@ -202,6 +214,8 @@ class MultiScaleDeformableAttention(nn.Module):
                           else hip_ops.linear(query, Wp, bp))
                 out = hip_ops.msda_encoder_packed(v, host_shapes, packed, P, self._encoder_windows_packed(host_shapes), counts, hm)
             if out is not None:
+                if defer_output_proj:
+                    return DeferredOutputProj(out.view(B, Nq, -1), identity)
                 return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
             if v is not None and hm and v.dtype == value.dtype:
                 value_projected = v.permute(0, 2, 1, 3).reshape(B, S, -1)   # (declined shape: the general kernel's layout)

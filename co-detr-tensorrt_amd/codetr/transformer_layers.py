@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import hip_ops
-from .multi_scale_deformable_attention import MultiScaleDeformableAttention
+from .multi_scale_deformable_attention import DeferredOutputProj, MultiScaleDeformableAttention
 
 
 def build_norm(cfg, dim):
@@ -83,11 +83,22 @@ class FFN(nn.Module):
         return (self.fp8_mode == "run" and hasattr(self, "_fp8_scales") and not torch.is_grad_enabled()
                 and hip_ops.ffn_fp8_supported(x, fc1.weight, fc2.weight, self.act))
 
-    def forward_norm(self, x, norm, pos=None, norm_in=None):
+    def takes_output_proj(self, x):
+        """True when forward_norm can fold a preceding attention's `output_proj(attn) + identity` into its launch
+        (the fp16 / bf16 fused kernel; not the fp8 mode, whose kernel has no such form)"""
+        return hip_ops.FFN_OPROJ and self.fp8_mode not in ("calibrate", "run") and self.fused_supported(x)
+
+    def forward_norm(self, x, norm, pos=None, norm_in=None, oproj=None):
         """LayerNorm(x + ffn(x)) -- and, with `pos`, also that + pos -- in the fused kernel's epilogue
-        (call only when fused_supported(x)).  norm_in: a LayerNorm applied to x first, inside the kernel."""
+        (call only when fused_supported(x)).  norm_in: a LayerNorm applied to x first, inside the kernel.
+        oproj = (output_proj Linear, identity): x is an attention output and the kernel starts with
+        identity + output_proj(x) (call only when takes_output_proj(x))."""
         fc1, fc2 = self.layers[0][0], self.layers[1]
         ln_in = None if norm_in is None else (norm_in.weight, norm_in.bias, norm_in.eps)
+        if oproj is not None:
+            lin, identity = oproj
+            return hip_ops.ffn_oproj_fused(x, lin.weight, lin.bias, identity, fc1.weight, fc1.bias, fc2.weight, fc2.bias,
+                                           ln=(norm.weight, norm.bias, norm.eps), pos=pos, ln_in=ln_in)
         if self.fp8_mode == "calibrate":
             self._fp8_observe(x, ln_in)
         elif self._fp8_ready(x):
@@ -223,6 +234,7 @@ class BaseTransformerLayer(nn.Module):
         ops = self.operation_order
         skip_norm = False
         norm_in = None  # a LayerNorm deferred into the fused FFN kernel
+        oproj = None    # (output_proj, identity) of a deformable attention, deferred into the same kernel
         for oi, op in enumerate(ops):
             if skip_norm and op == "norm":
                 skip_norm = False
@@ -236,9 +248,18 @@ class BaseTransformerLayer(nn.Module):
                     mask = query_key_padding_mask if op == "self_attn" else key_padding_mask
                     qpp = query_plus_pos if (ai == 0 and oi == 0) else None  # valid for the layer's input only
                     vp = kw.get("value_projected") if op == "cross_attn" else None
+                    # (attn, norm, ffn, norm) of a post-norm layer whose FFN runs fused: output_proj + identity go there too
+                    defer = (not self.pre_norm and op == "self_attn" and tuple(ops[oi + 1:oi + 4]) == ("norm", "ffn", "norm")
+                             and att.output_proj.bias is not None and not torch.is_grad_enabled()
+                             and all(isinstance(n, nn.LayerNorm) and n.weight is not None and n.weight.dtype == query.dtype
+                                     for n in self.norms[ni:ni + 2])
+                             and self.ffns[fi].takes_output_proj(query))
                     query = att.forward_bf(query, val, query if res is None else res, query_pos, mask,
                                            kw["reference_points"], kw["spatial_shapes"], kw["level_start_index"],
-                                           query_plus_pos=qpp, value_projected=vp)
+                                           query_plus_pos=qpp, value_projected=vp, defer_output_proj=defer)
+                    if isinstance(query, DeferredOutputProj):
+                        oproj = (att.output_proj, query.identity)
+                        query = query.attn
                 else:
                     if op == "self_attn":
                         query = att.forward_bf(query, query, query, res, query_pos, query_pos)
@@ -257,6 +278,8 @@ class BaseTransformerLayer(nn.Module):
                     # fused FFN kernel applies it to its input rows in registers
                     norm_in = n
                 else:
+                    if oproj is not None:
+                        raise AssertionError("an output projection was deferred into a fused FFN that does not follow")
                     query = hip_ops.layer_norm(query, n.weight, n.bias, n.eps)
                 ni += 1
             else:  # ffn
@@ -269,16 +292,16 @@ class BaseTransformerLayer(nn.Module):
                     # `+ query_pos`) ride in the fused FFN kernel's epilogue
                     pos = query_pos if (want_plus_pos and want_pos_output and last_pair and query_pos is not None
                                         and query_pos.shape == query.shape) else None
-                    r = ffn.forward_norm(query, self.norms[ni], pos, norm_in)
-                    norm_in = None
+                    r = ffn.forward_norm(query, self.norms[ni], pos, norm_in, oproj)
+                    norm_in = oproj = None
                     if pos is not None:
                         query, plus_pos_out = r
                     else:
                         query = r
                     skip_norm = True
                 else:
-                    if norm_in is not None:
-                        raise AssertionError("a LayerNorm was deferred into a fused FFN that did not run")
+                    if norm_in is not None or oproj is not None:
+                        raise AssertionError("a LayerNorm / output projection was deferred into a fused FFN that did not run")
                     query = ffn(query, identity if self.pre_norm else None)
                 fi += 1
         if want_plus_pos:

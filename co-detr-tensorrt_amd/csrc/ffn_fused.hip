@@ -34,7 +34,8 @@
 
 // diagnostic builds only (tools/micro/ffn_ablate.hip -DCODETR_FFN_ABL=mask; WRONG results by construction, never shipped):
 // 1 = no LDS-DMA inside the chunk loop, 2 = no MFMAs, 4 = no W fragment reads inside the chunk loop, 8 = no waits / barriers in the
-// chunk loop, 16 = no ReLU / pack between the products (B operand of product 2 = stale registers)
+// chunk loop, 16 = no ReLU / pack between the products (B operand of product 2 = stale registers); OPROJ form: 32 = no identity
+// loads, 64 = no accumulator -> operand transform (operand = the attention rows), 128 = no product-0 MFMAs, 256 = no Wo staging
 #ifdef CODETR_FFN_ABL
 #define CODETR_FFN_ABL_MASK CODETR_FFN_ABL
 #else
@@ -107,15 +108,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // chunks arrive.
 // MTT = 16-row tiles per wave: 2 (128 rows per workgroup, the product shape) or 1 (64 rows per workgroup: a tile takes
 // half the MFMA time for the same weight stream -- used for a left-over partial round, see ffn_entry).
-template <class ET, int MTT = 2>
+//
+// OPROJ (the encoder layer's attention output projection folded in -- reference transformer_mmcv.py post-norm layer:
+// x1 = norm1(identity + output_proj(attn)), y = norm2(x1 + ffn(x1))): X holds the ATTENTION OUTPUT rows, and a tile starts with
+// a "product 0"  T^T[n][m] = Wo . A^T  (4 chunks of 64 output channels through the W1 ring: 256 MFMAs per wave on top of the
+// tile's 4096), + bo -> E, + identity row (ID, read here) -> E, LayerNorm (ln_in) -> E: the first product's operand.  That
+// operand is produced in the EPILOGUE's lane layout (a lane owns 8 consecutive channels 32 j + cbase ..), which is the MFMA
+// B layout with lane groups 1 and 2 exchanged; the exchange is baked into W1's columns once on the host
+// (codetr_ffn_oproj_w1_index), so no data moves between lanes and the epilogue's identity is the operand register itself.
+// What it replaces: a GEMM launch that reads the attention output and the identity and writes x0 = identity +
+// output_proj(attn) (1.26 GB at four 1920x1280 images), and this kernel's read of x0 (0.42 GB).
+template <class ET, int MTT = 2, bool OPROJ = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, int M,
     int Hd, const unsigned short* __restrict__ ln_g, const unsigned short* __restrict__ ln_b, float ln_eps,
     const unsigned short* __restrict__ pos, unsigned short* __restrict__ Y2,
-    const unsigned short* __restrict__ lnin_g, const unsigned short* __restrict__ lnin_b, float lnin_eps, int ntiles) {
-  // [W1 stage 0 | W1 stage 1 | W2 stage 0 | W2 stage 1 | b1 | LayerNorm gamma, beta | b2]: 145.5 KiB, one object
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2 + 1536];
+    const unsigned short* __restrict__ lnin_g, const unsigned short* __restrict__ lnin_b, float lnin_eps, int ntiles,
+    const unsigned short* __restrict__ Wo = nullptr, const unsigned short* __restrict__ bo = nullptr,
+    const unsigned short* __restrict__ ID = nullptr) {
+  // [W1 stage 0 | W1 stage 1 | W2 stage 0 | W2 stage 1 | b1 | LayerNorm gamma, beta | b2 | bo]: 146 KiB, one object
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes + kMaxHidden * 2 + 2048];
   using E = typename ET::e;
   using V8 = typename ET::v8;
   using V4 = typename ET::v4;
@@ -129,6 +142,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   unsigned short* sB1 = reinterpret_cast<unsigned short*>(lds + 2 * kStageBytes);
   unsigned short* sLn = reinterpret_cast<unsigned short*>(lds + 2 * kStageBytes + kMaxHidden * 2);  // gamma[256], beta[256]
   unsigned short* sB2 = sLn + 512;
+  unsigned short* sBo = sB2 + 256;
 
   // LDS-DMA geometry (the images of the previous version of this kernel: tests/test_lds_bank_model.py).
   // W1 chunk: 64 rows x 32 chunks of 16 B; piece p (0..7) = rows 8 p + (tid >> 5), position tid & 31 of row r holds
@@ -141,16 +155,27 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   const unsigned w2_voff = (unsigned)((tid >> 3) * Hd * 2 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16));
   const unsigned char* W1b = reinterpret_cast<const unsigned char*>(W1);
   const unsigned char* W2b = reinterpret_cast<const unsigned char*>(W2);
+  const unsigned char* Wob = reinterpret_cast<const unsigned char*>(Wo);
   auto stage_w1 = [&](int p, int c, unsigned char* dst) {
     dma16(W1b + (size_t)c * kW1Bytes + p * 4096, w1_voff[p & 1], dst + (p * kThreads + wave * 64) * 16);
+  };
+  auto stage_wo = [&](int p, int c, unsigned char* dst) {   // chunk c of Wo: rows 64 c .. + 63, the W1 chunk geometry
+    dma16(Wob + (size_t)c * kW1Bytes + p * 4096, w1_voff[p & 1], dst + (p * kThreads + wave * 64) * 16);
   };
   auto stage_w2 = [&](int q, int c, unsigned char* dst) {
     dma16(W2b + (size_t)q * 64 * Hd + c * (BH * 2), w2_voff, dst + (q * kThreads + wave * 64) * 16);
   };
 #pragma unroll
-  for (int p = 0; p < 8; ++p) stage_w1(p, 0, ringA);
+  for (int p = 0; p < 8; ++p) {
+    if (OPROJ) stage_wo(p, 0, ringA);
+    else stage_w1(p, 0, ringA);
+  }
 #pragma unroll
   for (int p = 0; p < 8; ++p) stage_w2(p, 0, ringB);
+  if (OPROJ) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_wo(p, 1, ringA + kW1Bytes);
+  }
 
   // a tile's input rows as they come from memory (B-operand layout: lane (j = l15, g) holds X[m][32 ks + 8 g .. + 7])
   V8 xn[MT][8];
@@ -171,9 +196,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     *reinterpret_cast<s16x8*>(sLn + (tid >> 5) * 256 + i * 8) = *reinterpret_cast<const s16x8*>((tid >> 5 ? ln_b : ln_g) + i * 8);
   }
   if (tid >= 64 && tid < 96) *reinterpret_cast<s16x8*>(sB2 + (tid - 64) * 8) = *reinterpret_cast<const s16x8*>(b2 + (tid - 64) * 8);
+  if (OPROJ && tid >= 96 && tid < 128) *reinterpret_cast<s16x8*>(sBo + (tid - 96) * 8) = *reinterpret_cast<const s16x8*>(bo + (tid - 96) * 8);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tables written; the first barrier below publishes them
 
   int gc = 0;  // chunks consumed so far: ring stage = gc & 1
+  int ga = 0;  // W1-ring stages consumed so far (OPROJ: three of Wo's four chunks per tile pass through it too)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m0 = tile * TR + wave * WR;
     // ---- the MFMA operand of the first product and the identity: the rows, or their LayerNorm (the post-norm layer's
@@ -181,6 +208,139 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     // (8 k-steps x 8 values each): statistics are two xor-shuffles away; fp32 two-pass like layernorm_kernel, result
     // rounded to E = the tensor the separate kernel would have written.
     V8 xf[MT][8];
+    f32x4 yacc[16][MT];
+    if constexpr (OPROJ) {
+      // ---- product 0 (see the kernel's header): x1 = LayerNorm(identity + E(Wo . attn + bo)), in the epilogue's lane layout
+      const int cb = 16 * (grp & 1) + 8 * (grp >> 1);
+      // identity rows, in the epilogue's lane layout: requested now, consumed behind the 256 MFMAs below (requested a tile
+      // ahead, with the attention rows, they measured the same and cost the bf16 form 76 bytes of scratch)
+      V8 idn[MT][8];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int m = m0 + mt * 16 + l15;
+        m = m < M ? m : M - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (CODETR_FFN_ABL_MASK & 32) idn[mt][j] = xn[mt][j];
+          else idn[mt][j] = *reinterpret_cast<const V8*>(ID + (size_t)m * C + 32 * j + cb);
+        }
+      }
+      // the tile's attention rows were requested after the LDS-DMA pieces of Wo[0] / W2[0]: once they have landed, so have
+      // those (vmcnt is in order) -- the first chunk takes no counted wait, as chunk 0 of the plain kernel
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(xn[mt][7]) : "memory");
+#pragma unroll
+      for (int nt = 0; nt < 16; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) yacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // Wo's chunks run two products ahead of their use, through three buffers -- A0 / A1 = the W1 ring's stages and the stage
+      // of the W2 ring that is free until chunk 0's second product (B1):
+      //   Wo[0] -> A0 during the previous tile's last first product (initially: before the loop), Wo[1] -> A1 at the start
+      //   of its epilogue (in front of this tile's row loads), Wo[2] -> B1 during chunk 0 here, Wo[3] -> A0 during chunk 1, W1[0] -> A1 during chunk 2.
+      // Wo[0] / Wo[1] / W2[0] are older than the tile's rows (waited for above); Wo[2] and Wo[3] take a counted wait (the 8
+      // pieces issued during the chunk before are the younger ones).
+      unsigned char* const A0 = ringA + (ga & 1) * kW1Bytes;
+      unsigned char* const A1 = ringA + ((ga + 1) & 1) * kW1Bytes;
+      unsigned char* const B1 = ringB + ((gc + 1) & 1) * kW2Bytes;
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const unsigned char* sW = pc == 0 ? A0 : pc == 1 ? A1 : pc == 2 ? B1 : A0;
+        if (pc >= 2 && !(CODETR_FFN_ABL_MASK & 256)) wait_vmcnt<8>();
+        __builtin_amdgcn_s_barrier();
+        auto read_wo = [&](int ks, V8 (&a)[4]) {
+#pragma unroll
+          for (int ht = 0; ht < 4; ++ht) {
+            const int row = ht * 16 + l15;
+            const int chunk = (ks * 4 + grp) ^ (row & 15);
+            a[ht] = *reinterpret_cast<const V8*>(sW + row * (C * 2) + chunk * 16);
+          }
+        };
+        V8 aw[2][4];
+        read_wo(0, aw[0]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks + 1 < 8) read_wo(ks + 1, aw[(ks + 1) & 1]);
+          if (pc == 0 && !(CODETR_FFN_ABL_MASK & 256)) stage_wo(ks, 2, B1);
+          else if (pc == 1 && !(CODETR_FFN_ABL_MASK & 256)) stage_wo(ks, 3, A0);
+          else if (pc == 2) stage_w1(ks, 0, A1);   // the tile's first W1 chunk: read from A1 by chunk 0 (ga + 3)
+#pragma unroll
+          for (int i = 0; i < 4 * MT; ++i)
+            if (!(CODETR_FFN_ABL_MASK & 128))
+              yacc[4 * pc + i / MT][i % MT] = ET::mfma(aw[ks & 1][i / MT], xn[i % MT][ks], yacc[4 * pc + i / MT][i % MT]);
+            else asm volatile("" ::"v"(aw[ks & 1][i / MT]));
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 2, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      ga += 3;
+      // accumulators -> E (+ bo), lanes 16 apart swap halves (as the epilogue), + identity -> E, LayerNorm -> E
+      const int oddp = grp & 1;
+      if (CODETR_FFN_ABL_MASK & 64) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            xf[mt][j] = xn[mt][j];
+            asm volatile("" ::"v"(idn[mt][j]), "v"(yacc[2 * j][mt]), "v"(yacc[2 * j + 1][mt]));
+          }
+      } else
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        unsigned yp[16][2];
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt) {
+          const V4 bb = *reinterpret_cast<const V4*>(sBo + nt * 16 + grp * 4);
+          const V4 y = {(E)(yacc[nt][mt][0] + (float)bb[0]), (E)(yacc[nt][mt][1] + (float)bb[1]),
+                        (E)(yacc[nt][mt][2] + (float)bb[2]), (E)(yacc[nt][mt][3] + (float)bb[3])};
+          __builtin_memcpy(yp[nt], &y, 8);
+        }
+        float o[8][8];
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned s0 = oddp ? yp[2 * j][0] : yp[2 * j + 1][0], s1 = oddp ? yp[2 * j][1] : yp[2 * j + 1][1];
+          const unsigned k0 = oddp ? yp[2 * j + 1][0] : yp[2 * j][0], k1 = oddp ? yp[2 * j + 1][1] : yp[2 * j][1];
+          const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+          const unsigned z[4] = {oddp ? r0 : k0, oddp ? r1 : k1, oddp ? k0 : r0, oddp ? k1 : r1};   // channels 32 j + cb .. + 7
+          V8 yv;
+          __builtin_memcpy(&yv, z, 16);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o[j][e] = (float)(E)((float)yv[e] + (float)idn[mt][j][e]);   // identity + output_proj(attn): E + E -> E
+            sm += o[j][e];
+          }
+        }
+        if (lnin_g) {
+          sm += __shfl_xor(sm, 16, 64);
+          sm += __shfl_xor(sm, 32, 64);
+          const float mean = sm * (1.0f / C);
+          float q = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float d = o[j][e] - mean;
+              q = fmaf(d, d, q);
+            }
+          q += __shfl_xor(q, 16, 64);
+          q += __shfl_xor(q, 32, 64);
+          const float rstd = rsqrtf(q * (1.0f / C) + lnin_eps);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const V8 gw = *reinterpret_cast<const V8*>(lnin_g + 32 * j + cb);
+            const V8 gb = *reinterpret_cast<const V8*>(lnin_b + 32 * j + cb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[j][e] = fmaf((o[j][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xf[mt][j][e] = (E)o[j][e];
+      }
+    } else {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (lnin_g) {
@@ -221,9 +381,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       // (vmcnt is in order, so the older pieces have landed too), whatever it does with the copies.
       asm volatile("" ::"v"(xn[mt][7]) : "memory");
     }
+    }
     // (b2 is added in the epilogue, from LDS: as the accumulators' initial value it is loop-invariant across tiles and
     // the compiler keeps all 64 converted values alive through the whole loop -- spills)
-    f32x4 yacc[16][MT];
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt)
 #pragma unroll
@@ -239,14 +399,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     // W1[c+1] goes to the stage product 1 of chunk c-1 read (every wave passed M of c-1), W2[c+1] to the one product 2
     // of chunk c-1 read (every wave passed T of c).  Chunk nchunks wraps to chunk 0 of the next tile (past the last
     // tile: a fetch nobody reads, drained at the end).
-    for (int c = 0; c < nchunks; ++c, ++gc) {
+    for (int c = 0; c < nchunks; ++c, ++gc, ++ga) {
       const int cn = c + 1 < nchunks ? c + 1 : 0;
-      const unsigned char* sW1 = ringA + (gc & 1) * kW1Bytes;
+      const unsigned char* sW1 = ringA + (ga & 1) * kW1Bytes;
       const unsigned char* sW2 = ringB + (gc & 1) * kW2Bytes;
-      unsigned char* nW1 = ringA + ((gc + 1) & 1) * kW1Bytes;
+      unsigned char* nW1 = ringA + ((ga + 1) & 1) * kW1Bytes;
       unsigned char* nW2 = ringB + ((gc + 1) & 1) * kW2Bytes;
+      const unsigned char* nsrc1 = (OPROJ && c + 1 == nchunks) ? Wob : W1b + (size_t)cn * kW1Bytes;
       if (!(CODETR_FFN_ABL_MASK & 8)) {
         if (c > 0) wait_vmcnt<8>();
+        else if (OPROJ) wait_vmcnt<0>();   // W1[0] was staged during product 0's third chunk
         __builtin_amdgcn_s_barrier();  // T
       }
 
@@ -275,7 +437,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         if (ks + 1 < 8 && !(CODETR_FFN_ABL_MASK & 4)) read_w1(ks + 1, aw[(ks + 1) & 1]);
-        if (!(CODETR_FFN_ABL_MASK & 1)) stage_w1(ks, cn, nW1);
+        // (OPROJ: the next tile starts with product 0 -- the source is a scalar select, no branch inside the schedule)
+        if (!(CODETR_FFN_ABL_MASK & 1)) dma16(nsrc1 + ks * 4096, w1_voff[ks & 1], nW1 + (ks * kThreads + wave * 64) * 16);
 #pragma unroll
         for (int i = 0; i < 4 * MT; ++i)
           if (!(CODETR_FFN_ABL_MASK & 2))
@@ -360,6 +523,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     // The next tile's input rows are requested as the epilogue goes (each half once the registers of the half just
     // written are free) and arrive while it runs.
     const int next_tile = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+    if (OPROJ) {
+      // Wo[1] -> the W1 stage the last chunk's first product read (every wave is past that chunk's barrier M; nobody reads
+      // the W1 ring in a second product).  Issued BEFORE the next tile's rows, so "rows landed" still implies "Wo[1] landed".
+#pragma unroll
+      for (int p = 0; p < 8; ++p) stage_wo(p, 1, ringA + ((ga + 1) & 1) * kW1Bytes);
+    }
     const int odd = grp & 1;
     const int cbase = 16 * odd + 8 * (grp >> 1);
     const int src_lane4 = (l15 + 16 * (2 * odd + (grp >> 1))) * 4;   // byte address of the lane that holds the identity
@@ -388,6 +557,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         __builtin_memcpy(&yv, z, 16);
         int xw[4];
         __builtin_memcpy(xw, &xf[mt][j], 16);
+        if (!OPROJ)   // (OPROJ: the operand already has the epilogue's lane layout)
 #pragma unroll
         for (int d = 0; d < 4; ++d) xw[d] = __builtin_amdgcn_ds_bpermute(src_lane4, xw[d]);
         __builtin_memcpy(&xid, xw, 16);
@@ -472,9 +642,14 @@ int ffn_entry(void* stream, const void* x_dev, const void* w1_dev, const void* b
                             const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
                             int64_t hidden, const void* ln_in_gamma_dev, const void* ln_in_beta_dev, float ln_in_eps,
                             const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps, const void* pos_dev,
-                            void* y_plus_pos_dev) {
+                            void* y_plus_pos_dev, const void* wo_dev = nullptr, const void* bo_dev = nullptr,
+                            const void* identity_dev = nullptr) {
   const void* w2_dev = w2_packed_dev;
   if (!x_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !y_dev || M <= 0 || hidden <= 0) return CODETR_E_BADARG;
+  const bool oproj = wo_dev != nullptr;
+  if (oproj && (!bo_dev || !identity_dev)) return CODETR_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(wo_dev) | reinterpret_cast<uintptr_t>(bo_dev) | reinterpret_cast<uintptr_t>(identity_dev)) & 15)
+    return CODETR_E_BADARG;
   if ((ln_gamma_dev == nullptr) != (ln_beta_dev == nullptr) || (pos_dev == nullptr) != (y_plus_pos_dev == nullptr) ||
       (ln_in_gamma_dev == nullptr) != (ln_in_beta_dev == nullptr))
     return CODETR_E_BADARG;
@@ -504,14 +679,20 @@ int ffn_entry(void* stream, const void* x_dev, const void* w1_dev, const void* b
     const unsigned blocks = (unsigned)(ntiles < cus ? ntiles : cus);
     const size_t off = (size_t)row0 * C;
     auto at = [&](const void* p) { return p ? static_cast<const unsigned short*>(p) + off : nullptr; };
-    hipLaunchKernelGGL((ffn_fused_kernel<ET, MTT>), dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                       at(x_dev), static_cast<const unsigned short*>(w1_dev), static_cast<const unsigned short*>(b1_dev),
-                       static_cast<const unsigned short*>(w2_dev), static_cast<const unsigned short*>(b2_dev),
-                       const_cast<unsigned short*>(at(y_dev)), (int)rows, (int)hidden,
-                       static_cast<const unsigned short*>(ln_gamma_dev), static_cast<const unsigned short*>(ln_beta_dev),
-                       ln_eps, at(pos_dev), const_cast<unsigned short*>(at(y_plus_pos_dev)),
-                       static_cast<const unsigned short*>(ln_in_gamma_dev),
-                       static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps, ntiles);
+#define CODETR_FFN_ARGS \
+    at(x_dev), static_cast<const unsigned short*>(w1_dev), static_cast<const unsigned short*>(b1_dev), \
+        static_cast<const unsigned short*>(w2_dev), static_cast<const unsigned short*>(b2_dev), \
+        const_cast<unsigned short*>(at(y_dev)), (int)rows, (int)hidden, static_cast<const unsigned short*>(ln_gamma_dev), \
+        static_cast<const unsigned short*>(ln_beta_dev), ln_eps, at(pos_dev), const_cast<unsigned short*>(at(y_plus_pos_dev)), \
+        static_cast<const unsigned short*>(ln_in_gamma_dev), static_cast<const unsigned short*>(ln_in_beta_dev), ln_in_eps, ntiles
+    if (oproj)
+      hipLaunchKernelGGL((ffn_fused_kernel<ET, MTT, true>), dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                         CODETR_FFN_ARGS, static_cast<const unsigned short*>(wo_dev),
+                         static_cast<const unsigned short*>(bo_dev), at(identity_dev));
+    else
+      hipLaunchKernelGGL((ffn_fused_kernel<ET, MTT, false>), dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                         CODETR_FFN_ARGS);
+#undef CODETR_FFN_ARGS
   };
   if (M1 > 0) launch(std::integral_constant<int, 2>{}, 0, M1);
   if (split) launch(std::integral_constant<int, 1>{}, M1, M - M1);
@@ -549,6 +730,40 @@ int codetr_ffn_relu_ln2_bf16(void* stream, const void* x_dev, const void* w1_dev
                             void* y_plus_pos_dev) {
   return ffn_entry<BF16E>(stream, x_dev, w1_dev, b1_dev, w2_packed_dev, b2_dev, y_dev, M, C_in, hidden, ln_in_gamma_dev,
                          ln_in_beta_dev, ln_in_eps, ln_gamma_dev, ln_beta_dev, ln_eps, pos_dev, y_plus_pos_dev);
+}
+
+int codetr_ffn_oproj_relu_ln2_f16(void* stream, const void* attn_dev, const void* wo_dev, const void* bo_dev,
+                                  const void* identity_dev, const void* w1_perm_dev, const void* b1_dev,
+                                  const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                                  int64_t hidden, const void* ln_in_gamma_dev, const void* ln_in_beta_dev, float ln_in_eps,
+                                  const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps, const void* pos_dev,
+                                  void* y_plus_pos_dev) {
+  if (!wo_dev) return CODETR_E_BADARG;
+  return ffn_entry<F16E>(stream, attn_dev, w1_perm_dev, b1_dev, w2_packed_dev, b2_dev, y_dev, M, C_in, hidden, ln_in_gamma_dev,
+                         ln_in_beta_dev, ln_in_eps, ln_gamma_dev, ln_beta_dev, ln_eps, pos_dev, y_plus_pos_dev, wo_dev, bo_dev,
+                         identity_dev);
+}
+
+int codetr_ffn_oproj_relu_ln2_bf16(void* stream, const void* attn_dev, const void* wo_dev, const void* bo_dev,
+                                   const void* identity_dev, const void* w1_perm_dev, const void* b1_dev,
+                                   const void* w2_packed_dev, const void* b2_dev, void* y_dev, int64_t M, int64_t C_in,
+                                   int64_t hidden, const void* ln_in_gamma_dev, const void* ln_in_beta_dev, float ln_in_eps,
+                                   const void* ln_gamma_dev, const void* ln_beta_dev, float ln_eps, const void* pos_dev,
+                                   void* y_plus_pos_dev) {
+  if (!wo_dev) return CODETR_E_BADARG;
+  return ffn_entry<BF16E>(stream, attn_dev, w1_perm_dev, b1_dev, w2_packed_dev, b2_dev, y_dev, M, C_in, hidden,
+                          ln_in_gamma_dev, ln_in_beta_dev, ln_in_eps, ln_gamma_dev, ln_beta_dev, ln_eps, pos_dev,
+                          y_plus_pos_dev, wo_dev, bo_dev, identity_dev);
+}
+
+/* column j of the permuted W1 takes column idx[j] of nn.Linear's weight: the epilogue's lane layout (a lane owns channels
+ * 32 s + 16 (g & 1) + 8 (g >> 1) .. + 7 of a row) as MFMA k-slot order (32 s + 8 g ..) */
+int codetr_ffn_oproj_w1_index(int64_t C_in, int32_t* idx_host) {
+  if (!idx_host || C_in != C) return CODETR_E_BADARG;
+  for (int s = 0; s < C / 32; ++s)
+    for (int g = 0; g < 4; ++g)
+      for (int e = 0; e < 8; ++e) idx_host[32 * s + 8 * g + e] = 32 * s + 16 * (g & 1) + 8 * (g >> 1) + e;
+  return 0;
 }
 
 int codetr_ffn_relu_ln_f16(void* stream, const void* x_dev, const void* w1_dev, const void* b1_dev,

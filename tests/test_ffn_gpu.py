@@ -191,3 +191,93 @@ def test_ffn_bf16_layernorm_pos_epilogue_matches_three_kernels():
     r1 = hip_ops.ffn_fused(x, w1, b1, w2, b2, ln=(gam, bet, 1e-5), ln_in=(gam, bet, 1e-5))
     torch.testing.assert_close(r1.float(), r0.float(), rtol=0, atol=6e-2)
     assert (r1 != r0).float().mean() < 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,with_ln_in,with_pos", [(128 * 256 + 3333, True, True), (30785, True, False), (128 * 3 + 5, False, False)])
+def test_ffn_with_output_projection_folded_in(M, with_ln_in, with_pos, dtype):
+    """codetr_ffn_oproj_relu_ln2_*: x0 = identity + E(attn Wo^T + bo); x1 = LN_in(x0); y = LN(x1 + ffn(x1)) (+ pos) in ONE
+    launch == codetr_linear_* with the residual epilogue, then the fused FFN kernel with ln_in.  The out-projection
+    accumulates in a different order than the GEMM kernel and the norm statistics in a different lane order, so a few x1
+    values differ in their last bit: 1 ulp of the normalised output scale, the vast majority bit-identical; and against the
+    fp32 composition of the same operands."""
+    from codetr import _cabi, hip_ops
+
+    g = torch.Generator(device=DEV).manual_seed(M)
+    r = lambda *s, k=1.0: (torch.randn(*s, device=DEV, generator=g) * k).to(dtype)   # noqa: E731
+    attn, ident, pos = r(M, 256), r(M, 256, k=2.0), r(M, 256)
+    wo, bo = r(256, 256, k=1 / 16), r(256, k=0.5)
+    w1, b1 = r(2048, 256, k=1 / 16), r(2048)
+    w2, b2 = r(256, 2048, k=1 / 45), r(256)
+    gam, bet = (1 + 0.1 * torch.randn(256, device=DEV, generator=g)).to(dtype), r(256, k=0.1)
+    gi, bi = (1 + 0.1 * torch.randn(256, device=DEV, generator=g)).to(dtype), r(256, k=0.1)
+    ln, ln_in = (gam, bet, 1e-5), ((gi, bi, 1e-5) if with_ln_in else None)
+    with torch.no_grad():
+        x0 = hip_ops.linear(attn, wo, bo, residual=ident)
+        ref = hip_ops.ffn_fused(x0, w1, b1, w2, b2, ln=ln, pos=pos if with_pos else None, ln_in=ln_in)
+        before = dict(_cabi.CALLS)
+        got = hip_ops.ffn_oproj_fused(attn, wo, bo, ident, w1, b1, w2, b2, ln, pos=pos if with_pos else None, ln_in=ln_in)
+        torch.cuda.synchronize()
+        assert _cabi.CALLS["ffn_oproj_fused"] == before["ffn_oproj_fused"] + 1
+        assert _cabi.CALLS["linear"] == before["linear"] and _cabi.CALLS["layernorm"] == before["layernorm"]
+    if not with_pos:
+        ref, got = (ref,), (got,)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    for a, b, scale in zip(got, ref, (4.0, 8.0)):
+        assert a.shape == b.shape and a.dtype == dtype
+        err = (a.float() - b.float()).abs()
+        assert float(err.max()) <= 4 * ulp * scale, float(err.max())
+        assert float((a != b).float().mean()) < (0.03 if dtype == torch.float16 else 0.06)
+    if with_pos:
+        assert torch.equal(got[1], got[0] + pos)
+    # fp32 composition of the same operands (roundings at the same places as the kernels': E after the out-projection,
+    # after the residual, after the norm, after the hidden activation, after the second product, after the last residual)
+    E = lambda t: t.to(dtype).float()   # noqa: E731
+    f0 = E(E(attn.float() @ wo.float().t() + bo.float()) + ident.float())
+    f1 = E(torch.nn.functional.layer_norm(f0, (256,), gi.float(), bi.float(), 1e-5)) if with_ln_in else f0
+    h = E(torch.relu(f1 @ w1.float().t() + b1.float()))
+    f2 = E(E(h @ w2.float().t() + b2.float()) + f1)
+    fy = torch.nn.functional.layer_norm(f2, (256,), gam.float(), bet.float(), 1e-5)
+    err = (got[0].float() - fy).abs()
+    # a 1-ulp flip of x1 moves the normalised output by a few ulp on the rows it touches: bound the mean tightly, the max loosely
+    assert float(err.mean()) < ulp * 1.0 and float(err.max()) < 24 * ulp * 4.0, (float(err.mean()), float(err.max()))
+
+
+def test_encoder_layer_defers_the_output_projection_into_the_ffn_launch():
+    """DetrTransformerEncoder on the packed MSDA path: per layer ONE projection launch, the MSDA kernel, ONE FFN launch
+    (output_proj, norm1, FFN, norm2, + query_pos inside) -- and the same result as with the switch off."""
+    from codetr import _cabi, hip_ops
+    from codetr.transformer import DetrTransformerEncoder
+
+    torch.manual_seed(0)
+    cfg = dict(type="BaseTransformerLayer",
+               attn_cfgs=dict(type="MultiScaleDeformableAttention", embed_dims=256, num_levels=5, dropout=0.0),
+               feedforward_channels=2048, ffn_dropout=0.0, operation_order=("self_attn", "norm", "ffn", "norm"))
+    enc = DetrTransformerEncoder(transformerlayers=cfg, num_layers=2).to(DEV).half().eval()
+    shapes = [(160, 200), (80, 100), (40, 50), (20, 25), (10, 13)]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    q = torch.randn(1, S, 256, device=DEV, generator=g).half()
+    pos = torch.randn(1, S, 256, device=DEV, generator=g).half()
+    from codetr.transformer import _shape_tensors
+
+    ss, ls = _shape_tensors(shapes, torch.device(DEV))
+    mask = torch.zeros(1, S, dtype=torch.bool, device=DEV)
+    vr = torch.ones(1, 5, 2, device=DEV, dtype=torch.float16)
+    _, ref, _, _ = hip_ops.encoder_geometry(vr, mask, shapes)
+    # fp32 reference points from the valid pixel counts (the packed kernel's contract): an unpadded image
+    ref._codetr_valid_counts = torch.tensor([[[w, h] for h, w in shapes]], dtype=torch.float32, device=DEV)
+    kw = dict(reference_points=ref, spatial_shapes=ss, level_start_index=ls)
+    before = dict(_cabi.CALLS)
+    with torch.no_grad():
+        out = enc.forward_bf(q, pos, mask, **kw)
+    d = {k: _cabi.CALLS[k] - before[k] for k in ("ffn_oproj_fused", "encoder_projections", "msda_encoder_packed", "layernorm")}
+    assert d == {"ffn_oproj_fused": 2, "encoder_projections": 2, "msda_encoder_packed": 2, "layernorm": 0}, d
+    hip_ops.FFN_OPROJ = False
+    try:
+        with torch.no_grad():
+            out0 = enc.forward_bf(q, pos, mask, **kw)
+    finally:
+        hip_ops.FFN_OPROJ = True
+    torch.testing.assert_close(out.float(), out0.float(), rtol=0, atol=1.6e-2)
+    assert float((out.float() - out0.float()).abs().mean()) < 1e-3

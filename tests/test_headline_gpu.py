@@ -94,7 +94,10 @@ def test_headline_batch4_vs_oracle_rows_and_alone(case):
         torch.cuda.synchronize()
         calls = {k: _cabi.CALLS[k] - before[k] for k in before}
     assert cap4["route"] == "tokens"
-    assert calls["linear_xadd"] == 6 and calls["msda_encoder"] == 6 and calls["ffn_fused"] == 6, calls
+    # per encoder layer: one projection launch (value + packed offsets | logits), the packed MSDA kernel, one launch from the
+    # attention output to the layer output (output_proj + identity, norm1, FFN, norm2, + query_pos)
+    assert calls["encoder_projections"] == 6 and calls["msda_encoder_packed"] == 6 and calls["ffn_oproj_fused"] == 6, calls
+    assert calls["linear_xadd"] == 0 and calls["ffn_fused"] == 6, calls
     # (decoder: the head-only launch + one per layer, the self-attention cores between them)
     assert calls["decoder_layer"] == 7 and calls["mha_attention"] == 6 and calls["window_attention"] == 24, calls
     assert calls["linear_xs"] > 0 and calls["linear_tile256"] > 0 and calls["linear_splitk"] > 0, calls
@@ -146,7 +149,7 @@ def test_headline_fp8_batch4_vs_oracle_rows(case, mode):
             calls = {k: _cabi.CALLS[k] - before[k] for k in before}
         n8 = calls["linear_fp8"]
         assert n8 == 4 * 22 and calls["ffn_fp8"] == 6 and calls["ffn_fused"] == 0, calls      # stages 1-3: 2 + 18 + 2 blocks
-        assert calls["msda_encoder"] == 6 and calls["linear_xadd"] == 6, calls
+        assert calls["msda_encoder_packed"] == 6 and calls["encoder_projections"] == 6 and calls["ffn_oproj_fused"] == 0, calls
         got = F.sample_capture(NAME, cap4, image=0, images=4)
         bounds = {"backbone0": 5e-3, "backbone1": 7e-2, "backbone2": 1.2e-1, "backbone3": 1.4e-1, "memory": 1.2e-1,
                   "enc_outputs_class": 1.2e-1, "neck0": 5e-3}   # measured: 7.9e-4, 4.5e-2, 8.1e-2, 8.9e-2, 9.1e-2, 8.5e-2, 9.2e-4

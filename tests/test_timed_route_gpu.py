@@ -106,17 +106,18 @@ def test_midsize_timed_route_vs_live_oracle():
     (b2, s2, l2), calls2 = run(None)
     assert torch.equal(torch.nan_to_num(b2), torch.nan_to_num(boxes)) and torch.equal(l2, labels)
     assert calls2["linear"] == calls["linear"] - 3  # capture adds the all-rows box branch (3 linears) for inspection
-    # second pass with (x + pos) folded into the (offsets | logits) GEMM's operand load (full size: >= 400 k rows)
-    old = hip_ops.XADD_MIN_ROWS
-    hip_ops.XADD_MIN_ROWS = 32768
+    assert calls["encoder_projections"] == 6 and calls["ffn_oproj_fused"] == 6, calls   # per encoder layer: ONE projection launch,
+    # the MSDA kernel, ONE launch from the attention output to the layer output
+    # second pass with those two fusions off: value projection / (x + pos) GEMM / output projection / FFN as separate launches
+    hip_ops.ENC_PROJ_FUSED, hip_ops.FFN_OPROJ = False, False
     try:
         cap2 = {}
         _, calls3 = run(cap2)
     finally:
-        hip_ops.XADD_MIN_ROWS = old
-    assert calls3["linear_xadd"] == 6, calls3
+        hip_ops.ENC_PROJ_FUSED, hip_ops.FFN_OPROJ = True, True
+    assert calls3["linear_xadd"] == 6 and calls3["encoder_projections"] == 0 and calls3["ffn_oproj_fused"] == 0, calls3
     errs2 = _stage_errors(cap2, cap_o, 1e-2)
-    errs.update({k + "(xadd)": v for k, v in errs2.items() if k in ("memory", "final_state", "outputs_coords")})
+    errs.update({k + "(separate launches)": v for k, v in errs2.items() if k in ("memory", "final_state", "outputs_coords")})
     # native proposal selection at this size against a stable sort of the same scores
     enc_max = hip_ops.row_max(cap["enc_outputs_class"])
     idx = hip_ops.topk(enc_max, 900, want_values=False)[1]
