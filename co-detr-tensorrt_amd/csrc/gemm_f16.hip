@@ -989,6 +989,11 @@ int launch_big(hipStream_t st, const void* X, const void* W, const void* bias, c
 // per wave, activation, fp16 image of the wave's 32 x 32 piece in its private LDS region, row-wise read-back,
 // residual (requested before the MFMAs) / row mask, 16-B stores.  X is read from HBM exactly once, Y written once,
 // W (<= 1.2 MB) comes from L2.
+// diagnostic builds only (tools/micro/build_variant.sh ... "-DCODETR_XS_ABL=mask", WRONG results by construction): 1 = no output
+// stores, 2 = no MFMAs, 4 = no W chunk staging inside the loop, 8 = no wait / barrier per chunk, 16 = no X / X2 loads
+#ifndef CODETR_XS_ABL
+#define CODETR_XS_ABL 0
+#endif
 #ifdef CODETR_XS_STAMPS   // diagnostic build only (tools/micro/xs_stamps.hip): where wave 0 of every workgroup spends its cycles
 __device__ unsigned long long* g_xs_stamps = nullptr;
 #define XS_STAMP(i) xs_t[i] = __builtin_readcyclecounter()
@@ -1066,11 +1071,17 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
     int m = m0 + mt * 16 + l15;
     m = m < M ? m : M - 1;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < KS; ++ks) {
+      if (CODETR_XS_ABL & 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[mt][ks][e] = (typename T::elem)(float)(m + ks);
+        continue;
+      }
       xf[mt][ks] = *reinterpret_cast<const typename T::frag*>(X + (size_t)m * K + ks * 32 + grp * 8);
+    }
     // optional second input, added element-wise on the way in (x + x2 rounded to T, the fp16 / bf16 add the host
     // would otherwise run as its own kernel: `query + query_pos` in front of the offsets | logits projection)
-    if (X2 && !SPLIT) {
+    if (X2 && !SPLIT && !(CODETR_XS_ABL & 16)) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const typename T::frag p = *reinterpret_cast<const typename T::frag*>(X2 + (size_t)m * K + ks * 32 + grp * 8);
@@ -1184,7 +1195,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
           const int head = n / hm_hd, ch = n - head * hm_hd;
           off = (((size_t)bb * (Ny / hm_hd) + head) * hm_rows + pos) * hm_hd + ch;
         }
-        *reinterpret_cast<s16x8*>(Y + off) = v;
+        if (!(CODETR_XS_ABL & 1) || v[0] == 0x1234) *reinterpret_cast<s16x8*>(Y + off) = v;
       }
     }
     __builtin_amdgcn_wave_barrier();  // the staging region is rewritten by the next pair
@@ -1203,9 +1214,9 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
 #endif
   for (int c = 0; c < nchunks; ++c) {
     XS_STAMP(0);
-    wait_vmcnt_n<kPieces>();
+    if (!(CODETR_XS_ABL & 8)) wait_vmcnt_n<kPieces>();
     XS_STAMP(1);
-    __builtin_amdgcn_s_barrier();
+    if (!(CODETR_XS_ABL & 8)) __builtin_amdgcn_s_barrier();
     XS_STAMP(2);
     const int n0 = c * CN;
     if (!(c & 1)) {
@@ -1217,7 +1228,7 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
     {
       const int c2 = c + 2 < nchunks ? c + 2 : nchunks - 1;  // (past the end: a fetch nobody reads, same counts)
       const int s2 = slot == 0 ? 2 : slot - 1;               // the slot W[c-1] used
-      stage_chunk(c2, lds + s2 * kChunkBytes);
+      if (!(CODETR_XS_ABL & 4)) stage_chunk(c2, lds + s2 * kChunkBytes);
     }
     XS_STAMP(4);
     if (SPLIT && c == c1) {
@@ -1264,7 +1275,10 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = T::mfma(a[nt], xf[mt][ks], acc[nt][mt]);
+        for (int mt = 0; mt < 2; ++mt) {
+          if (CODETR_XS_ABL & 2) acc[nt][mt][0] += (float)a[nt][0] * (float)xf[mt][ks][0];
+          else acc[nt][mt] = T::mfma(a[nt], xf[mt][ks], acc[nt][mt]);
+        }
     }
     // ---- chunk epilogue: this wave's 32 rows x 32 columns into its half of the staged pair ----
 #ifdef CODETR_XS_STAMPS
