@@ -48,6 +48,35 @@ def test_host_only_entry_points():
     assert _cabi.msda_variant(torch.float16, 2, 2, 2, 2) == "scalar"  # reference tiny case D=2
 
 
+def test_round5_host_only_tables_and_contract_errors():
+    """codetr_ffn_oproj_w1_index: the column order of W1 for the FFN launch that starts with the attention output projection
+    -- the epilogue's lane layout (a lane of group g owns channels 32 s + 16 (g & 1) + 8 (g >> 1) .. + 7) written as MFMA
+    k-slots (32 s + 8 g ..): groups 1 and 2 exchanged inside every 32-channel block; argument errors of the two fused
+    encoder entry points are host-side."""
+    from codetr import _cabi
+
+    idx = _cabi.ffn_oproj_w1_index(256)
+    assert sorted(idx) == list(range(256))
+    for s in range(8):
+        blk = idx[32 * s:32 * s + 32]
+        assert blk[0:8] == list(range(32 * s, 32 * s + 8)) and blk[8:16] == list(range(32 * s + 16, 32 * s + 24))
+        assert blk[16:24] == list(range(32 * s + 8, 32 * s + 16)) and blk[24:32] == list(range(32 * s + 24, 32 * s + 32))
+    lib = _cabi.load()
+    null, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    bad = ctypes.c_void_p(24)   # not 16-byte aligned
+    assert lib.codetr_ffn_oproj_w1_index(192, ctypes.cast((ctypes.c_int32 * 192)(), ctypes.c_void_p)) == -1
+    # encoder projections: null operand, misaligned operand -> BADARG; K != 256 / too few rows / value width not 64 n -> UNSUPPORTED
+    f = lib.codetr_encoder_projections_f16
+    assert f(null, null, one, one, one, null, one, one, 40000, 256, 512, 256, 0, 0) == -1
+    assert f(null, one, bad, one, one, null, one, one, 40000, 256, 512, 256, 0, 0) == -1
+    assert f(null, one, one, one, one, null, one, one, 40000, 256, 512, 192, 0, 0) == _cabi.E_UNSUPPORTED
+    assert f(null, one, one, one, one, null, one, one, 1000, 256, 512, 256, 0, 0) == _cabi.E_UNSUPPORTED
+    assert f(null, one, one, one, one, null, one, one, 40000, 224, 512, 256, 0, 0) == _cabi.E_UNSUPPORTED
+    g = lib.codetr_ffn_oproj_relu_ln2_f16
+    assert g(null, one, null, one, one, one, one, one, one, one, 1000, 256, 2048, null, null, 0.0, null, null, 0.0, null, null) == -1
+    assert g(null, one, one, one, one, one, one, one, one, one, 1000, 192, 2048, null, null, 0.0, null, null, 0.0, null, null) == _cabi.E_UNSUPPORTED
+
+
 def test_argument_validation_without_gpu():
     """Contract errors are detected on the host before any launch, so they are testable here."""
     from codetr import _cabi
