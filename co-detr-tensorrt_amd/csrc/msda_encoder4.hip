@@ -54,7 +54,7 @@ constexpr int kBand = MSDA4_BAND;   // region rows per band of the tile walk (se
 #ifndef MSDA4_ABL
 #define MSDA4_ABL 0           // timing experiments only (tools/micro/build_variant.sh): parts compiled out, WRONG results
 #endif
-constexpr int kAbl = MSDA4_ABL;   // 1: no wait for the staging DMA, 2: no staging, 4: no gather, 8: no preparation, 16: no barriers
+constexpr int kAbl = MSDA4_ABL;   // 1: no wait for the staging DMA, 2: no staging, 4: no gather, 8: no preparation, 16: no barriers, 32: no output stores
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   for (int it = 0; it < kMaxIt; ++it)
     if (it < n_it && (it * kWaves + wave) * 16 + pl < total) {
       const u32x4 o = ET::pack8(acc[it]);
-      *reinterpret_cast<u32x4*>(orow + (size_t)((unsigned)qs[it] * ((unsigned)M * kRow))) = o;   // out is [B, S, M, 32] in either case
+      if (!(kAbl & 32) || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(orow + (size_t)((unsigned)qs[it] * ((unsigned)M * kRow))) = o;   // out is [B, S, M, 32] in either case
     }
 }
 
