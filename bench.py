@@ -252,7 +252,8 @@ def kernel_rooflines(model, images, masks, device):
     launch stream (hip_ops.LINEAR_PROFILE / KERNEL_PROFILE):
       roofline       linear_kernel, the dominant kernel (~40 % of the GPU time of a forward): sum of 2*M*N*K over its
                      launches / sum of their durations, against the dense fp16 MFMA peak
-      roofline_ffn   ffn_fused_kernel (encoder FFN, 4*M*256*2048 flops per launch), same peak
+      roofline_ffn   ffn_fused_kernel (encoder FFN, 4*M*256*2048 flops per launch -- + 2*M*256*256 where the launch also does
+                     the attention output projection, round 5), same peak
       roofline_msda  the fused MSDA gather kernel at the encoder shape (Nq = S), algorithmic bytes of BASELINE.md
                      section 3 (value + offsets + logits + output, each once) against the 8 TB/s HBM peak."""
     from codetr import hip_ops
