@@ -376,7 +376,7 @@ def kernel_rooflines(model, images, masks, device):
                 "windows; packed-half blend, three passes, fp32 reference points)" if _cabi_mod.CALLS.get("msda_encoder_packed", 0) > 0 else
                 ("msda_encoder_v3_kernel<F16> (packed-half blend, three passes, fp32 reference points)"
                  if __import__("codetr.hip_ops", fromlist=["x"]).msda_encoder_passes(torch.float16, m["L"], m["P"]) == 3
-                 else "msda_encoder_v2_kernel<F16> (packed-half blend, one pass)") if enc_native
+                 else "msda_encoder_kernel<F16> (generic L x P, one pass)") if enc_native
                 else "msda_tiled_kernel<F16,4,fused>", len(enc), m["S"]),
             "bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
@@ -745,27 +745,40 @@ def main():
             # encoder-memory error <= 2e-2 against the fp16 product): 8 of the 88 GEMMs -- timed so that the line says what
             # that selection is worth, and that the full selection above is a FAST mode
             fp8_line["recommended"] = False
-            # (accuracy figures are READ from the committed sensitivity run, with its path and date: they are not
-            # measurements of this run -- ADVICE r04)
-            sens_path = os.path.join(ROOT, "profiles", "r04_fp8_sensitivity.json")
-            try:
-                sens = json.load(open(sens_path))
-                fp8_line["accuracy"] = {"encoder_memory_rel_l2_vs_fp16": sens["all_e4m3"]["memory_rel_l2"],
-                                        "proxy_AP": sens["all_e4m3"]["AP"], "proxy_AP_fp16": sens["fp16"]["AP"],
-                                        "source": "profiles/r04_fp8_sensitivity.json (all_e4m3), file of %s -- an earlier "
-                                                  "run of tools/fp8_sensitivity.py, not measured here"
-                                                  % time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(sens_path)))}
-            except (OSError, KeyError, ValueError):
-                fp8_line["accuracy"] = {"source": "profiles/r04_fp8_sensitivity.json not readable"}
+
+            def _memory(nimg=nb0):
+                # one eager forward on the TIMED images: the deformable encoder's output (captured intermediates)
+                cap = {}
+                with torch.no_grad():
+                    model(images[:nimg].contiguous(), masks[:nimg].contiguous(), capture=cap)
+                torch.cuda.synchronize(device)
+                return cap["memory"].float()
+
+            def _rel(m8, m16):
+                per = [float(torch.linalg.vector_norm(x - y) / torch.linalg.vector_norm(y).clamp_min(1e-30))
+                       for x, y in zip(m8, m16)]
+                return round(max(per), 5)
+
+            # accuracy of THIS run's kernels (the line carried figures of a round-4 file): encoder memory of the
+            # e4m3 selection against the fp16 product's on the same images, worst image; the proxy AP needs the oracle's
+            # detections and stays with tools/fp8_sensitivity.py
+            mem8 = _memory()
+            fp8.enable(model, False)
+            mem16 = _memory()
+            fp8_line["accuracy"] = {"encoder_memory_rel_l2_vs_fp16": _rel(mem8, mem16),
+                                    "source": "measured in this run: eager forwards of the timed images (first %d), "
+                                              "worst image" % nb0}
+            del mem8
             fp8.enable(model, True, "mx", select="accurate")
             graphs = capture()
             ea, pera = timed(False)
             fp8_line["accurate_preset"] = {"images_per_s": round(a.steps * a.batch / ea, 3),
                                            "p50_ms_per_image": round(pera[len(pera) // 2] / a.batch, 3),
                                            "config": fp8.report(model),
-                                           "note": "stage-3 qkv / fc1 / fc2 + stage-1 fc2 in e4m3, encoder FFN in fp16; encoder-"
-                                                   "memory error 1.7e-2 vs the fp16 product when tools/fp8_sensitivity.py "
-                                                   "was last run (profiles/r04_fp8_sensitivity.json), not measured here"}
+                                           "encoder_memory_rel_l2_vs_fp16": _rel(_memory(), mem16),
+                                           "note": "stage-3 qkv / fc1 / fc2 + stage-1 fc2 in e4m3, encoder FFN in fp16; the "
+                                                   "memory error is measured in this run like `accuracy` above"}
+            del mem16
         except Exception as e:  # noqa: BLE001 -- the optional sub-record must never cost the measured fp16 line
             torch.cuda.synchronize(device)
             fp8_line = {"error": repr(e)}

@@ -119,21 +119,39 @@ class MultiScaleDeformableAttention(nn.Module):
 
         return hip_ops.derived(ws, "_codetr_enc_projections", build)
 
-    def _encoder_windows_packed(self, host_shapes):
-        key = ("_codetr_enc_windows_v4_" + "_".join(f"{int(h)}x{int(w)}" for h, w in host_shapes)
-               + f"_{hip_ops.MSDA_V4_THREADS}_{hip_ops.MSDA_V4_REGION}_{hip_ops.MSDA_V4_LDS_BUDGET}_{hip_ops.MSDA_V4_MARGIN_CAP}")
+    _WINDOW_CACHE_SHAPES = 8       # pyramids whose windows are kept per layer (variable input sizes: the cache must not grow)
+
+    def _windows_lru(self, key, build):
+        """Windows per (pyramid shape, settings) derived from the offset bias: ONE derived attribute on the bias tensor
+        holding an ordered dict of at most _WINDOW_CACHE_SHAPES entries, least recently used dropped (one
+        attribute per shape string grew by M * L * 4 ints with every new input size).  hip_ops.derived rebuilds the
+        dict -- empty -- whenever the bias tensor changes."""
+        from collections import OrderedDict
+
         b = self.sampling_offsets.bias
-        return hip_ops.derived((b,), key, lambda: hip_ops.msda_encoder_windows_packed(
-            b, [(int(h), int(w)) for h, w in host_shapes], self.num_heads, self.num_levels, self.num_points))
+        table = hip_ops.derived((b,), "_codetr_enc_windows_lru", OrderedDict)
+        hit = table.get(key)
+        if hit is None:
+            hit = table[key] = build(b)
+            while len(table) > self._WINDOW_CACHE_SHAPES:
+                table.popitem(last=False)
+        else:
+            table.move_to_end(key)
+        return hit
+
+    def _encoder_windows_packed(self, host_shapes):
+        shapes = tuple((int(h), int(w)) for h, w in host_shapes)
+        key = ("v4", shapes, hip_ops.MSDA_V4_THREADS, tuple(hip_ops.MSDA_V4_REGION), hip_ops.MSDA_V4_LDS_BUDGET,
+               hip_ops.MSDA_V4_MARGIN_CAP)
+        return self._windows_lru(key, lambda b: hip_ops.msda_encoder_windows_packed(
+            b, list(shapes), self.num_heads, self.num_levels, self.num_points))
 
     def _encoder_windows(self, host_shapes, dtype, passes):
         """staged window per (head, level) of the LDS-staged encoder kernel, from the offset bias; rebuilt only when
         the bias tensor or the pyramid changes (one device-to-host copy of 320 values, outside the steady state)"""
-        key = f"_codetr_enc_windows_{passes}_" + "_".join(f"{int(h)}x{int(w)}" for h, w in host_shapes) + str(dtype)
-        b = self.sampling_offsets.bias
-        return hip_ops.derived((b,), key, lambda: hip_ops.msda_encoder_windows(
-            b, [(int(h), int(w)) for h, w in host_shapes], self.num_heads, self.num_levels, self.num_points,
-            passes, dtype == torch.float16))
+        shapes = tuple((int(h), int(w)) for h, w in host_shapes)
+        return self._windows_lru(("v3", shapes, passes, str(dtype)), lambda b: hip_ops.msda_encoder_windows(
+            b, list(shapes), self.num_heads, self.num_levels, self.num_points, passes, dtype == torch.float16))
 
     # ------------------------------------------------------------------ batch-first core
     def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,

@@ -69,13 +69,7 @@ def assert_close_lowp(actual, ref, rel_l2=1e-2, max_abs=None, what=""):
     return err
 
 
-def row_error_stats(actual, ref, rel_l2):
-    """Per-row companions of the whole-tensor relative L2 error, for [rows, C] samples of a stage (a tile-edge bug that
-    corrupts a handful of rows moves the whole-tensor number by nothing):
-      row_ratio  = max over rows of ||a_row - r_row|| / (rel_l2 * max(||r_row||, rms row norm of the tensor)),
-      elem_frac  = max over rows of the fraction of the row's elements with |a - r| > 4 rel_l2 (|r| + rms element)
-                   (rows narrower than 32 elements: that fraction over the whole tensor).
-    Non-finite elements must agree in position (checked by assert_close_lowp) and are left out."""
+def _row_error_terms(actual, ref, rel_l2):
     a = np.asarray(actual, dtype=np.float64).reshape(-1, np.asarray(actual).shape[-1])
     r = np.asarray(ref, dtype=np.float64).reshape(a.shape)
     fin = np.isfinite(r) & np.isfinite(a)
@@ -86,24 +80,55 @@ def row_error_stats(actual, ref, rel_l2):
     rms_el = np.sqrt((rz * rz).sum() / max(fin.sum(), 1))
     ratio = np.sqrt((d * d).sum(-1)) / (rel_l2 * np.maximum(row_norm, max(rms_row, 1e-30)))
     out = np.abs(d) > 4.0 * rel_l2 * (np.abs(rz) + rms_el)
-    if a.shape[-1] >= 32:
+    return ratio, out, fin
+
+
+def row_error_stats(actual, ref, rel_l2):
+    """Per-row companions of the whole-tensor relative L2 error, for [rows, C] samples of a stage (a tile-edge bug that
+    corrupts a handful of rows moves the whole-tensor number by nothing):
+      row_ratio  = max over rows of ||a_row - r_row|| / (rel_l2 * max(||r_row||, rms row norm of the tensor)),
+      elem_frac  = max over rows of the fraction of the row's elements with |a - r| > 4 rel_l2 (|r| + rms element)
+                   (rows narrower than 32 elements: that fraction over the whole tensor; assert_rows_close does NOT
+                   compare it with a share there, see narrow_row_outliers).
+    Non-finite elements must agree in position (checked by assert_close_lowp) and are left out."""
+    ratio, out, fin = _row_error_terms(actual, ref, rel_l2)
+    if out.shape[-1] >= 32:
         frac = out.sum(-1) / np.maximum(fin.sum(-1), 1)
     else:
-        # rows of a few elements (box coordinates [rows, 4]): one element is already 25 % of its row, so the per-row share
-        # says nothing -- the share over the whole tensor is reported instead (round 5: a single coordinate of 3 600 beyond
-        # the bound failed the batch-of-4-vs-alone comparison of the headline test after a kernel change upstream)
         frac = np.asarray(out.sum() / max(fin.sum(), 1))
     return float(ratio.max()), float(frac.max()), int(ratio.argmax())
+
+
+def narrow_row_outliers(actual, ref, rel_l2):
+    """Rows of a few elements (box coordinates [rows, 4]): one element is already 25 % of its row, so a per-row SHARE says
+    nothing and a share over the whole tensor would let dozens of coordinates through.  Counted instead:
+    (outlier elements in the whole tensor, the largest number of outliers any one row holds)."""
+    _, out, _ = _row_error_terms(actual, ref, rel_l2)
+    return int(out.sum()), int(out.sum(-1).max()) if out.size else 0
+
+
+NARROW_MAX_OUTLIERS = 3      # elements of the whole tensor (3 600 box coordinates in the headline test), never a share
 
 
 def assert_rows_close(actual, ref, rel_l2, what="", row_factor=5.0, elem_frac=0.01):
     """assert_close_lowp plus the per-row bound: no row's error above row_factor x the tensor's bound (relative to
     the larger of its own norm and the tensor's rms row norm), no row with more than elem_frac of its elements beyond
-    4 rel_l2 (|ref| + rms).  Returns (tensor rel-L2, worst row ratio / row_factor, worst element fraction)."""
+    4 rel_l2 (|ref| + rms).  Rows narrower than 32 elements (boxes): at most NARROW_MAX_OUTLIERS such elements in the
+    WHOLE tensor and never two in one row -- an absolute count (round 5 compared a 1 % / 5 % share here, which let
+    36 - 180 box coordinates through).  The lone coordinates this admits are order-of-summation
+    differences between a batch-of-4 and a single-image launch landing on a box whose fp16 offset rounds the other
+    way; a row with two wrong coordinates is a wrong box and fails.
+    Returns (tensor rel-L2, worst row ratio / row_factor, worst element fraction)."""
     err = assert_close_lowp(actual, ref, rel_l2, None, what)
     ratio, frac, worst = row_error_stats(actual, ref, rel_l2)
     assert ratio <= row_factor, f"{what}: row {worst} is {ratio:.2f} x the tensor bound {rel_l2:.1e} (limit {row_factor})"
-    assert frac <= elem_frac, f"{what}: a row has {100 * frac:.1f} % of its elements beyond 4 x {rel_l2:.1e} (|ref| + rms)"
+    if np.asarray(actual).shape[-1] >= 32:
+        assert frac <= elem_frac, f"{what}: a row has {100 * frac:.1f} % of its elements beyond 4 x {rel_l2:.1e} (|ref| + rms)"
+    else:
+        total, per_row = narrow_row_outliers(actual, ref, rel_l2)
+        assert total <= NARROW_MAX_OUTLIERS and per_row <= 1, (
+            f"{what}: {total} elements beyond 4 x {rel_l2:.1e} (|ref| + rms), up to {per_row} in one row "
+            f"(limits {NARROW_MAX_OUTLIERS} / 1)")
     return err, ratio / row_factor, frac
 
 

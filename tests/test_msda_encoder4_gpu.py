@@ -32,7 +32,16 @@ M, L, P, D = 8, 5, 4, 32
 PYR_DIV = [(40, 64), (20, 32), (10, 16), (5, 8), (3, 4)]
 PYR_ODD = [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3)]
 PYR_FULL = [(320, 480), (160, 240), (80, 120), (40, 60), (20, 30)]
-CFGS = {"t256": (256, (16, 8), 40 * 1024), "t512": (512, (32, 8), 80 * 1024)}
+# "shipped" is what hip_ops launches by default (MSDA_V4_THREADS / _REGION / _LDS_BUDGET: 512 threads, 16 x 16 regions,
+# 64 KiB): the region shape changes the slots per wave, the iteration count, the band walk and the window sizes, so it is
+# pinned to the oracle at the op's own tolerance like the two other shapes
+CFGS = {"t256": (256, (16, 8), 40 * 1024), "t512": (512, (32, 8), 80 * 1024), "shipped": (512, (16, 16), 64 * 1024)}
+
+
+def test_shipped_cfg_is_what_hip_ops_launches():
+    from codetr import hip_ops
+
+    assert CFGS["shipped"] == (hip_ops.MSDA_V4_THREADS, tuple(hip_ops.MSDA_V4_REGION), hip_ops.MSDA_V4_LDS_BUDGET)
 
 
 def _inputs(shapes, B, off_scale, seed, counts=None):

@@ -17,6 +17,25 @@ sys.path.insert(0, os.path.join(ROOT, "co-detr-tensorrt_amd"))
 sys.path.insert(0, ROOT)
 
 
+def _parse(name, old, text):
+    """NAME=VALUE by the type of the switch's default: bool / int through int(), float through float(), a tuple as
+    AxB[xC...] of ints, a string as it stands; any other type is refused instead of being set to something else."""
+    if isinstance(old, bool):
+        return bool(int(text))
+    if isinstance(old, int):
+        return int(text)
+    if isinstance(old, float):
+        return float(text)
+    if isinstance(old, tuple):
+        val = tuple(int(t) for t in text.lower().split("x"))
+        if len(val) != len(old):
+            raise SystemExit(f"{name}: expected {len(old)} values joined by 'x', got {text!r}")
+        return val
+    if isinstance(old, str):
+        return text
+    raise SystemExit(f"{name}: cannot parse a {type(old).__name__} switch from the command line")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE")
@@ -37,8 +56,7 @@ def main():
         mod = homes.get(k, hip_ops)
         if not hasattr(mod, k):
             raise SystemExit(f"unknown switch {k}")
-        old = getattr(mod, k)
-        setattr(mod, k, type(old)(int(v)) if not isinstance(old, str) else v)
+        setattr(mod, k, _parse(k, getattr(mod, k), v))
     print("non-default switches:", hip_ops.nondefault_switches(), file=sys.stderr)
     script = [s for s in a.script if s != "--"]
     if not script:
