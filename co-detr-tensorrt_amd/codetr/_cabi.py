@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 44
+ABI_VERSION = 45
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -113,6 +113,10 @@ SIGNATURES = {
     "codetr_linear_sk_supported": (_i32, [_i64, _i64, _i64]),
     "codetr_linear_sk_preferred": (_i32, [_i64, _i64, _i64, _i32, _i32]),
     "codetr_linear_sk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
+    "codetr_linear_pp_supported": (_i32, [_i64, _i64, _i64]),
+    "codetr_linear_pp_preferred": (_i32, [_i64, _i64, _i64, _i32, _i32]),
+    "codetr_linear_pp_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32]),
+    "codetr_linear_pp_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32]),
     "codetr_linear_sk_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
     "codetr_decoder_layer_supported": (_i32, [_i32] * 7),
     "codetr_decoder_layer_blob_halfs": (_i64, [_i32] * 4),
@@ -159,7 +163,7 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "msda_encoder_packed": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
-         "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0, "encoder_projections": 0,
+         "linear_pp": 0, "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0, "encoder_projections": 0,
          "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0, "ffn_fp8": 0, "decoder_layer": 0}
 
 
@@ -170,6 +174,7 @@ RECORDER = None
 _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
             "codetr_linear_sk_workspace_bytes", "codetr_linear_sk_supported", "codetr_linear_sk_preferred",
+            "codetr_linear_pp_supported", "codetr_linear_pp_preferred",
             "codetr_msda_encoder_lds_bytes", "codetr_msda_encoder_packed_lds_bytes", "codetr_msda_pack_projection_index",
             "codetr_mx_scale_bytes", "codetr_decoder_layer_supported",
             "codetr_decoder_layer_blob_halfs"}
@@ -357,6 +362,33 @@ def linear_sk(x2d, weight, bias, residual2d, act, out2d, flags=0):
             residual2d.data_ptr() if residual2d is not None else None, out2d.data_ptr(), M, N, K, _ACT[act],
             ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, flags)
     check(rc, "codetr_linear_sk")
+    return out2d
+
+
+_PP_PREFERRED = {}
+
+
+def linear_pp_preferred(M, N, K, act=None, has_residual=False) -> bool:
+    """True where the ping-pong GEMM (csrc/gemm_pp.hip) measured faster than the other two (the library's own rule)"""
+    key = (M, N, K, act, bool(has_residual))
+    v = _PP_PREFERRED.get(key)
+    if v is None:
+        v = _PP_PREFERRED[key] = bool(load().codetr_linear_pp_preferred(M, N, K, _ACT[act], 1 if has_residual else 0))
+    return v
+
+
+def linear_pp(x2d, weight, bias, residual2d, act, out2d, flags=0):
+    """y = act(x @ w.T + b) (+ r) by the ping-pong persistent GEMM; flags as in include/codetr_hip.h"""
+    lib = load()
+    CALLS["linear"] += 1
+    CALLS["linear_pp"] += 1
+    M, K = x2d.shape
+    N = weight.shape[0]
+    fn = lib.codetr_linear_pp_f16 if x2d.dtype == torch.float16 else lib.codetr_linear_pp_bf16
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), weight.data_ptr(),
+            bias.data_ptr() if bias is not None else None,
+            residual2d.data_ptr() if residual2d is not None else None, out2d.data_ptr(), M, N, K, _ACT[act], flags)
+    check(rc, "codetr_linear_pp")
     return out2d
 
 

@@ -62,6 +62,16 @@ def _gpu(x, what):
         )
 
 
+LINEAR_PP = True     # route switch (A/B): False keeps the long-K layers on the round-4 kernels
+
+
+def _persistent_ok(mk, head_major, out, x2, w, r2, bias):
+    """what both persistent GEMMs ask of their operands: no row mask / head-major output, 16-byte aligned bases"""
+    return (mk is None and not head_major and out.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0 and (r2 is None or r2.data_ptr() % 16 == 0)
+            and (bias is None or bias.data_ptr() % 16 == 0))
+
+
 def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_major=None):
     """y = act(x @ weight.T + bias) (+ residual);  act in {None, 'relu', 'gelu'}.
     row_mask (bool, x.shape[:-1]): rows where it is True come out as zeros (before the residual).
@@ -100,8 +110,11 @@ def linear(x, weight, bias=None, act=None, residual=None, row_mask=None, head_ma
                     # few output tiles, long K (the neck's extra level as a GEMM): two-pass split-K, fp32 partials
                     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
                     launch = lambda: _cabi.linear_splitk(x2, w, bias, r2, act, out, splits, ws, mk)  # noqa: E731
-                elif (mk is None and not head_major and out.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
-                      and w.data_ptr() % 16 == 0 and (r2 is None or r2.data_ptr() % 16 == 0) and (bias is None or bias.data_ptr() % 16 == 0)
+                elif (LINEAR_PP and _persistent_ok(mk, head_major, out, x2, w, r2, bias)
+                      and _cabi.linear_pp_preferred(x2.shape[0], N, K, act, r2 is not None)):
+                    # the long-K layers with a tile per CU (Swin stages 2-3, stage 1's fc2): ping-pong persistent GEMM
+                    launch = lambda: _cabi.linear_pp(x2, w, bias, r2, act, out)  # noqa: E731
+                elif (_persistent_ok(mk, head_major, out, x2, w, r2, bias)
                       and _cabi.linear_sk_preferred(x2.shape[0], N, K, act, r2 is not None)):
                     # the large short-K layers (Swin stages 0-2, the encoder's output projections): persistent GEMM
                     launch = lambda: _cabi.linear_sk(x2, w, bias, r2, act, out)  # noqa: E731
@@ -672,7 +685,7 @@ MSDA_FP32_REF = True    # False = reference points read in the model dtype
 MSDA_LDS_BUDGET = {1: 80 * 1024, 3: 40 * 1024}   # bytes per workgroup: two / four workgroups per CU share 160 KiB
 
 
-_SWITCH_DEFAULTS = {"LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
+_SWITCH_DEFAULTS = {"LINEAR_PP": True, "LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
                     "MSDA_HALO": 4, "MSDA_WINDOWS": True, "MSDA_PASSES": 3, "MSDA_FP32_REF": True, "FP8_MIN_TILES": 96}
 
 

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 44
+#define CODETR_HIP_ABI_VERSION 45
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -507,6 +507,23 @@ int codetr_linear_sk_f16(void *stream, const void *x_dev, const void *w_dev, con
 int codetr_linear_sk_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                           const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act,
                           void *workspace_dev, int64_t workspace_bytes, int flags);
+
+/* Ping-pong form of codetr_linear_sk_* (round 6, csrc/gemm_pp.hip) for the same layers (reference codetr/swin.py:92-112,
+ * 331-352): the same persistent 256 x 256 tiles, operand ring and epilogue, but the two waves of every SIMD take turns --
+ * one multiplies (32 MFMAs, nothing else) while the other reads its fragments from LDS and issues its LDS-DMA pieces, a
+ * workgroup barrier between the segments, the second group of four waves one barrier behind the first.  Same semantics
+ * and domain as codetr_linear_sk_* (no workspace, no stream-K split).
+ *   codetr_linear_pp_supported   1 when (M, N, K) is inside the kernel's domain (K % 64 == 0, K >= 128, N % 8 == 0)
+ *   codetr_linear_pp_preferred   1 where it measured faster than codetr_linear_* and codetr_linear_sk_*
+ *                                (profiles/r06_gemm_pp.txt): hosts call codetr_linear_pp_* then
+ *   codetr_linear_pp_*           flags: 0 (reserved: the measured variants of the main loop are kept out of the library,
+ *                                tools/micro/experiments/gemm_pp_variants.hip) */
+int codetr_linear_pp_supported(int64_t M, int64_t N, int64_t K);
+int codetr_linear_pp_preferred(int64_t M, int64_t N, int64_t K, int act, int has_residual);
+int codetr_linear_pp_f16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                         const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act, int flags);
+int codetr_linear_pp_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
+                          const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act, int flags);
 
 /* ------------------------------------------------------------------------------------------
  * Padding-mask pyramid: everything the detection transformer derives from img_masks, one launch.

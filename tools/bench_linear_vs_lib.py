@@ -55,7 +55,7 @@ def main():
         r = torch.randn(M, N, device="cuda", generator=g).half() if res else None
         before = dict(_cabi.CALLS)
         tn = timeit(lambda: hip_ops.linear(x, w, b, act=act, residual=r))
-        kern = [k for k in ("linear_sk", "linear_tile256", "linear_tile128", "linear_xs") if _cabi.CALLS[k] > before[k]]
+        kern = [k for k in ("linear_pp", "linear_sk", "linear_tile256", "linear_tile128", "linear_xs") if _cabi.CALLS[k] > before[k]]
         tl = timeit(lambda: F.linear(x, w, b))
 
         def lib_epi():

@@ -21,6 +21,8 @@ typedef int (*linear_fn)(void*, const void*, const void*, const void*, const voi
                          int64_t, int, int64_t, int);
 typedef int (*linear_sk_fn)(void*, const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int,
                             void*, int64_t, int);
+typedef int (*linear_pp_fn)(void*, const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int,
+                            int);
 typedef int64_t (*ws_fn)(void);
 
 static uint16_t f2h(float f) {
@@ -58,7 +60,7 @@ struct Shape {
 
 int main(int argc, char** argv) {
   int images = 4, reps = 20;
-  bool quick = false, nocheck = false;
+  bool quick = false, nocheck = false, streamk = false;
   const char* only = nullptr;
   std::vector<std::pair<std::string, std::string>> extra;   // name=path of further builds of gemm_sk.hip (diagnostic)
   const char* lib = "co-detr-tensorrt_amd/codetr/libcodetr_hip.so";
@@ -68,6 +70,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--quick")) quick = true;
     else if (!strcmp(argv[i], "--lib")) lib = argv[++i];
     else if (!strcmp(argv[i], "--nocheck")) nocheck = true;
+    else if (!strcmp(argv[i], "--streamk")) streamk = true;
     else if (!strcmp(argv[i], "--only")) only = argv[++i];
     else if (!strcmp(argv[i], "--sklib")) {
       std::string a = argv[++i];
@@ -83,6 +86,7 @@ int main(int argc, char** argv) {
   linear_fn lin = (linear_fn)dlsym(h, "codetr_linear_f16");
   linear_sk_fn sk = (linear_sk_fn)dlsym(h, "codetr_linear_sk_f16");
   ws_fn wsb = (ws_fn)dlsym(h, "codetr_linear_sk_workspace_bytes");
+  linear_pp_fn pp = (linear_pp_fn)dlsym(h, "codetr_linear_pp_f16");   // round 6: the ping-pong kernel (csrc/gemm_pp.hip)
   if (!lin || !sk || !wsb) {
     printf("missing symbol\n");
     return 2;
@@ -135,13 +139,30 @@ int main(int argc, char** argv) {
     int flags;   // -1: the old kernel
     linear_sk_fn fn;
     bool check;
+    linear_pp_fn ppfn = nullptr;
   };
-  std::vector<Variant> variants = {{"old256", -1, nullptr, false}, {"sk.default", 0, sk, true}, {"sk.streamk", 0x40, sk, true}};
-  for (auto& e : extra) {
-    void* h2 = dlopen(e.second.c_str(), RTLD_NOW | RTLD_LOCAL);
+  std::vector<Variant> variants = {{"old256", -1, nullptr, false}, {"sk.default", 0, sk, true}};
+  if (streamk) variants.push_back({"sk.streamk", 0x40, sk, true});
+  if (pp) {
+    variants.push_back({"pp", 0, nullptr, true, pp});
+  }
+  for (auto& e : extra) {   // name=path[:flags]: a further build of gemm_sk.hip, or of an experiment file with the pp entry point
+    std::string path = e.second;
+    int xflags = 0;
+    const size_t colon = path.rfind(':');
+    if (colon != std::string::npos) {
+      xflags = atoi(path.c_str() + colon + 1);
+      path = path.substr(0, colon);
+    }
+    void* h2 = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h2) {
-      printf("dlopen %s failed: %s\n", e.second.c_str(), dlerror());
+      printf("dlopen %s failed: %s\n", path.c_str(), dlerror());
       return 2;
+    }
+    linear_pp_fn p2 = (linear_pp_fn)dlsym(h2, "codetr_linear_pp_f16");
+    if (p2) {
+      variants.push_back({e.first, xflags, nullptr, true, p2});
+      continue;
     }
     linear_sk_fn f2 = (linear_sk_fn)dlsym(h2, "codetr_linear_sk_f16");
     variants.push_back({e.first, 0, f2, false});
@@ -170,6 +191,7 @@ int main(int argc, char** argv) {
 
     auto run = [&](const Variant& v, void* y) {
       if (v.flags < 0) return lin(st, dx, dw, db, dr, nullptr, y, M, N, K, sh.act, 0, 0);
+      if (v.ppfn) return v.ppfn(st, dx, dw, db, dr, y, M, N, K, sh.act, v.flags);
       return v.fn(st, dx, dw, db, dr, y, M, N, K, sh.act, ws, ws_bytes, v.flags);
     };
     // ---- correctness ----
