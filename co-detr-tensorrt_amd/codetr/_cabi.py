@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 45
+ABI_VERSION = 46
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -113,6 +113,8 @@ SIGNATURES = {
     "codetr_linear_sk_supported": (_i32, [_i64, _i64, _i64]),
     "codetr_linear_sk_preferred": (_i32, [_i64, _i64, _i64, _i32, _i32]),
     "codetr_linear_sk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
+    "codetr_msda_op4_supported": (_i32, [_i32, _i64, _i64, _i32, _i32, _i32, _i64, _i32]),
+    "codetr_msda_op4_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i32, _vp]),
     "codetr_linear_pp_supported": (_i32, [_i64, _i64, _i64]),
     "codetr_linear_pp_preferred": (_i32, [_i64, _i64, _i64, _i32, _i32]),
     "codetr_linear_pp_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32]),
@@ -174,7 +176,7 @@ RECORDER = None
 _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
             "codetr_linear_sk_workspace_bytes", "codetr_linear_sk_supported", "codetr_linear_sk_preferred",
-            "codetr_linear_pp_supported", "codetr_linear_pp_preferred",
+            "codetr_linear_pp_supported", "codetr_linear_pp_preferred", "codetr_msda_op4_supported",
             "codetr_msda_encoder_lds_bytes", "codetr_msda_encoder_packed_lds_bytes", "codetr_msda_pack_projection_index",
             "codetr_mx_scale_bytes", "codetr_decoder_layer_supported",
             "codetr_decoder_layer_blob_halfs"}

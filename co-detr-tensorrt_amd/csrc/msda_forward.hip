@@ -35,6 +35,7 @@
 #include <stdint.h>
 
 #include "codetr_hip.h"
+#include "msda_op4_plan.h"
 
 namespace {
 
@@ -270,8 +271,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
     const int64_t* __restrict__ level_start, const typename TR::storage* __restrict__ loc,
     const typename TR::storage* __restrict__ weight, typename TR::storage* __restrict__ out,
     unsigned n_pairs /* B*Nq*M */, unsigned pairs_per_image /* Nq*M */, unsigned image_bytes /* S*M*D*sizeof */,
-    int M, int L, int P, FusedArgs fa) {
+    int M, int L, int P, FusedArgs fa, int skip_S, int skip_BM) {
   using S = typename TR::storage;
+  // skip_S != 0: the windowed kernel (csrc/msda_op4.hip) was launched in front of this one for the same call; where its
+  // device-side plan applies it has done the work (the pyramid's shapes are a device tensor: the host cannot tell)
+  if (skip_S != 0) {
+    codetr_op4::Plan plan;
+    if (codetr_op4::make_plan(spatial_shapes, level_start, skip_S, skip_BM, plan)) return;
+  }
   constexpr int VEC = TR::VEC;
   constexpr int D = VEC * LANES;
   constexpr int PAIRS = kThreads / LANES;  // pairs per workgroup
@@ -574,7 +581,8 @@ int tiled_lanes(int elem_bytes, int D, int L, int P) {
 
 template <class TR, int LANES, bool FUSED>
 int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int64_t* ls, const void* loc,
-                 const void* w, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq, int P, FusedArgs fa) {
+                 const void* w, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq, int P, FusedArgs fa,
+                 bool behind_op4 = false) {
   using ST = typename TR::storage;
   constexpr int D = TR::VEC * LANES;
   constexpr int PAIRS = kThreads / LANES;
@@ -605,7 +613,7 @@ int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int
                        static_cast<const ST*>(value) + b0 * image_elems, ss, ls,
                        static_cast<const ST*>(loc) + b0 * loc_per_image, static_cast<const ST*>(w) + b0 * w_per_image,
                        static_cast<ST*>(out) + b0 * pairs_per_image * D, n_pairs, (unsigned)pairs_per_image,
-                       (unsigned)image_bytes, M, L, P, fb);
+                       (unsigned)image_bytes, M, L, P, fb, behind_op4 ? (int)S : 0, behind_op4 ? (int)(B * M) : 0);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
   }
@@ -614,12 +622,13 @@ int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int
 
 template <class TR>
 int dispatch_tiled(int lanes, hipStream_t st, const void* value, const int64_t* ss, const int64_t* ls,
-                   const void* loc, const void* w, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq, int P) {
+                   const void* loc, const void* w, void* out, int64_t B, int64_t S, int M, int L, int64_t Nq, int P,
+                   bool behind_op4 = false) {
   const FusedArgs none{nullptr, 0, 0, 0};
   switch (lanes) {
     case 1: return launch_tiled<TR, 1, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
     case 2: return launch_tiled<TR, 2, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
-    case 4: return launch_tiled<TR, 4, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
+    case 4: return launch_tiled<TR, 4, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none, behind_op4);
     case 8: return launch_tiled<TR, 8, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
     case 16: return launch_tiled<TR, 16, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
     case 32: return launch_tiled<TR, 32, false>(st, value, ss, ls, loc, w, out, B, S, M, L, Nq, P, none);
@@ -681,7 +690,7 @@ const char* codetr_msda_variant(int elem_bytes, int M, int D, int L, int P) {
   return "scalar";
 }
 
-#define CODETR_MSDA_ENTRY(NAME, TR, ST, AT, CV, EB)                                                              \
+#define CODETR_MSDA_ENTRY(NAME, TR, ST, AT, CV, EB, OP4)                                                              \
   int NAME(void* stream, const void* value_dev, const int64_t* spatial_shapes_dev, const int64_t* level_start_dev, \
            const void* loc_dev, const void* weight_dev, int64_t B, int64_t S, int M, int D, int L, int64_t Nq,   \
            int P, int64_t im2col_step, void* out_dev) {                                                          \
@@ -690,18 +699,26 @@ const char* codetr_msda_variant(int elem_bytes, int M, int D, int L, int P) {
     if (rc) return rc;                                                                                           \
     hipStream_t st = static_cast<hipStream_t>(stream);                                                           \
     const int lanes = tiled_lanes(EB, D, L, P);                                                                  \
+    /* encoder-shaped fp16 calls: the windowed kernel first, this file's kernel behind it with the skip test on */ \
+    bool behind_op4 = false;                                                                                     \
+    if (OP4 && lanes == 4 && codetr_msda_op4_supported(EB, B, S, M, D, L, Nq, P)) {                               \
+      const int orc = codetr_msda_op4_forward_f16(stream, value_dev, spatial_shapes_dev, level_start_dev, loc_dev, \
+                                                  weight_dev, B, S, M, D, L, Nq, P, out_dev);                     \
+      if (orc == 0) behind_op4 = true;                                                                           \
+      else if (orc != CODETR_E_UNSUPPORTED) return orc;                                                          \
+    }                                                                                                            \
     if (lanes) {                                                                                                 \
       const int trc = dispatch_tiled<TR>(lanes, st, value_dev, spatial_shapes_dev, level_start_dev, loc_dev,     \
-                                         weight_dev, out_dev, B, S, M, L, Nq, P);                                \
+                                         weight_dev, out_dev, B, S, M, L, Nq, P, behind_op4);                    \
       if (trc != CODETR_E_TOO_LARGE) return trc;                                                                 \
     }                                                                                                            \
     return launch_scalar<ST, AT, CV>(st, value_dev, spatial_shapes_dev, level_start_dev, loc_dev, weight_dev,    \
                                      out_dev, B, S, M, D, L, Nq, P);                                             \
   }
 
-CODETR_MSDA_ENTRY(codetr_msda_forward_f16, F16, _Float16, float, CvF16, 2)
-CODETR_MSDA_ENTRY(codetr_msda_forward_bf16, BF16, unsigned short, float, CvBF16, 2)
-CODETR_MSDA_ENTRY(codetr_msda_forward_f32, F32, float, float, CvF32, 4)
+CODETR_MSDA_ENTRY(codetr_msda_forward_f16, F16, _Float16, float, CvF16, 2, true)
+CODETR_MSDA_ENTRY(codetr_msda_forward_bf16, BF16, unsigned short, float, CvBF16, 2, false)
+CODETR_MSDA_ENTRY(codetr_msda_forward_f32, F32, float, float, CvF32, 4, false)
 
 #define CODETR_MSDA_FUSED_ENTRY(NAME, TR, REF32)                                                                 \
   int NAME(void* stream, const void* value_dev, const int64_t* spatial_shapes_dev, const int64_t* level_start_dev, \

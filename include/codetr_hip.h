@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 45
+#define CODETR_HIP_ABI_VERSION 46
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -82,6 +82,22 @@ int codetr_msda_forward_f64(void *stream, const void *value_dev, const int64_t *
                             const int64_t *level_start_dev, const void *loc_dev, const void *weight_dev,
                             int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P, int64_t im2col_step,
                             void *out_dev);
+
+/* The windowed kernel behind codetr_msda_forward_f16 for encoder-shaped calls (round 6, csrc/msda_op4.hip; the same op,
+ * reference codetr/csrc/ms_deform_attn.cu:211-261, 762-779): Nq == S, 5 levels x 4 points, 32-channel heads, fp16.  Per
+ * (16 x 16 region of the finest level, head) the value rows the region's samples can reach are staged in LDS with a zero
+ * border, sampling locations / attention weights reach the lanes through LDS records, samples outside a window take a
+ * fix-up path with the reference's gate -- results as the general kernel's for ANY locations.  codetr_msda_forward_f16 calls it
+ * by itself; the two entry points are exported for tests and benchmarks:
+ *   codetr_msda_op4_supported    the host-visible part of the routing test (types, counts, 32-bit offset ranges); the
+ *                                pyramid itself is a device tensor and is judged on the device (csrc/msda_op4_plan.h)
+ *   codetr_msda_op4_forward_f16  launches the windowed kernel only: where the device-side plan does not apply its workgroups
+ *                                return without writing `out` (codetr_msda_forward_f16 launches the general kernel behind
+ *                                it, which evaluates the same plan and returns at once where this kernel did the work) */
+int codetr_msda_op4_supported(int elem_bytes, int64_t B, int64_t S, int M, int D, int L, int64_t Nq, int P);
+int codetr_msda_op4_forward_f16(void *stream, const void *value_dev, const int64_t *spatial_shapes_dev,
+                                const int64_t *level_start_dev, const void *loc_dev, const void *weight_dev, int64_t B,
+                                int64_t S, int M, int D, int L, int64_t Nq, int P, void *out_dev);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-scale deformable attention with its prologue fused.
