@@ -189,8 +189,30 @@ def msda_offset_stats(model, images, masks, halo=4):
     return rec
 
 
+def _msda_op_pmc():
+    """HBM-side bytes per launch of the public op's kernels from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/rNN_msda_op_pmc.json, newest round first; made by tools/pmc_msda_op.sh + tools/fold_msda_op_pmc.py on
+    tools/bench_msda_op.py --pmc: the same shapes and inputs as below; reads corrected x2 as MI355X_MICROARCH.md prescribes for
+    gfx950).  Counters cannot be collected from inside this process."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_msda_op_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            d["_file"] = os.path.relpath(path, ROOT)
+            return d
+        except (OSError, ValueError):
+            continue
+    return {}
+
+
 def msda_roofline(B, H, W, dtype, device, iters=30):
-    """Time the MSDA HIP kernel alone at the encoder shape (Nq = S) with HIP events on the launch stream."""
+    """Time the PUBLIC op torch.ops.codetr.multi_scale_deformable_attention alone with HIP events on the launch stream:
+    at the encoder shape (Nq = S: the windowed kernel of csrc/msda_op4.hip + the general kernel's skipped launch behind it)
+    and at the decoder shape (Nq = 900: the general kernel).  Returns (encoder record, decoder record)."""
+    from codetr import _cabi
+
     shapes = pyramid(H, W)
     ss = torch.tensor(shapes, dtype=torch.int64, device=device)
     ls = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
@@ -205,29 +227,64 @@ def msda_roofline(B, H, W, dtype, device, iters=30):
         refs.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
     ref = torch.cat(refs)[None, :, None, None, None, :]
     norm = torch.stack((ss[:, 1], ss[:, 0]), -1).float()[None, None, None, :, None, :]
+    op = torch.ops.codetr.multi_scale_deformable_attention
+    st = torch.cuda.current_stream(device)
+    pmc = _msda_op_pmc()
+
+    def timed(loc, w):
+        for _ in range(5):
+            op(value, ss, ls, loc, w, 64)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record(st)
+            op(value, ss, ls, loc, w, 64)
+            b.record(st)
+        torch.cuda.synchronize(device)
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return sum(ts) / len(ts) * 1e-3
+
+    tname = "BF16" if dtype == torch.bfloat16 else "F16"
+    # ---- encoder shape ----
     loc = (ref + torch.randn(B, S, M, L, P, 2, device=device, generator=g) * 3.0 / norm).to(dtype).contiguous()
     w = torch.rand(B, S, M, L, P, device=device, generator=g)
     w = (w / w.sum((-1, -2), keepdim=True)).to(dtype).contiguous()
-    op = torch.ops.codetr.multi_scale_deformable_attention
-    for _ in range(5):
-        op(value, ss, ls, loc, w, 64)
-    st = torch.cuda.current_stream(device)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in evs:
-        a.record(st)
-        op(value, ss, ls, loc, w, 64)
-        b.record(st)
-    torch.cuda.synchronize(device)
-    ts = sorted(a.elapsed_time(b) for a, b in evs)
-    avg_s = sum(ts) / len(ts) * 1e-3
+    windowed = bool(_cabi.load().codetr_msda_op4_supported(value.element_size(), B, S, M, D, L, S, P)) and dtype == torch.float16
+    avg_s = timed(loc, w)
     nbytes = msda_algorithmic_bytes(B, S, S, e=value.element_size())
     achieved = nbytes / avg_s / 1e9
-    return {
-        "kernel": "msda_tiled_kernel<%s,4> (encoder call, Nq=S=%d, batch %d)" % ("BF16" if dtype == torch.bfloat16 else "F16", S, B),
+    enc = {
+        "kernel": ("msda_op4_kernel (windowed: per-(region, head) LDS windows + zero border, locations / weights through LDS "
+                   "records, fp32 blend, fix-up path) + msda_tiled_kernel<%s,4>'s skipped launch behind it" % tname if windowed
+                   else "msda_tiled_kernel<%s,4>" % tname) + " (encoder call, Nq=S=%d, batch %d, 3 px of spread)" % (S, B),
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": pmc.get("encoder", {}).get("hbm_bytes_per_launch") if windowed else None,
+        "traffic_source": pmc.get("_file") if windowed else None,
         "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg_s * 1e6, 1),
     }
+    del loc, w
+    # ---- decoder shape: 900 queries anywhere in the image, 10 px of spread around each query's point ----
+    Nq = 900
+    refq = torch.rand(B, Nq, 1, 1, 1, 2, device=device, generator=g) * 0.8 + 0.1
+    loc = (refq + torch.randn(B, Nq, M, L, P, 2, device=device, generator=g) * 10.0 / norm).to(dtype).contiguous()
+    w = torch.softmax(torch.randn(B, Nq, M, L * P, device=device, generator=g), -1).view(B, Nq, M, L, P).to(dtype).contiguous()
+    avg_s = timed(loc, w)
+    e = value.element_size()
+    baseline_bytes = msda_algorithmic_bytes(B, S, Nq, e=e)                      # the whole value map read once
+    touched = e * B * (Nq * M * L * P * 4 * D + 3 * Nq * M * L * P + Nq * M * D)   # at most 4 corner rows per sample are ever read
+    nbytes = min(baseline_bytes, touched)
+    achieved = nbytes / avg_s / 1e9
+    dec = {
+        "kernel": "msda_tiled_kernel<%s,4> (decoder call, Nq=%d, S=%d, batch %d)" % (tname, Nq, S, B),
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": pmc.get("decoder", {}).get("hbm_bytes_per_launch"), "traffic_source": pmc.get("_file"),
+        "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg_s * 1e6, 1),
+        "note": "BASELINE.md section 3 prices this call at %d bytes (the whole value map read once); 900 queries x 8 heads x 20 "
+                "samples x 4 corner rows can touch at most %d bytes of it, which is what `achieved` uses -- a launch of 113 "
+                "workgroups on 256 CUs is bound by latency, not by bandwidth" % (baseline_bytes, touched),
+    }
+    return enc, dec
 
 
 def _pmc_traffic():
@@ -878,7 +935,7 @@ def main():
             # rooflines: one eager forward over the images of ONE replayed graph (batch / streams: the launches of the
             # timed region, same shapes and kernels; the committed PMC passes ran this shape).  The stand-alone MSDA
             # operator and the latency are single-image quantities.
-            op = msda_roofline(1, H, W, dtype, device)
+            op, op_dec = msda_roofline(1, H, W, dtype, device)
             out["latency_batch1"] = batch1_latency(model, images[:1].contiguous(), masks[:1].contiguous(), device)
             # ... and at the reference's other two published sizes (README.md:33-35: 1920x1280, 1152x768, 608x608)
             by_size = {a.res: out["latency_batch1"]}
@@ -899,6 +956,7 @@ def main():
                 out.update(kernel_rooflines(model, xi, xm, device))
                 out["roofline_images_per_launch"] = nb
                 out["roofline_msda_op"] = op
+                out["roofline_msda_op_dec"] = op_dec
                 if "roofline_msda" in out:
                     out["roofline_msda"]["offsets"] = msda_offset_stats(model, xi, xm)
                     if a.offset_noise_px > 0:

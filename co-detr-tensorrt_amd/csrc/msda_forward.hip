@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
   // device-side plan applies it has done the work (the pyramid's shapes are a device tensor: the host cannot tell)
   if (skip_S != 0) {
     codetr_op4::Plan plan;
-    if (codetr_op4::make_plan(spatial_shapes, level_start, skip_S, skip_BM, plan)) return;
+    if (codetr_op4::make_plan(spatial_shapes, level_start, skip_S, skip_BM, plan, false)) return;   // (the verdict alone)
   }
   constexpr int VEC = TR::VEC;
   constexpr int D = VEC * LANES;
@@ -285,16 +285,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Entry* entries = reinterpret_cast<Entry*>(smem_raw);  // [L*P][PAIRS]
 
-  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
-  const unsigned pair0 = tile * PAIRS;
   const int LP = L * P;
   const unsigned row_bytes = (unsigned)(M * D * sizeof(S));  // one pixel, all heads
-
-  // ---------------- phase 1: sample points -> {corner offsets, weights} in LDS ----------------
   int* s_meta = reinterpret_cast<int*>(entries + (size_t)LP * PAIRS);
   load_level_table(s_meta, spatial_shapes, level_start, L);
   const int pl = threadIdx.x / LANES;
   const int sub = threadIdx.x % LANES;
+  // One tile per workgroup in the ordinary launch (grid = tiles).  Behind the windowed kernel the grid is capped (a skipped
+  // launch of 25 000 workgroups costs ~30 us of dispatch alone) and a workgroup walks tiles blockIdx, blockIdx + grid, ...
+  // (measured: with the ordinary launch routed through the stride loop as well the decoder-shaped call went from 12 to
+  // 30 us -- the body is therefore instantiated twice, once straight-line and once inside the loop)
+  auto do_tile = [&](const unsigned tile) {
+  const unsigned pair0 = tile * PAIRS;
+
+  // ---------------- phase 1: sample points -> {corner offsets, weights} in LDS ----------------
   {
     unsigned g = pair0 + pl;
     g = g < n_pairs ? g : n_pairs - 1;  // tail: recompute the last pair, its store is masked
@@ -360,6 +364,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSDA_W
 #pragma unroll
     for (int j = 0; j < VEC; ++j) packed[j] = TR::from_f32(acc[j]);
     *reinterpret_cast<V*>(reinterpret_cast<unsigned char*>(out) + ((size_t)g * D * sizeof(S) + lane_byte)) = packed;
+  }
+  };
+  if (skip_S == 0) {
+    do_tile(xcd_tile(blockIdx.x, gridDim.x));
+  } else {
+    const unsigned n_tiles = (n_pairs + PAIRS - 1) / PAIRS;
+    for (unsigned tile = xcd_tile(blockIdx.x, gridDim.x); tile < n_tiles; tile += gridDim.x) {
+      do_tile(tile);
+      __syncthreads();   // the entries are rewritten for the next tile
+    }
   }
 }
 
@@ -604,7 +618,8 @@ int launch_tiled(hipStream_t st, const void* value, const int64_t* ss, const int
   for (int64_t b0 = 0; b0 < B; b0 += bc) {
     const int64_t nb = (B - b0) < bc ? (B - b0) : bc;
     const unsigned n_pairs = (unsigned)(nb * pairs_per_image);
-    const unsigned grid = (n_pairs + PAIRS - 1) / PAIRS;
+    unsigned grid = (n_pairs + PAIRS - 1) / PAIRS;
+    if (behind_op4 && grid > 2048u) grid = 2048u;   // (the kernel walks tiles with a grid stride)
     FusedArgs fb = fa;
     if (FUSED)
       fb.ref = fa.ref_f32 ? static_cast<const void*>(static_cast<const float*>(fa.ref) + b0 * Nq * L * fa.ref_dim)

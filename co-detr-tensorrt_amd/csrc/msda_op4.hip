@@ -44,12 +44,12 @@ namespace {
 
 using namespace codetr_op4;
 
-constexpr int kQ = 2;                         // fix-up records per (query, head) pair and queue round
+constexpr int kQ = 1;                         // fix-up records per (query, head) pair and queue round
 constexpr int kWaves = kThreads / 64;
 constexpr int kRecBytes = 144;                // operand record of a pair: 128 bytes used, 144 apart (bank spread)
 constexpr unsigned kWinBytes = kWinPixels * 64u;
 constexpr unsigned kQueueBytes = kPairs * kQ * 32u;
-constexpr unsigned kLdsBytes = kWinBytes + kQueueBytes;   // 79 872 B: two workgroups per CU
+constexpr unsigned kLdsBytes = kWinBytes + kQueueBytes;   // 80 896 B: two workgroups per CU
 static_assert(kWaves * 16 * kRecBytes <= (int)kWinBytes, "the operand records alias the front of the window area");
 #ifndef MSDA_OP4_ABL
 #define MSDA_OP4_ABL 0     // timing experiments only: 2: no staging, 4: no gather, 8: no preparation, 32: no output stores (WRONG results)
@@ -169,6 +169,9 @@ __device__ __forceinline__ Smp sample_at(const Lv& v, unsigned o2) {
   return s;
 }
 
+// weight of level k out of the lane's five packed halves
+__device__ __forceinline__ float weight_of(const unsigned (&awp)[3], int k) { return (float)as_h2(awp[k >> 1])[k & 1]; }
+
 // prepared sample: LDS address of its (x0, y0) row, the four corner weights (zero when the sample is not served from LDS)
 struct Prep {
   unsigned ad;
@@ -196,115 +199,98 @@ __device__ __forceinline__ bool prepare(Prep& pp, const Lv& v, const float a, co
 // kernel runs at four waves per SIMD, 128 registers)
 __device__ __forceinline__ void gather_level(float (&acc)[8], const Prep& pp, const unsigned pitch, const unsigned lds_lane) {
   using LV = const __attribute__((address_space(3))) u32x4*;
-  u32x4 rows[2][4];
+  // 16 rows (4 points x 4 corners), a ring of 5 registers sets: row k + 4 is requested right before row k is consumed (a
+  // double buffer of whole steps needs 8 sets: the kernel runs at four waves per SIMD, 128 registers, and spilled)
+  constexpr int RING = 5;
+  u32x4 rows[RING];
   // DPP hazard (see msda_encoder4.hip): the inline-assembly DPP add reads an address register the instruction right before
   // may have written; one s_nop tied to it
   unsigned adr = pp.ad;
   asm volatile("s_nop 1" : "+v"(adr));
-  auto fetch = [&](int o, int buf) {
-    const unsigned a0 = quad_bcast_add(adr, o, lds_lane);
-    const unsigned a1 = a0 + pitch;
-    rows[buf][0] = *(LV)(uintptr_t)a0;
-    rows[buf][1] = *(LV)(uintptr_t)(a0 + 64);
-    rows[buf][2] = *(LV)(uintptr_t)a1;
-    rows[buf][3] = *(LV)(uintptr_t)(a1 + 64);
+  unsigned a0[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) a0[o] = quad_bcast_add(adr, o, lds_lane);
+  auto fetch = [&](int k) {   // row k = point k >> 2, corner k & 3
+    const unsigned a = a0[k >> 2] + ((k & 2) ? pitch : 0u) + ((k & 1) ? 64u : 0u);
+    rows[k % RING] = *(LV)(uintptr_t)a;
   };
-  fetch(0, 0);
 #pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    const int b = o & 1;
-    if (o + 1 < 4) fetch(o + 1, b ^ 1);
-    const float wq[4] = {quad_bcast_f(pp.w00, o), quad_bcast_f(pp.w01, o), quad_bcast_f(pp.w10, o), quad_bcast_f(pp.w11, o)};
+  for (int k = 0; k < RING - 1; ++k) fetch(k);
 #pragma unroll
-    for (int cr = 0; cr < 4; ++cr)
+  for (int k = 0; k < 16; ++k) {
+    if (k + RING - 1 < 16) fetch(k + RING - 1);
+    const int o = k >> 2, cr = k & 3;
+    const float w = quad_bcast_f(cr == 0 ? pp.w00 : cr == 1 ? pp.w01 : cr == 2 ? pp.w10 : pp.w11, o);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fma_h2(acc[2 * j], acc[2 * j + 1], rows[b][cr][j], wq[cr]);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < 4; ++j) fma_h2(acc[2 * j], acc[2 * j + 1], rows[k % RING][j], w);
+    if (cr == 3) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // samples the windows do not serve: re-derived with the reference's gate / corner logic (cu:52-71, 249), queued per pair
 // (32-byte records in LDS: first pixel, corner strides, four fp32 weights) and added from global memory by the pair's four
 // lanes, kQ records per round
-template <int LV0, int NLV>
-struct Fix {
-  u32x4 ra[NLV], rb[NLV];
-  unsigned bad;
-  int cnt;
+// One sample re-derived the reference's way: (is it served by the windows?, does it pass the gate?) and its record
+struct FixRec {
+  u32x4 ra, rb;
+  bool ok, gate;
+};
+__device__ __forceinline__ FixRec fix_record(const Lv& v, const float a, const unsigned o2) {
+  FixRec f;
+  const Smp s = sample_at(v, o2);
+  const unsigned dx = (unsigned)(s.x0 - v.px0), dy = (unsigned)(s.y0 - v.py0);
+  f.ok = dx <= (unsigned)v.xspan && dy <= (unsigned)v.yspan;
+  // cu:249: h_im > -1 && w_im > -1 && h_im < H && w_im < W  <=>  floor in [-1, size - 1]
+  f.gate = (unsigned)(s.x0 + 1) <= (unsigned)v.W && (unsigned)(s.y0 + 1) <= (unsigned)v.H;
+  const float wy0 = s.y0 >= 0 ? (1.f - s.lh) * a : 0.f, wy1 = s.y0 + 1 <= v.H - 1 ? s.lh * a : 0.f;   // cu:52-71
+  const float wx0 = s.x0 >= 0 ? 1.f - s.lw : 0.f, wx1 = s.x0 + 1 <= v.W - 1 ? s.lw : 0.f;
+  const int x0c = max(s.x0, 0), x1c = min(s.x0 + 1, v.W - 1), y0c = max(s.y0, 0), y1c = min(s.y0 + 1, v.H - 1);
+  f.ra = u32x4{(unsigned)(v.start + y0c * v.W + x0c), (unsigned)((y1c - y0c) * v.W) | ((unsigned)(x1c - x0c) << 16), 0u, 0u};
+  f.rb = u32x4{__float_as_uint(wy0 * wx0), __float_as_uint(wy0 * wx1), __float_as_uint(wy1 * wx0), __float_as_uint(wy1 * wx1)};
+  return f;
+}
 
-  __device__ __forceinline__ void derive(const Lv (&lv)[kL], const float (&aw)[kL], const unsigned (&o2)[kL], const int sub) {
-    bad = 0;
+// The rare path: one queued sample per pair and round.  Nothing but the pair's `bad` mask stays live between rounds -- the
+// record of a sample is re-derived when its turn comes (the kernel runs at 128 registers; a path that kept the records and
+// two rounds' rows cost the main path 27 spilled registers).
+template <int LV0, int NLV>
+__device__ __forceinline__ void fixup(float (&acc)[8], const Lv (&lv)[kL], const unsigned (&awp)[3], const unsigned (&o2)[kL],
+                                      u32x4* __restrict__ queue, const unsigned char* __restrict__ vhead, const unsigned pix_bytes,
+                                      const int sub) {
+  unsigned bad = 0;
 #pragma unroll
-    for (int i = 0; i < NLV; ++i) {
-      const Lv& v = lv[LV0 + i];
-      const Smp s = sample_at(v, o2[LV0 + i]);
-      const unsigned dx = (unsigned)(s.x0 - v.px0), dy = (unsigned)(s.y0 - v.py0);
-      const bool ok = dx <= (unsigned)v.xspan && dy <= (unsigned)v.yspan;
-      // cu:249: h_im > -1 && w_im > -1 && h_im < H && w_im < W  <=>  floor in [-1, size - 1]
-      const bool gate = (unsigned)(s.x0 + 1) <= (unsigned)v.W && (unsigned)(s.y0 + 1) <= (unsigned)v.H;
-      const float a = aw[LV0 + i];
-      const float wy0 = s.y0 >= 0 ? (1.f - s.lh) * a : 0.f, wy1 = s.y0 + 1 <= v.H - 1 ? s.lh * a : 0.f;   // cu:52-71
-      const float wx0 = s.x0 >= 0 ? 1.f - s.lw : 0.f, wx1 = s.x0 + 1 <= v.W - 1 ? s.lw : 0.f;
-      const int x0c = max(s.x0, 0), x1c = min(s.x0 + 1, v.W - 1), y0c = max(s.y0, 0), y1c = min(s.y0 + 1, v.H - 1);
-      ra[i] = u32x4{(unsigned)(v.start + y0c * v.W + x0c), (unsigned)((y1c - y0c) * v.W) | ((unsigned)(x1c - x0c) << 16), 0u, 0u};
-      rb[i] = u32x4{__float_as_uint(wy0 * wx0), __float_as_uint(wy0 * wx1), __float_as_uint(wy1 * wx0), __float_as_uint(wy1 * wx1)};
-      bad |= (!ok && gate) ? 1u << (sub + 4 * i) : 0u;
-    }
-    bad |= dpp_u<kXor2>(bad);
-    bad |= dpp_u<kXor1>(bad);
-    cnt = __builtin_popcount(bad);
+  for (int i = 0; i < NLV; ++i) {
+    const FixRec f = fix_record(lv[LV0 + i], weight_of(awp, LV0 + i), o2[LV0 + i]);
+    bad |= (!f.ok && f.gate) ? 1u << (sub + 4 * i) : 0u;
   }
-  __device__ __forceinline__ void push(u32x4* __restrict__ queue, int base, int sub) {
+  bad |= dpp_u<kXor2>(bad);
+  bad |= dpp_u<kXor1>(bad);
+  const int cnt = __builtin_popcount(bad);
+  for (int base = 0; __builtin_amdgcn_ballot_w64(cnt > base) != 0; ++base) {
 #pragma unroll
     for (int i = 0; i < NLV; ++i) {
       const int pt = sub + 4 * i;
-      if ((bad >> pt) & 1u) {
-        const int pos = __builtin_popcount(bad & ((1u << pt) - 1u)) - base;
-        if ((unsigned)pos < (unsigned)kQ) {
-          queue[2 * pos] = ra[i];
-          queue[2 * pos + 1] = rb[i];
-        }
+      if (((bad >> pt) & 1u) && __builtin_popcount(bad & ((1u << pt) - 1u)) == base) {
+        const FixRec f = fix_record(lv[LV0 + i], weight_of(awp, LV0 + i), o2[LV0 + i]);
+        queue[0] = f.ra;
+        queue[1] = f.rb;
       }
     }
-  }
-  __device__ __forceinline__ void blend(float (&acc)[8], const u32x4* __restrict__ queue, int base, const unsigned char* __restrict__ vhead,
-                                        unsigned pix_bytes) {
-    u32x4 r4[kQ][4], wts[kQ];
+    __builtin_amdgcn_wave_barrier();   // (the quad reads what one of its lanes just queued: one wave, LDS in order -- pins the compiler)
+    if (base < cnt) {
+      const u32x4 rc = queue[0], wts = queue[1];
+      const unsigned char* p = vhead + (size_t)rc[0] * pix_bytes;
+      const unsigned xs = (rc[1] >> 16) * pix_bytes, ys = (rc[1] & 0xffffu) * pix_bytes;
+      const u32x4 r0 = *reinterpret_cast<const u32x4*>(p), r1 = *reinterpret_cast<const u32x4*>(p + xs);
+      const u32x4 r2 = *reinterpret_cast<const u32x4*>(p + ys), r3 = *reinterpret_cast<const u32x4*>(p + ys + xs);
 #pragma unroll
-    for (int j = 0; j < kQ; ++j) {
-      if (base + j < cnt) {
-        const u32x4 rc = queue[2 * j];
-        wts[j] = queue[2 * j + 1];
-        const unsigned char* p = vhead + (size_t)rc[0] * pix_bytes;
-        const unsigned xs = (rc[1] >> 16) * pix_bytes, ys = (rc[1] & 0xffffu) * pix_bytes;
-        r4[j][0] = *reinterpret_cast<const u32x4*>(p);
-        r4[j][1] = *reinterpret_cast<const u32x4*>(p + xs);
-        r4[j][2] = *reinterpret_cast<const u32x4*>(p + ys);
-        r4[j][3] = *reinterpret_cast<const u32x4*>(p + ys + xs);
+      for (int jj = 0; jj < 4; ++jj) {
+        fma_h2(acc[2 * jj], acc[2 * jj + 1], r0[jj], __uint_as_float(wts[0]));
+        fma_h2(acc[2 * jj], acc[2 * jj + 1], r1[jj], __uint_as_float(wts[1]));
+        fma_h2(acc[2 * jj], acc[2 * jj + 1], r2[jj], __uint_as_float(wts[2]));
+        fma_h2(acc[2 * jj], acc[2 * jj + 1], r3[jj], __uint_as_float(wts[3]));
       }
     }
-#pragma unroll
-    for (int j = 0; j < kQ; ++j) {
-      if (base + j < cnt) {
-#pragma unroll
-        for (int cr = 0; cr < 4; ++cr)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) fma_h2(acc[2 * jj], acc[2 * jj + 1], r4[j][cr][jj], __uint_as_float(wts[j][cr]));
-      }
-    }
-  }
-};
-
-template <int LV0, int NLV>
-__device__ __forceinline__ void fixup(float (&acc)[8], const Lv (&lv)[kL], const float (&aw)[kL], const unsigned (&o2)[kL],
-                                      u32x4* __restrict__ queue, const unsigned char* __restrict__ vhead, const unsigned pix_bytes,
-                                      const int sub) {
-  Fix<LV0, NLV> fx;
-  fx.derive(lv, aw, o2, sub);
-  for (int base = 0; __builtin_amdgcn_ballot_w64(fx.cnt > base) != 0; base += kQ) {
-    fx.push(queue, base, sub);
-    __builtin_amdgcn_wave_barrier();   // (the quad reads what its lanes just queued: one wave, LDS in order -- pins the compiler)
-    fx.blend(acc, queue, base, vhead, pix_bytes);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -465,27 +451,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
     // every wave is done with the previous tile's staged rows and queue before the records overwrite the window area
     __syncthreads();
     // ---- through LDS: the pair's record [(x, y) of level 0-4: 80 B | weights: 40 B], read back transposed ----
-    float aw[kMaxIt][kL], acc[kMaxIt][8];
-    unsigned o2[kMaxIt][kL];
+    float acc[kMaxIt][8];
+    unsigned o2[kMaxIt][kL], awp[kMaxIt][3];   // the five weights stay packed halves (three registers per iteration)
 #pragma unroll
     for (int it = 0; it < kMaxIt; ++it) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[it][j] = 0.f;
 #pragma unroll
-      for (int k = 0; k < kL; ++k) {
-        o2[it][k] = 0u;
-        aw[it][k] = 0.f;
-      }
+      for (int k = 0; k < kL; ++k) o2[it][k] = 0u;
+      awp[it][0] = awp[it][1] = awp[it][2] = 0u;
       if (it < n_it) {
         *reinterpret_cast<u32x4*>(rec + sub * 16) = rawA[it];
         *reinterpret_cast<u32x2*>(rec + 64 + sub * 16) = rawB[it];
         *reinterpret_cast<u32x2*>(rec + 72 + sub * 16) = rawC[it];
         __builtin_amdgcn_wave_barrier();   // (the LDS serves one wave's operations in order; this only pins the compiler)
 #pragma unroll
-        for (int k = 0; k < kL; ++k) {
-          o2[it][k] = *reinterpret_cast<const unsigned*>(rec + k * 16 + sub * 4);
-          aw[it][k] = (float)*reinterpret_cast<const _Float16*>(rec + 80 + (k * 4 + sub) * 2);
-        }
+        for (int k = 0; k < kL; ++k) o2[it][k] = *reinterpret_cast<const unsigned*>(rec + k * 16 + sub * 4);
+        unsigned short wh[kL];
+#pragma unroll
+        for (int k = 0; k < kL; ++k) wh[k] = *reinterpret_cast<const unsigned short*>(rec + 80 + (k * 4 + sub) * 2);
+        awp[it][0] = (unsigned)wh[0] | ((unsigned)wh[1] << 16);
+        awp[it][1] = (unsigned)wh[2] | ((unsigned)wh[3] << 16);
+        awp[it][2] = (unsigned)wh[4];
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -532,11 +519,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
           for (int i = 0; i < NLV; ++i) {
             const Lv& v = lv[LV0 + i];
             Prep pp = Prep{v.base, 0.f, 0.f, 0.f, 0.f};
-            if (!(kAbl & 8)) clean = prepare(pp, v, aw[it][LV0 + i], o2[it][LV0 + i]) && clean;
+            if (!(kAbl & 8)) clean = prepare(pp, v, weight_of(awp[it], LV0 + i), o2[it][LV0 + i]) && clean;
             gather_level(acc[it], pp, v.pitch, lds_lane);
           }
           clean = __builtin_amdgcn_ballot_w64(!clean) == 0;
-          if (!clean) fixup<LV0, NLV>(acc[it], lv, aw[it], o2[it], queue, vhead, pix_bytes, sub);
+          if (!clean) fixup<LV0, NLV>(acc[it], lv, awp[it], o2[it], queue, vhead, pix_bytes, sub);
         }
     };
     run_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});

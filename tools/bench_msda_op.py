@@ -20,7 +20,7 @@ M, D, L, P = 8, 32, 5, 4
 
 
 def pyramid(H, W):
-    out, h, w = [], -(-H // 8), -(-W // 8)
+    out, h, w = [], -(-H // 4), -(-W // 4)      # strides 4 .. 64 (Co-DINO Swin-L 5-scale: 320 x 480 ... 20 x 30 at 1920x1280)
     for _ in range(L):
         out.append((h, w))
         h, w = -(-h // 2), -(-w // 2)
