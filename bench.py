@@ -133,11 +133,7 @@ def msda_offset_stats(model, images, masks, halo=4):
         # the coarser levels' sub-pixel phases)
         wmiss = None
         if pyramid_shapes is not None:
-            if packed:
-                wl = att._encoder_windows_packed(pyramid_shapes)
-            else:
-                passes = hip_ops.msda_encoder_passes(torch.float16, att.num_levels, att.num_points)
-                wl = att._encoder_windows(pyramid_shapes, torch.float16, passes)
+            wl = att._encoder_windows_packed(pyramid_shapes)
             win = torch.tensor(wl, dtype=torch.float32, device=off.device)             # [M, L, 4] lox, hix, loy, hiy
             o = off.view(*off.shape[:-1], att.num_heads, att.num_levels, att.num_points, 2)
             x0, y0 = torch.floor(o[..., 0]), torch.floor(o[..., 1])
@@ -421,7 +417,7 @@ def kernel_rooflines(model, images, masks, device):
     if enc:
         from codetr import _cabi as _cabi_mod
 
-        enc_native = _cabi_mod.CALLS.get("msda_encoder", 0) > 0   # the LDS-staged encoder kernel served the launches
+        enc_native = _cabi_mod.CALLS.get("msda_encoder_packed", 0) > 0   # the LDS-staged encoder kernel served the launches
         m = enc[0][2]
         e = 2
         # value + offsets (2 per point) + logits (1 per point) + output, each touched once
@@ -430,10 +426,7 @@ def kernel_rooflines(model, images, masks, device):
         out["roofline_msda"] = {
             "kernel": "%s (the %d encoder launches of one forward, Nq = S = %d)" % (
                 "msda_encoder_v4_kernel (lane-major packed projection, head-major value map, scalar geometry, zero-border "
-                "windows; packed-half blend, three passes, fp32 reference points)" if _cabi_mod.CALLS.get("msda_encoder_packed", 0) > 0 else
-                ("msda_encoder_v3_kernel<F16> (packed-half blend, three passes, fp32 reference points)"
-                 if __import__("codetr.hip_ops", fromlist=["x"]).msda_encoder_passes(torch.float16, m["L"], m["P"]) == 3
-                 else "msda_encoder_kernel<F16> (generic L x P, one pass)") if enc_native
+                "windows; packed-half blend, three passes, fp32 reference points)" if enc_native
                 else "msda_tiled_kernel<F16,4,fused>", len(enc), m["S"]),
             "bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),

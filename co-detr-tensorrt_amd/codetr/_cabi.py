@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 46
+ABI_VERSION = 47
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -40,15 +40,6 @@ SIGNATURES = {
                                                    _i32, _i32, _i32, _i64, _i32, _vp]),
     "codetr_msda_fused_forward_ref32_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _i64,
                                                     _i32, _i32, _i32, _i64, _i32, _vp]),
-    "codetr_msda_encoder_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32,
-                                               _i32, _i32, _vp]),
-    "codetr_msda_encoder_forward_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32,
-                                                _i32, _i32, _vp]),
-    "codetr_msda_encoder_forward_win_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
-                                                   _i32, _i32, _vp, _i32, _vp]),
-    "codetr_msda_encoder_forward_win_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
-                                                    _i32, _i32, _vp, _i32, _vp]),
-    "codetr_msda_encoder_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32]),
     "codetr_msda_encoder_forward_packed_f16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
                                                       _vp, _i32, _i32, _i32, _i32, _vp]),
     "codetr_msda_encoder_forward_packed_bf16": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
@@ -177,7 +168,7 @@ _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_varian
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
             "codetr_linear_sk_workspace_bytes", "codetr_linear_sk_supported", "codetr_linear_sk_preferred",
             "codetr_linear_pp_supported", "codetr_linear_pp_preferred", "codetr_msda_op4_supported",
-            "codetr_msda_encoder_lds_bytes", "codetr_msda_encoder_packed_lds_bytes", "codetr_msda_pack_projection_index",
+            "codetr_msda_encoder_packed_lds_bytes", "codetr_msda_pack_projection_index",
             "codetr_mx_scale_bytes", "codetr_decoder_layer_supported",
             "codetr_decoder_layer_blob_halfs"}
 
@@ -634,8 +625,6 @@ def msda_fused(value, spatial_shapes, level_start_index, proj, off_col, logit_co
     return out
 
 
-_MSDA_ENCODER_BY_DTYPE = {torch.float16: "codetr_msda_encoder_forward_win_f16",
-                          torch.bfloat16: "codetr_msda_encoder_forward_win_bf16"}
 E_UNSUPPORTED = -4
 
 
@@ -647,37 +636,6 @@ def _windows_array(windows, M, L):
     if len(flat) != M * L * 4 or any(not -128 <= v <= 127 for v in flat):
         raise ValueError(f"msda_encoder: windows must be [M={M}][L={L}][4] int8 values")
     return (ctypes.c_int8 * len(flat))(*flat)
-
-
-def msda_encoder_lds_bytes(level_shapes, M, num_points, windows, variant=2) -> int:
-    """LDS bytes per workgroup codetr_msda_encoder_forward_win_* needs for these windows (variant 1: generic, 2: packed
-    single pass, 3: three passes; negative: CODETR_E_* code)"""
-    L = len(level_shapes)
-    shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
-    return int(load().codetr_msda_encoder_lds_bytes(shapes, M, L, num_points, _windows_array(windows, M, L), int(variant)))
-
-
-def msda_encoder(value, level_shapes, proj, off_col, logit_col, ref, num_points, windows, out, passes=1,
-                 valid_counts=None) -> bool:
-    """Encoder self-attention form (queries = pixels of the pyramid): value [B,S,M,32]; level_shapes = host
-    list of (h, w); proj / ref as msda_fused (ref [B,S,L,2]); windows [M][L][4] or a halo; passes 1 | 3; valid_counts
-    [B,L,2] fp32 or None (see the header).  Returns False when the library reports the shape as unsupported (the caller
-    then uses msda_fused), raises on any other error."""
-    lib = load()
-    B, S, M, D = value.shape
-    L = len(level_shapes)
-    shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
-    ncols, es = proj.shape[2], proj.element_size()
-    rc = getattr(lib, _MSDA_ENCODER_BY_DTYPE[value.dtype])(
-        current_stream_ptr(value.device), value.data_ptr(), shapes,
-        proj.data_ptr() + off_col * es, ncols, proj.data_ptr() + logit_col * es, ncols, ref.data_ptr(),
-        valid_counts.data_ptr() if valid_counts is not None else None, B, S, M, D, L,
-        num_points, _windows_array(windows, M, L), int(passes), out.data_ptr())
-    if rc == E_UNSUPPORTED:
-        return False
-    check(rc, "codetr_msda_encoder_forward_win")
-    CALLS["msda_encoder"] += 1
-    return True
 
 
 def linear_bf16_f16out(x2d, weight, bias, out2d, row_mask=None, hm_rows=0, hm_head_dim=0) -> bool:

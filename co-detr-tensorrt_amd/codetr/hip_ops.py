@@ -25,7 +25,7 @@ NATIVE = {"msda", "linear(f16/bf16, K%64==0)", "layer_norm(f16/bf16)", "swin_win
           "encoder_geometry(f16: reference points, proposals, keep/drop state)", "row_max(f16)",
           "preprocess_image(u8 -> f16/f32, cv2-exact resize + pad + normalise + mask)", "batched_nms(f32)",
           "patch_merge_layernorm(f16: Swin 2x2 gather + LayerNorm)",
-          "msda_encoder(f16/bf16: LDS-staged gather for the encoder's self-attention)",
+          "msda_encoder_packed(f16/bf16: LDS-staged gather for the encoder's self-attention, csrc/msda_encoder4.hip)",
           "patch_embed(f16/bf16: 4x4 patch gather + GEMM)",
           "mha_attention(f16/bf16: dense softmax attention, head_dim 32, <= 1024 keys)",
           "topk(f16/bf16 rows, k <= 1024: radix select + bitonic sort)",
@@ -678,15 +678,11 @@ def topk(x, k, want_values=True):
 # Route switches of the encoder MSDA (plain module attributes; tools/ab_host_routes.py patches them for A/B runs -- the
 # package reads no CODETR_* environment variable except checkpoint.py's CODETR_ALLOW_PICKLE):
 MSDA_ENCODER = True     # False = general fused kernel in the encoder
-MSDA_HALO = 4           # staged offset range when no windows are given
-MSDA_WINDOWS = True     # False = symmetric halo instead of bias windows
-MSDA_PASSES = 3         # 1 = single-pass encoder kernels only
 MSDA_FP32_REF = True    # False = reference points read in the model dtype
-MSDA_LDS_BUDGET = {1: 80 * 1024, 3: 40 * 1024}   # bytes per workgroup: two / four workgroups per CU share 160 KiB
 
 
 _SWITCH_DEFAULTS = {"LINEAR_PP": True, "LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
-                    "MSDA_HALO": 4, "MSDA_WINDOWS": True, "MSDA_PASSES": 3, "MSDA_FP32_REF": True, "FP8_MIN_TILES": 96}
+                    "MSDA_FP32_REF": True, "FP8_MIN_TILES": 96}
 
 
 def nondefault_switches():
@@ -705,82 +701,8 @@ def nondefault_switches():
     return sorted(out)
 
 
-def msda_encoder_passes(dtype, num_levels, num_points):
-    """3 where the three-pass encoder kernel exists (fp16, 5 levels x 4 points), else 1"""
-    return 3 if (MSDA_PASSES == 3 and dtype == torch.float16 and num_levels == 5 and num_points == 4) else 1
-
-
-def msda_encoder_windows(bias, level_shapes, num_heads, num_levels, num_points, passes=1, fp16=True):
-    """Staged window per (head, level) for the encoder kernel from the offset bias [M*L*P*2] (pixels): the bounding box
-    of the head's P bias points on that level, grown on every side by the largest margin (pixels, steps of 1/2) that
-    keeps the workgroup inside MSDA_LDS_BUDGET -- per head (LDS is per (region, head) workgroup) and, with three
-    passes, per pass (each pass stages only its own levels).  A trained head's offsets scatter around its bias points;
-    the reference's initialisation is the grid of multi_scale_deformable_attention.py:90-115.  Host arithmetic on a
-    parameter copy: call once per (module, pyramid) and cache."""
-    import math
-
-    b = bias.detach().float().cpu().view(num_heads, num_levels, num_points, 2)
-    b = torch.round(b * 1024) / 1024   # (cos(pi / 2) is 6e-17, not 0: keep floor / ceil off such dust)
-    lo, hi = b.amin(2).tolist(), b.amax(2).tolist()      # [M][L][2]
-    variant = 3 if passes == 3 else (2 if fp16 and num_levels == 5 and num_points == 4 else 1)
-    groups = [[0], [1, 2], [3, 4]] if passes == 3 else [list(range(num_levels))]
-
-    def window(m, l, mg):
-        return (max(-127, math.floor(lo[m][l][0] - mg)), min(127, math.ceil(hi[m][l][0] + mg)),
-                max(-127, math.floor(lo[m][l][1] - mg)), min(127, math.ceil(hi[m][l][1] + mg)))
-
-    out = []
-    for m in range(num_heads):
-        win = [window(m, l, 0.0) for l in range(num_levels)]
-        for grp in groups:
-            for half in range(24, -1, -1):
-                trial = list(win)
-                for l in grp:
-                    trial[l] = window(m, l, 0.5 * half)
-                need = _cabi.msda_encoder_lds_bytes(level_shapes, num_heads, num_points, [trial] * num_heads, variant)
-                if 0 < need <= MSDA_LDS_BUDGET[passes] or half == 0:
-                    win = trial
-                    break
-        out.append(win)
-    return out
-
-
-def msda_encoder(value, level_shapes, proj, off_col, logit_col, reference_points, num_points, windows=None, passes=1,
-                 valid_counts=None):
-    """Encoder self-attention form of msda_fused (queries = the pixels of the pyramid, 2-d reference points): the
-    gather runs out of LDS-staged neighbourhoods.  level_shapes: host sequence of (h, w); windows: [M][L][4] staged
-    offset ranges (msda_encoder_windows), default the symmetric MSDA_HALO; passes: 1 | 3; valid_counts [B,L,2] fp32
-    (hip_ops.mask_pyramid): with passes == 3 the reference points are then computed in fp32 inside the kernel instead of
-    being read in the model dtype.  Returns None when the library does not take the shape (caller falls back to
-    msda_fused); fp16 at the model's shape: within the op tolerance of msda_fused, not bit-identical (packed-half blend,
-    see include/codetr_hip.h)."""
-    _gpu(value, "msda_encoder")
-    B, S, M, D = value.shape
-    if not (MSDA_ENCODER and D == 32 and value.dtype in (torch.float16, torch.bfloat16)
-            and proj.shape[1] == S and reference_points.shape[-1] == 2 and len(level_shapes) <= 8):
-        return None
-    out = torch.empty((B, S, M * D), dtype=value.dtype, device=value.device)
-    ok = [True]
-    win = windows if (windows is not None and MSDA_WINDOWS) else MSDA_HALO
-    vc = valid_counts if (passes == 3 and MSDA_FP32_REF and valid_counts is not None) else None
-    if vc is not None and not (vc.dtype == torch.float32 and vc.is_contiguous() and vc.shape == (B, len(level_shapes), 2)):
-        raise ValueError("msda_encoder: valid_counts must be a contiguous fp32 [B, L, 2] tensor")
-
-    def run():
-        ok[0] = _cabi.msda_encoder(value.contiguous(), level_shapes, proj.contiguous(), off_col, logit_col,
-                                   reference_points.to(value.dtype).contiguous(), num_points, win, out, passes, vc)
-        if not ok[0] and passes == 3:    # (regions of more queries than the three-pass kernel's waves hold)
-            ok[0] = _cabi.msda_encoder(value.contiguous(), level_shapes, proj.contiguous(), off_col, logit_col,
-                                       reference_points.to(value.dtype).contiguous(), num_points, MSDA_HALO, out, 1, None)
-
-    with torch.cuda.device(value.device):
-        _timed("msda_fused", {"B": B, "S": S, "Nq": S, "M": M, "D": D, "L": len(level_shapes), "P": num_points},
-               run, value.device)
-    return out if ok[0] else None
-
-
 # ---- round-5 encoder kernel (csrc/msda_encoder4.hip): lane-major packed projection, scalar geometry, zero border ----
-MSDA_V4 = True                 # route switch: False = the round-3/4 three-pass kernel on the unpacked projection
+MSDA_V4 = True                 # route switch: False = the general fused kernel on the unpacked projection
 # Measured on MI355X at 4 x 1920x1280, offsets with 0 / 2 / 4 / 8 px of spread (profiles/r05_msda_encoder4_sweep.txt):
 # 512 threads x 16x16 regions x 64 KiB = 918 / 973 / 1210 / 1637 us per launch; 256 x 16x8 x 40 KiB = 926 / 1019 / 1332 /
 # 1832; 80 KiB windows trade 3 % at 2 px for 5 % at 8 px (round-4 kernel: 1220 / 1318 / 1810 / 2566).

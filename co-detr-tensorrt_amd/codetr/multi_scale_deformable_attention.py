@@ -146,13 +146,6 @@ class MultiScaleDeformableAttention(nn.Module):
         return self._windows_lru(key, lambda b: hip_ops.msda_encoder_windows_packed(
             b, list(shapes), self.num_heads, self.num_levels, self.num_points))
 
-    def _encoder_windows(self, host_shapes, dtype, passes):
-        """staged window per (head, level) of the LDS-staged encoder kernel, from the offset bias; rebuilt only when
-        the bias tensor or the pyramid changes (one device-to-host copy of 320 values, outside the steady state)"""
-        shapes = tuple((int(h), int(w)) for h, w in host_shapes)
-        return self._windows_lru(("v3", shapes, passes, str(dtype)), lambda b: hip_ops.msda_encoder_windows(
-            b, list(shapes), self.num_heads, self.num_levels, self.num_points, passes, dtype == torch.float16))
-
     # ------------------------------------------------------------------ batch-first core
     def forward_bf(self, query, value, identity, query_pos, key_padding_mask, reference_points, spatial_shapes,
                    level_start_index, query_plus_pos=None, value_projected=None, defer_output_proj=False):
@@ -247,17 +240,8 @@ class MultiScaleDeformableAttention(nn.Module):
             # one GEMM for (offsets | logits); softmax and location arithmetic happen inside the MSDA kernel
             Wc, bc = self._fused_projection()
             proj = hip_ops.linear_xadd(query, pos_in_gemm, Wc, bc) if pos_in_gemm is not None else hip_ops.linear(query, Wc, bc)
-            out = None
-            host_shapes = getattr(spatial_shapes, "_codetr_host", None)
-            if host_shapes is not None and Nq == S and reference_points.shape[-1] == 2:
-                # encoder self-attention: queries are the pixels of the pyramid -> LDS-staged gather
-                passes = hip_ops.msda_encoder_passes(v.dtype, L, P)
-                out = hip_ops.msda_encoder(v, host_shapes, proj, 0, H * L * P * 2, reference_points, P,
-                                           self._encoder_windows(host_shapes, v.dtype, passes), passes,
-                                           getattr(reference_points, "_codetr_valid_counts", None))
-            if out is None:
-                out = hip_ops.msda_fused(v, spatial_shapes, level_start_index, proj, 0, H * L * P * 2,
-                                         reference_points, L, P)
+            # (encoder calls the packed kernel turned down -- other level / point counts, head widths -- run here too)
+            out = hip_ops.msda_fused(v, spatial_shapes, level_start_index, proj, 0, H * L * P * 2, reference_points, L, P)
             return hip_ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=identity)
         offsets = hip_ops.linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias)
         offsets = offsets.view(B, Nq, H, L, P, 2)

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 46
+#define CODETR_HIP_ABI_VERSION 47
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -145,71 +145,12 @@ int codetr_msda_fused_forward_ref32_bf16(void *stream, const void *value_dev, co
                                          int M, int D, int L, int64_t Nq, int P, void *out_dev);
 
 /* ------------------------------------------------------------------------------------------
- * Encoder self-attention form of the fused op (LDS-staged gather).  bf16, and fp16 shapes other than L == 5, P == 4: the
- * general kernel's arithmetic, bit-identical results.  fp16 with L == 5, P == 4: packed-half blend, within the op tolerance
- * of codetr_msda_fused_forward_f16 but not bit-identical (see the _win entry below).
- *
- * For DetrTransformerEncoder (codetr/transformer.py:81-92), where the queries ARE the pixels of the flattened
- * multi-level map (Nq == S, query q = pixel q) and reference_points are 2-d (get_reference_points,
- * codetr/transformer.py:280-305): a workgroup serves every query of one 64x32-image-pixel region for one head
- * and first stages the region's neighbourhood on every level in LDS, so each value row crosses L2 -> CU once
- * per region instead of once per sample.  Samples that leave the staged neighbourhood (offsets beyond `halo`
- * pixels of the sampled level) are read from global memory: `halo` changes speed, never results.
- *
- *   value_dev          [B, S, M, D]   D == 32, 16-bit storage
- *   level_shapes_host  [L][2] (h, w) HOST copy of spatial_shapes (the launch geometry depends on it); sum h*w == S
- *   offsets / logits / ref as for codetr_msda_fused_forward_* with ref_dim == 2
- *   halo               staged offset range in pixels of the sampled level (4 = the reference's initialisation,
- *                      multi_scale_deformable_attention.py:90-115); CODETR_E_UNSUPPORTED if the neighbourhoods
- *                      of one region exceed 160 KB of LDS (callers fall back to codetr_msda_fused_forward_*)
+ * Encoder self-attention form of the fused op (LDS-staged gather), for DetrTransformerEncoder
+ * (codetr/transformer.py:81-92), where the queries ARE the pixels of the flattened multi-level map (Nq == S, query q =
+ * pixel q) and reference_points are 2-d (get_reference_points, codetr/transformer.py:280-305).
+ * (The round-3/4 forms codetr_msda_encoder_forward[_win]_* left the library in round 6 with their kernels:
+ * tools/micro/experiments/msda_encoder_v3.hip.)
  * ------------------------------------------------------------------------------------------ */
-int codetr_msda_encoder_forward_f16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
-                                    const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
-                                    int64_t logits_row_stride, const void *ref_dev, int64_t B, int64_t S, int M, int D,
-                                    int L, int P, int halo, void *out_dev);
-int codetr_msda_encoder_forward_bf16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
-                                     const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
-                                     int64_t logits_row_stride, const void *ref_dev, int64_t B, int64_t S, int M,
-                                     int D, int L, int P, int halo, void *out_dev);
-
-/* The same with a staged WINDOW per (head, level) instead of one symmetric halo, fp32 reference points, and the
- * three-pass form:
- *   windows_host      [M][L][4] int8 (x lo, x hi, y lo, y hi): sampling offsets, in pixels of the sampled level relative
- *                     to the query's own location, inside [x lo, x hi] x [y lo, y hi] are served from LDS; halo h is
- *                     (-h, h, -h, h).  A trained head's offsets lean one way (the reference initialises head m along
- *                     the angle 2 pi m / M, multi_scale_deformable_attention.py:90-115): the host derives the windows
- *                     from sampling_offsets.bias so that the same LDS covers more of what the head actually samples.
- *   passes            1: all levels staged at once (<= 80 KiB per workgroup keeps two per CU), the general kernel's fp32
- *                     arithmetic: bit-identical to codetr_msda_fused_forward_*;
- *                     3: fp16, L == 5, P == 4 only (CODETR_E_UNSUPPORTED otherwise): levels {0}, {1, 2}, {3, 4} staged
- *                     one pass after the other, accumulators kept in registers -- <= 40 KiB and <= 128 registers per
- *                     workgroup, four per CU, wider windows in the same LDS.
- *   valid_counts_dev  NULL, or (passes == 3) [B][L][2] fp32: valid pixels of every level mask's first row (w) and first
- *                     column (h), as codetr_mask_pyramid writes them.  When given, ref_dev is ignored (may be NULL) and the
- *                     reference point of query pixel (x, y) of level q on level l is computed in fp32 as
- *                     ((x + 0.5) / (vr_q W_q)) vr_l with vr = count / size -- get_reference_points and the per-level
- *                     scaling of the reference (transformer.py:280-305, 384-400, 530) without the model dtype's rounding
- *                     (fp16 resolves a coordinate in [0.5, 1) to 1/2048: a quarter pixel on a 480-wide level).
- * Windows change speed, never results beyond the rounding of the packed blend: for fp16 with L == 5, P == 4 the blend
- * runs on packed halves (fp16 corner weights, 8-term fp16 partial sums added in fp32; samples outside the windows
- * are added in fp32): within rtol 1e-2 / atol 1e-3 of the fp64 oracle (the reference's own half tolerance,
- * tests/test_multi_scale_deformable_attention.py:62, 363-364), not
- * bit-identical to codetr_msda_fused_forward_f16.
- * codetr_msda_encoder_lds_bytes: LDS bytes per workgroup a launch would need (variant 1 or 2: the single-pass kernel -- the
- * packed single-pass form of round 3 was deleted in round 5 --, 3: three passes), or a negative CODETR_E_* code. */
-int codetr_msda_encoder_forward_win_f16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
-                                        const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
-                                        int64_t logits_row_stride, const void *ref_dev, const float *valid_counts_dev,
-                                        int64_t B, int64_t S, int M, int D, int L, int P, const int8_t *windows_host,
-                                        int passes, void *out_dev);
-int codetr_msda_encoder_forward_win_bf16(void *stream, const void *value_dev, const int64_t *level_shapes_host,
-                                         const void *offsets_dev, int64_t offsets_row_stride, const void *logits_dev,
-                                         int64_t logits_row_stride, const void *ref_dev, const float *valid_counts_dev,
-                                         int64_t B, int64_t S, int M, int D, int L, int P, const int8_t *windows_host,
-                                         int passes, void *out_dev);
-int64_t codetr_msda_encoder_lds_bytes(const int64_t *level_shapes_host, int M, int L, int P,
-                                      const int8_t *windows_host, int variant);
-
 /* Round-5 form of the encoder kernel ("v4", csrc/msda_encoder4.hip): the same op -- ms_deform_attn.cu:31-77, 211-261 with
  * the softmax / sampling-location prologue of multi_scale_deformable_attention.py:180-196 and the reference points of
  * transformer.py:280-305 -- for fp16, L == 5, P == 4, D == 32, with the (offsets | logits) projection handed over in a

@@ -210,8 +210,8 @@ def test_host_package_reads_no_route_switch_from_the_environment():
 
     assert hip_ops.nondefault_switches() == []
     transformer.DEC_FUSED = False
-    hip_ops.MSDA_PASSES = 1
+    hip_ops.MSDA_V4_THREADS = 256
     try:
-        assert hip_ops.nondefault_switches() == ["DEC_FUSED", "MSDA_PASSES"]
+        assert hip_ops.nondefault_switches() == ["DEC_FUSED", "MSDA_V4_THREADS"]
     finally:
-        transformer.DEC_FUSED, hip_ops.MSDA_PASSES = True, 3
+        transformer.DEC_FUSED, hip_ops.MSDA_V4_THREADS = True, 512

@@ -2,10 +2,10 @@
 (tests/test_cabi.py::test_host_package_reads_no_route_switch_from_the_environment): the switches are module attributes
 at their measured-best defaults, and this tool patches them from the OUTSIDE before it starts a bench / a script.
 
-    python tools/ab_host_routes.py --set MSDA_PASSES=1 --set DEC_FUSED=0 -- bench.py --batch 4 --steps 5
+    python tools/ab_host_routes.py --set MSDA_V4_REGION=16x8 --set DEC_FUSED=0 -- bench.py --batch 4 --steps 5
     python tools/ab_host_routes.py --list
 
-Switch names: hip_ops.{LN_GEMM, XADD, XADD_MIN_ROWS, MERGE_LN, MSDA_ENCODER, MSDA_HALO, MSDA_WINDOWS, MSDA_PASSES,
+Switch names: hip_ops.{LN_GEMM, XADD, XADD_MIN_ROWS, MERGE_LN, MSDA_ENCODER, LINEAR_PP,
 MSDA_FP32_REF, MSDA_V4 (+ _THREADS, _REGION, _LDS_BUDGET, _MARGIN_CAP, _HEAD_MAJOR), FP8_MIN_TILES}, transformer.{DEC_FUSED, DEC_VPROJ}, multi_scale_deformable_attention.HEAD_MAJOR_VALUE."""
 import argparse
 import os

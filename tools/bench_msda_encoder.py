@@ -66,26 +66,22 @@ def main():
         return e0.elapsed_time(e1) / a.iters * 1e3
 
     bias = off_bias = (grid[:, None, None, :] * (torch.arange(P, device=dev) + 1)[None, None, :, None]).expand(M, L, P, 2)
-    win = hip_ops.msda_encoder_windows(bias.reshape(-1), shapes, M, L, P, a.passes) if a.windows else None
     counts = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=dev)[None].expand(B, L, 2).contiguous()
-    enc = lambda: hip_ops.msda_encoder(value, shapes, proj, 0, M * L * P * 2, ref, P, win, a.passes,  # noqa: E731
-                                       counts if a.counts else None)
-    if a.v4:
-        hip_ops.MSDA_V4_THREADS = a.threads
-        hip_ops.MSDA_V4_REGION = tuple(int(v) for v in a.region.split("x"))
-        hip_ops.MSDA_V4_LDS_BUDGET = a.budget if a.budget else (40 * 1024 if a.threads == 256 else 64 * 1024)
-        hip_ops.MSDA_V4_MARGIN_CAP = a.cap
-        idx = torch.tensor(_cabi.msda_pack_projection_index(M, L, P), device=dev)
-        packed = proj[..., idx.clamp_min(0)].clone()
-        packed[..., idx < 0] = 0
-        packed = packed.contiguous()
-        win = hip_ops.msda_encoder_windows_packed(bias.reshape(-1), shapes, M, L, P)
-        vhm = value.permute(0, 2, 1, 3).contiguous() if a.hm else None
-        enc = lambda: hip_ops.msda_encoder_packed(vhm if a.hm else value, shapes, packed, P, win, counts, bool(a.hm))  # noqa: E731
-        print("v4 windows head 0/1:", win[0], win[1], "lds",
-              _cabi.msda_encoder_packed_lds_bytes(shapes, M, P, win, hip_ops.MSDA_V4_REGION, a.threads))
-    elif win is not None:
-        print("windows head 0/1:", win[0], win[1], "lds", _cabi.msda_encoder_lds_bytes(shapes, M, P, win, 3 if a.passes == 3 else 2))
+    # (the round-3/4 kernels -- --v4 0, --passes, --windows, --counts -- left the library in round 6:
+    # tools/micro/experiments/msda_encoder_v3.hip)
+    hip_ops.MSDA_V4_THREADS = a.threads
+    hip_ops.MSDA_V4_REGION = tuple(int(v) for v in a.region.split("x"))
+    hip_ops.MSDA_V4_LDS_BUDGET = a.budget if a.budget else (40 * 1024 if a.threads == 256 else 64 * 1024)
+    hip_ops.MSDA_V4_MARGIN_CAP = a.cap
+    idx = torch.tensor(_cabi.msda_pack_projection_index(M, L, P), device=dev)
+    packed = proj[..., idx.clamp_min(0)].clone()
+    packed[..., idx < 0] = 0
+    packed = packed.contiguous()
+    win = hip_ops.msda_encoder_windows_packed(bias.reshape(-1), shapes, M, L, P)
+    vhm = value.permute(0, 2, 1, 3).contiguous() if a.hm else None
+    enc = lambda: hip_ops.msda_encoder_packed(vhm if a.hm else value, shapes, packed, P, win, counts, bool(a.hm))  # noqa: E731
+    print("v4 windows head 0/1:", win[0], win[1], "lds",
+          _cabi.msda_encoder_packed_lds_bytes(shapes, M, P, win, hip_ops.MSDA_V4_REGION, a.threads))
     gen = lambda: hip_ops.msda_fused(value, ss, ls, proj, 0, M * L * P * 2, ref, L, P)  # noqa: E731
     o1, o2 = enc(), gen()
     assert o1 is not None
@@ -93,10 +89,10 @@ def main():
     rel = ((o1.double() - o2.double()).norm() / o2.double().norm()).item()
     t_enc, t_gen = timed(enc), timed(gen)
     alg = 2 * (B * S * M * D + 3 * B * S * M * L * P + B * S * M * D)
-    print(f"batch {B} noise {a.noise} halo {hip_ops.MSDA_HALO}: encoder kernel {t_enc:8.1f} us "
+    print(f"batch {B} noise {a.noise}: encoder kernel {t_enc:8.1f} us "
           f"({alg / t_enc / 1e6:6.2f} TB/s algorithmic)   general fused {t_gen:8.1f} us   identical: {same} "
-          f"rel L2 vs general {rel:.2e}  windows {'bias' if a.windows else 'halo'} passes {a.passes} counts {a.counts}"
-          + (f"  v4 threads {a.threads} region {a.region} cap {a.cap} hm {a.hm} budget {hip_ops.MSDA_V4_LDS_BUDGET}" if a.v4 else ""))
+          f"rel L2 vs general {rel:.2e}"
+          f"  v4 threads {a.threads} region {a.region} cap {a.cap} hm {a.hm} budget {hip_ops.MSDA_V4_LDS_BUDGET}")
 
 
 if __name__ == "__main__":

@@ -1,3 +1,8 @@
+// EXPERIMENT / A-B baseline, not part of libcodetr_hip.so since round 6 (dead weight in the product
+// library): the round-3/4 encoder MSDA kernels -- the generic single-pass LDS-staged kernel (bit-identical to the general
+// kernel) and the three-pass packed-half kernel ("v3") that csrc/msda_encoder4.hip replaced in round 5.  Their C-ABI entry
+// points (codetr_msda_encoder_forward[_win]_{f16,bf16}, codetr_msda_encoder_lds_bytes), host wrappers and tests left the
+// product with this file; build it as its own shared object to compare (profiles/r05_msda_encoder4_sweep.txt has the numbers).
 // Encoder self-attention form of the fused multi-scale deformable attention for MI355X (gfx950 / CDNA4).
 //
 // Same arithmetic as msda_tiled_kernel<.., FUSED> (msda_forward.hip): the op of reference

@@ -35,7 +35,7 @@ def main():
     if forwards <= 0:  # derive: encoder_geometry_kernel runs once per forward
         forwards = int(sum(v[0] for n, v in fetch.items() if "encoder_geometry_kernel" in n)) or 1
     # "linear_": linear_kernel + linear_xs_kernel + linear_256_kernel + splitk_reduce: every launch behind hip_ops.linear
-    groups = {"linear_": "linear_kernel", "msda_tiled_kernel": "msda", "msda_encoder_kernel": "msda_encoder", "ffn_fused_kernel": "ffn_fused",
+    groups = {"linear_": "linear_kernel", "msda_tiled_kernel": "msda", "msda_encoder_v4_kernel": "msda_encoder", "msda_op4_kernel": "msda_op4", "linear_pp_kernel": "linear_pp", "ffn_fused_kernel": "ffn_fused",
               "window_attention_kernel": "window_attention", "layernorm_kernel": "layernorm"}
     out = {"unit": "bytes", "forwards_profiled": forwards,
            "note": "FETCH_SIZE / WRITE_SIZE (KiB) x 1024; read_corrected = 2 x read_raw (gfx950 128-B requests tallied as 64 B)",
