@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 47
+ABI_VERSION = 48
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -106,6 +106,9 @@ SIGNATURES = {
     "codetr_linear_sk_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
     "codetr_msda_op4_supported": (_i32, [_i32, _i64, _i64, _i32, _i32, _i32, _i64, _i32]),
     "codetr_msda_op4_forward_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i64, _i32, _vp]),
+    "codetr_swin_mlp_supported": (_i32, [_i64, _i64, _i64]),
+    "codetr_swin_mlp_f16": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "codetr_swin_mlp_bf16": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "codetr_linear_pp_supported": (_i32, [_i64, _i64, _i64]),
     "codetr_linear_pp_preferred": (_i32, [_i64, _i64, _i64, _i32, _i32]),
     "codetr_linear_pp_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32]),
@@ -156,7 +159,7 @@ CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attent
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "msda_encoder_packed": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
          # which kernel behind codetr_linear_* served a launch (codetr_linear_variant), and the two fused operand loads
-         "linear_pp": 0, "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0, "encoder_projections": 0,
+         "linear_pp": 0, "swin_mlp": 0, "linear_tile128": 0, "linear_tile256": 0, "linear_xs": 0, "linear_ln": 0, "linear_xadd": 0, "encoder_projections": 0,
          "linear_fp8": 0, "cast_fp8": 0, "layernorm_fp8": 0, "small_ops": 0, "ffn_fp8": 0, "decoder_layer": 0}
 
 
@@ -167,7 +170,7 @@ RECORDER = None
 _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_variant", "codetr_linear_variant",
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
             "codetr_linear_sk_workspace_bytes", "codetr_linear_sk_supported", "codetr_linear_sk_preferred",
-            "codetr_linear_pp_supported", "codetr_linear_pp_preferred", "codetr_msda_op4_supported",
+            "codetr_linear_pp_supported", "codetr_linear_pp_preferred", "codetr_msda_op4_supported", "codetr_swin_mlp_supported",
             "codetr_msda_encoder_packed_lds_bytes", "codetr_msda_pack_projection_index",
             "codetr_mx_scale_bytes", "codetr_decoder_layer_supported",
             "codetr_decoder_layer_blob_halfs"}
@@ -355,6 +358,17 @@ def linear_sk(x2d, weight, bias, residual2d, act, out2d, flags=0):
             residual2d.data_ptr() if residual2d is not None else None, out2d.data_ptr(), M, N, K, _ACT[act],
             ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, flags)
     check(rc, "codetr_linear_sk")
+    return out2d
+
+
+def swin_mlp(x2d, ln_w, ln_b, eps, w1, b1, w2_packed, b2, out2d):
+    """out = x + fc2(gelu(fc1(layer_norm(x)))) in one launch (csrc/swin_mlp.hip); w2_packed = ffn_pack_w2(fc2.weight)"""
+    CALLS["swin_mlp"] += 1
+    lib = load()
+    fn = lib.codetr_swin_mlp_bf16 if x2d.dtype == torch.bfloat16 else lib.codetr_swin_mlp_f16
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), float(eps), w1.data_ptr(),
+            b1.data_ptr(), w2_packed.data_ptr(), b2.data_ptr(), out2d.data_ptr(), x2d.shape[0], x2d.shape[1])
+    check(rc, "codetr_swin_mlp")
     return out2d
 
 

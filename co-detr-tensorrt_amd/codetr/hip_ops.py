@@ -278,6 +278,31 @@ def _packed_w2(w2):
     return hit[1]
 
 
+SWIN_MLP = True            # route switch (A/B): False = norm2 | fc1 + GELU | fc2 + identity as separate launches
+SWIN_MLP_MIN_ROWS = 32768  # below this a stage's MLP is a few dozen tiles: the separate GEMMs fill the chip better
+
+
+def swin_mlp_supported(x, ln_weight, w1, w2, act):
+    """the fused Swin MLP (csrc/swin_mlp.hip) serves x [.., C] with C in {192, 384}, hidden = 4 C, GELU, 16-bit storage"""
+    C = x.shape[-1]
+    return (SWIN_MLP and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and act == "gelu" and C in (192, 384)
+            and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C) and ln_weight is not None
+            and x.numel() // C >= SWIN_MLP_MIN_ROWS and w1.dtype == x.dtype and w2.dtype == x.dtype)
+
+
+def swin_mlp(x, ln_weight, ln_bias, eps, w1, b1, w2, b2):
+    """y = x + fc2(gelu(fc1(layer_norm(x)))): the second half of a SwinBlock in one launch (reference swin.py:331-352)"""
+    _gpu(x, "swin_mlp")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    out = torch.empty_like(x2)
+    with torch.cuda.device(x.device):
+        _cabi.swin_mlp(x2, ln_weight, ln_bias, eps, w1 if w1.is_contiguous() else w1.contiguous(), b1, _packed_w2(w2), b2, out)
+    return out.view(x.shape)
+
+
 def ffn_fused(x, w1, b1, w2, b2, ln=None, pos=None, ln_in=None):
     """y = x + relu(x @ w1.T + b1) @ w2.T + b2 in one kernel (hidden activation stays on-chip); x [..., 256].
     w2 is the plain nn.Linear weight; its packed form is cached.
@@ -681,7 +706,7 @@ MSDA_ENCODER = True     # False = general fused kernel in the encoder
 MSDA_FP32_REF = True    # False = reference points read in the model dtype
 
 
-_SWITCH_DEFAULTS = {"LINEAR_PP": True, "LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
+_SWITCH_DEFAULTS = {"LINEAR_PP": True, "SWIN_MLP": True, "SWIN_MLP_MIN_ROWS": 32768, "LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
                     "MSDA_FP32_REF": True, "FP8_MIN_TILES": 96}
 
 

@@ -258,6 +258,10 @@ class SwinBlock(nn.Module):
             h = hip_ops.layer_norm(x, n1.weight, n1.bias, n1.eps)
             x = self.attn(h, hw_shape, identity=x)
         fc1, fc2 = self.ffn.layers[0][0], self.ffn.layers[1]
+        if (isinstance(n2, nn.LayerNorm) and self.ffn.add_identity and fc1.bias is not None and fc2.bias is not None
+                and hip_ops.swin_mlp_supported(x, n2.weight, fc1.weight, fc2.weight, self.ffn.act)):
+            # stages 0 / 1: norm2, fc1, GELU, fc2 and the identity in ONE launch (the hidden activation stays on-chip)
+            return hip_ops.swin_mlp(x, n2.weight, n2.bias, n2.eps, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
         if (isinstance(n2, nn.LayerNorm) and self.ffn.add_identity
                 and hip_ops.linear_ln_supported(x, n2.weight, fc1.weight)):
             # norm2 folded into fc1 (+ GELU); fc2 adds the identity as before

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 47
+#define CODETR_HIP_ABI_VERSION 48
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -464,6 +464,23 @@ int codetr_linear_sk_f16(void *stream, const void *x_dev, const void *w_dev, con
 int codetr_linear_sk_bf16(void *stream, const void *x_dev, const void *w_dev, const void *bias_dev,
                           const void *residual_dev, void *y_dev, int64_t M, int64_t N, int64_t K, int act,
                           void *workspace_dev, int64_t workspace_bytes, int flags);
+
+/* Fused Swin MLP (round 6, csrc/swin_mlp.hip): y = x + fc2(GELU(fc1(LayerNorm(x)))) in one launch -- the second half of a
+ * SwinBlock (reference codetr/swin.py:331-352: x = x + ffn(norm2(x)), FFN = Linear(C, 4C) -> GELU (erf) -> Linear(4C, C)),
+ * for the stages whose MLP is bound by the bytes of its hidden activation: C = 192 / 384 (Swin-L stages 0 / 1).  The hidden
+ * activation and norm2's output never leave the CU.
+ *   x_dev / y_dev        [M, C] row-major, 16-bit storage (y may not alias x: rows are read twice)
+ *   ln_gamma / ln_beta   [C], ln_eps: norm2
+ *   w1_dev [4C, C], b1_dev [4C];  w2_packed_dev [C, 4C] = codetr_ffn_pack_w2_f16(fc2.weight);  b2_dev [C]
+ * CODETR_E_UNSUPPORTED for other C.  Numerics: LayerNorm and GELU in fp32, each rounded to the storage type once; fp32
+ * accumulation; fc2's output rounded before the identity is added (the reference's two roundings). */
+int codetr_swin_mlp_supported(int64_t M, int64_t C, int64_t hidden);
+int codetr_swin_mlp_f16(void *stream, const void *x_dev, const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps,
+                        const void *w1_dev, const void *b1_dev, const void *w2_packed_dev, const void *b2_dev, void *y_dev,
+                        int64_t M, int64_t C);
+int codetr_swin_mlp_bf16(void *stream, const void *x_dev, const void *ln_gamma_dev, const void *ln_beta_dev, float ln_eps,
+                         const void *w1_dev, const void *b1_dev, const void *w2_packed_dev, const void *b2_dev, void *y_dev,
+                         int64_t M, int64_t C);
 
 /* Ping-pong form of codetr_linear_sk_* (round 6, csrc/gemm_pp.hip) for the same layers (reference codetr/swin.py:92-112,
  * 331-352): the same persistent 256 x 256 tiles, operand ring and epilogue, but the two waves of every SIMD take turns --

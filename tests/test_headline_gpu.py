@@ -102,8 +102,11 @@ def test_headline_batch4_vs_oracle_rows_and_alone(case):
     assert calls["decoder_layer"] == 7 and calls["mha_attention"] == 6 and calls["window_attention"] == 24, calls
     assert calls["linear_xs"] > 0 and calls["linear_splitk"] > 0, calls
     # round 6: every linear of Swin stages 2 and 3 (20 blocks x 4) and stage 1's fc2 run on the ping-pong persistent GEMM
-    assert calls["linear_pp"] >= 82 and calls["linear_sk"] > 0, calls
-    assert calls["linear_tile128"] > 0 and calls["linear_ln"] == 4 and calls["topk"] == 1, calls
+    assert calls["linear_pp"] >= 80 and calls["linear_sk"] > 0, calls
+    # round 6: the MLPs of Swin stages 0 and 1 (2 + 2 blocks) are ONE launch each (norm2, fc1, GELU, fc2, identity); norm1 of
+    # stage 0 stays folded into its qkv GEMM (2 launches)
+    assert calls["swin_mlp"] == 4 and calls["linear_ln"] == 2, calls
+    assert calls["linear_tile128"] > 0 and calls["topk"] == 1, calls
     for a, b in zip(out4, out4b):   # the capture hook changes nothing
         assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float()))
     got = F.sample_capture(NAME, cap4, image=0, images=4)

@@ -95,7 +95,9 @@ def test_midsize_timed_route_vs_live_oracle():
     assert calls["msda_encoder"] == 6, calls        # LDS-staged encoder self-attention
     assert calls["decoder_layer"] == 7, calls       # decoder: head-only launch + one launch per layer (cross-attention inside)
     assert calls["linear_tile256"] > 0 and calls["linear_xs"] > 0 and calls["linear_tile128"] > 0, calls
-    assert calls["linear_ln"] == 4, calls           # Swin stage 0: norm1 -> qkv, norm2 -> fc1 of both blocks
+    # Swin stage 0: norm1 -> qkv of both blocks (2 launches of the LayerNorm-folded GEMM); the MLPs: norm2 -> fc1 folded the
+    # same way (2 more), or -- from 32 768 tokens -- the one-launch MLP of round 6 (csrc/swin_mlp.hip)
+    assert calls["linear_ln"] + calls["swin_mlp"] >= 4 and calls["linear_ln"] in (2, 4), calls
     assert calls["linear_splitk"] >= 1, calls       # the neck's stride-2 extra level (+ the few-tile, long-K Swin layers)
     assert calls["window_attention"] == 24 and calls["patch_merge_layernorm"] == 3, calls
     assert calls["groupnorm_tokens"] == 5 and calls["sine_pos_tokens"] == 5 and calls["mask_pyramid"] == 1, calls
