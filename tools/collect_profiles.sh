@@ -2,7 +2,7 @@
 # Round evidence run (on the GPU box, through gpurun): bench lines, kernel traces at 8 images / 1 image per step, PMC
 # passes (each in its own run, never with a trace).  Writes only small folded files under gpurun_out/final/.
 #   tools/collect_profiles.sh <tag>      e.g. r04
-tag=${1:-r05}
+tag=${1:-r06}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
 if [ -z "$SKIP_BENCH" ]; then
@@ -47,4 +47,11 @@ python tools/pmc_fold.py --fetch "$(find /tmp/pf -name '*counter_collection.csv'
 if [ -z "$SKIP_BENCH" ]; then
 timeout 600 python tools/export_and_run_plan.py --res 1920x1280 --batch 1 > $out/${tag}_runner_1920x1280.json 2> $out/runner.err
 fi
+# round 6: the public op (timings over the offset spread, counters), the Swin MLP fusion, the GEMM yardstick against hipBLASLt
+timeout 300 python tools/bench_msda_op.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_msda_op.txt
+rm -f $out/${tag}_msda_op_pmc.txt
+bash tools/pmc_msda_op.sh $out/${tag}_msda_op_pmc.txt 3
+python tools/fold_msda_op_pmc.py $out/${tag}_msda_op_pmc.txt > $out/${tag}_msda_op_pmc.json
+timeout 300 python tools/bench_swin_mlp.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_swin_mlp.txt
+(timeout 400 python tools/bench_linear_vs_lib.py --images 4; timeout 400 python tools/bench_linear_vs_lib.py --images 8) 2>&1 | grep -v amdgpu.ids > $out/${tag}_linear_vs_hipblaslt.txt
 ls -la $out; tail -1 $out/${tag}_bench.json | cut -c1-300; cat $out/${tag}_runner_1920x1280.json | cut -c1-600
