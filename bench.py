@@ -380,6 +380,20 @@ def kernel_rooflines(model, images, masks, device):
             "traffic": pmc.get("ffn_fused", {}).get("hbm_bytes_per_launch"),
             "avg_launch_us": round(t / len(ffn) * 1e6, 1),
         }
+    smlp = kprof.get("swin_mlp", [])
+    if smlp:
+        # round 6: the one-launch MLPs of Swin stages 0 / 1 (norm2, fc1, GELU, fc2, identity): 2 * M * C * 4C * 2 flops each
+        fl = sum(16.0 * m["M"] * m["C"] * m["C"] for _, _, m in smlp)
+        t = sum(a.elapsed_time(b) for a, b, _ in smlp) * 1e-3
+        out["roofline_swin_mlp"] = {
+            "kernel": "swin_mlp_kernel (%d launches: C = %s)" % (len(smlp), ", ".join(str(m["C"]) for _, _, m in smlp)),
+            "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(fl / t / 1e12 / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(t / len(smlp) * 1e6, 1),
+            "note": "the three launches it replaces (norm2 | fc1 + GELU | fc2 + identity) ran at 395 / 580 TF/s, bound by the "
+                    "bytes of the hidden activation (profiles/r06_swin_mlp.txt); this kernel is bound by the issue slots of its one "
+                    "wave per SIMD (GELU: as many vector-issue cycles as the chunk's MFMAs at C = 192)",
+        }
     ffn8 = kprof.get("ffn_fp8", [])
     if ffn8:
         fl = sum(4.0 * m["M"] * m["C"] * m["hidden"] for _, _, m in ffn8)

@@ -298,8 +298,11 @@ def swin_mlp(x, ln_weight, ln_bias, eps, w1, b1, w2, b2):
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     out = torch.empty_like(x2)
+    w1c = w1 if w1.is_contiguous() else w1.contiguous()
     with torch.cuda.device(x.device):
-        _cabi.swin_mlp(x2, ln_weight, ln_bias, eps, w1 if w1.is_contiguous() else w1.contiguous(), b1, _packed_w2(w2), b2, out)
+        w2p = _packed_w2(w2)
+        _timed("swin_mlp", {"M": x2.shape[0], "C": C},
+               lambda: _cabi.swin_mlp(x2, ln_weight, ln_bias, eps, w1c, b1, w2p, b2, out), x.device)
     return out.view(x.shape)
 
 
