@@ -348,7 +348,7 @@ def kernel_rooflines(model, images, masks, device):
     pl = pmc.get("linear_kernel", {})
     traffic = pl["hbm_bytes_per_forward"] / len(prof) if "hbm_bytes_per_forward" in pl else pl.get("hbm_bytes_per_launch")
     out["roofline"] = {
-        "kernel": "linear_sk_kernel / linear_kernel / linear_256_kernel / linear_xs_kernel (16-bit operands of the run's "
+        "kernel": "linear_pp_kernel / linear_sk_kernel / linear_kernel / linear_256_kernel / linear_xs_kernel (16-bit operands of the run's "
                   "dtype, fp32 accumulation; all %d launches of one forward)" % len(prof),
         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),

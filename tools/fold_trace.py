@@ -33,8 +33,13 @@ def main():
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([n, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / tot, min(v), max(v)])
-    # forwards are delimited by the 6 encoder launches of the fused FFN kernel; skip the first two (warm-up)
-    ffn = [i for i, r in enumerate(rows) if "ffn_fused" in r[0]]
+    # forwards are delimited by the 6 encoder launches of the packed MSDA kernel (exactly one per encoder layer at every
+    # batch size; the fused FFN kernel -- the delimiter of rounds 1-5 -- runs TWICE per layer where a left-over partial round
+    # goes to its 64-row form, which made the single-image summaries of rounds 5 and 6 count every forward as two); the fused
+    # FFN's launches only where that kernel is absent; skip the first two forwards (warm-up)
+    ffn = [i for i, r in enumerate(rows) if "msda_encoder_v4" in r[0]]
+    if len(ffn) < 18:
+        ffn = [i for i, r in enumerate(rows) if "ffn_fused" in r[0]]
     sel = rows[ffn[11] + 1:ffn[-1] + 1]
     n = (len(ffn) - 12) / 6
     t = sum(r[2] - r[1] for r in sel)
