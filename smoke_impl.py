@@ -1,6 +1,7 @@
 """smoke(): one small invocation of the hot path on cuda:0, checked against the oracle.
 
-(1) the MSDA HIP op on a model-shaped golden case vs the C oracle;
+(1) the MSDA HIP op on a model-shaped golden case vs the C oracle (decoder shape: the general kernel; encoder shape: the
+    windowed kernel of round 6);
 (2) a tiny Swin-backbone CoDETR (every module kind, 2 images, one padded) in fp16 on the GPU vs
     the functional fp32 CPU oracle on the same weights, with the proposal top-k forced equal."""
 import os
@@ -33,6 +34,29 @@ def run():
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2e-3, atol=1e-3)
     print("[smoke] MSDA HIP kernel (fp16, M=8 D=32 L=5 P=4) matches the oracle:",
           float(np.abs(out.float().cpu().numpy() - ref).max()))
+
+    # (1b) an encoder-shaped call (Nq == S >= 4096): the windowed kernel of csrc/msda_op4.hip behind the same op
+    from codetr import _cabi
+
+    shapes = np.asarray([(64, 96), (32, 48), (16, 24), (8, 12), (4, 6)], dtype=np.int64)
+    ls = np.concatenate(([0], np.cumsum(shapes[:, 0] * shapes[:, 1])[:-1])).astype(np.int64)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    rng = np.random.default_rng(3)
+    h16 = lambda a: a.astype(np.float16).astype(np.float64)  # noqa: E731
+    value = h16(rng.standard_normal((1, S, 8, 32)))
+    cen = np.concatenate([np.stack(np.meshgrid((np.arange(w_) + 0.5) / w_, (np.arange(h_) + 0.5) / h_), -1).reshape(-1, 2)
+                          for h_, w_ in shapes], 0)
+    loc = h16(cen[None, :, None, None, None, :] + rng.standard_normal((1, S, 8, 5, 4, 2)) * 3.0 / shapes[None, None, None, :, None, ::-1])
+    wgt = rng.random((1, S, 8, 5, 4))
+    wgt = h16(wgt / wgt.sum((-1, -2), keepdims=True))
+    assert _cabi.load().codetr_msda_op4_supported(2, 1, S, 8, 32, 5, S, 4) == 1
+    out2 = torch.ops.codetr.multi_scale_deformable_attention(
+        torch.as_tensor(value).to(dev).half(), torch.as_tensor(shapes).to(dev), torch.as_tensor(ls).to(dev),
+        torch.as_tensor(loc).to(dev).half(), torch.as_tensor(wgt).to(dev).half(), 64)
+    ref2 = O.msda_forward_c(value, shapes, ls, loc, wgt, dtype=np.float64)
+    np.testing.assert_allclose(out2.float().cpu().numpy(), ref2, rtol=1.1 * 2.0 ** -10, atol=2e-6)
+    print("[smoke] MSDA windowed kernel (encoder shape, Nq = S = %d) matches the oracle to one fp16 ulp:" % S,
+          float(np.abs(out2.float().cpu().numpy() - ref2).max()))
 
     from test_model_gpu import _tiny_codetr_cfg
 
