@@ -697,8 +697,353 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   M4_T(k2);
   m4_s[15] = m4_tk1 - m4_tk0;   // prologue (geometry, operand loads, softmax)
   m4_s[16] = m4_tk2 - m4_tk0;   // whole workgroup
+  m4_s[17] = m4_tk0;            // start stamp (for the launch's span)
+  m4_s[18] = m4_tk2;
   if (tid == 0 && g_msda4_stamps)
     for (int i = 0; i < 20; ++i) g_msda4_stamps[(size_t)blockIdx.x * 20 + i] = m4_s[i];
+#endif
+}
+
+// ---- round-6 persistent form ("v5"): ONE 1024-thread workgroup per CU, windows double-buffered -----------------------
+// What the stamps of the kernel above show (tools/msda4_stamps.py, profiles/r06_msda_encoder_stamps.txt): a workgroup spends
+// a third of its life staging -- the DMA instructions of a pass stall at issue while the CU takes their data in at ~20 B/clk,
+// then the workgroup waits for the last of them and for its slowest wave -- and none of that overlaps its OWN gather; the
+// other workgroup of the CU hides a third of it.  Here the staging of the next pass (and, during the last pass of a tile,
+// the first pass of the NEXT tile together with that tile's operand rows) is issued before the gather of the current one
+// into the other of two window buffers, so that a pass boundary costs one barrier; the workgroup is persistent and walks
+// the tiles of its XCD's share.  Same gather, preparation and fix-up code as above.
+constexpr int kIt5 = 2;       // iterations per wave: 2 x 256 pairs = the 512 queries of a 24 x 16 region's pyramid share
+
+// the 40 divisions of a tile's geometry, one per lane (lane 8 l + j: item j of level l; see the kernel above)
+__device__ __forceinline__ int tile_res(const Geom4& g, const TileId& t, int lane) {
+  const int gl = lane >> 3 > kL - 1 ? kL - 1 : lane >> 3, gj = lane & 7;
+  int nW = g.W[0], nH = g.H[0], wword = 0;
+  const int mw = t.m < kMaxM ? t.m : kMaxM - 1;
+#pragma unroll
+  for (int l = 0; l < kL; ++l) {
+    int ww;
+    __builtin_memcpy(&ww, g.win[mw][l], 4);
+    nW = gl == l ? g.W[l] : nW;
+    nH = gl == l ? g.H[l] : nH;
+    wword = gl == l ? ww : wword;
+  }
+  const bool ay = (gj & 2) != 0, isq = gj >= 4, plus = (gj & 1) != 0;
+  const int n = ay ? nH : nW, R = ay ? g.RY : g.RX, rr = (ay ? t.ry : t.rx) + (plus ? 1 : 0);
+  const int wv = (int)(signed char)((unsigned)wword >> (8 * (gj & 3)));
+  const int num = 2 * rr * n + (isq ? R - 1 : 2 * wv * R - R);
+  const int numd = (!isq && plus) ? num + 2 * R - 1 : num;
+  const int q = fdiv(numd > 0 ? numd : 0, 2 * R);
+  return isq ? q : plus ? (num <= 0 ? 0 : (q > n ? n : q)) : (num < 0 ? -1 : (q > n - 1 ? n - 1 : q));
+}
+
+// scalar geometry of a tile from its division results; pass k of the tile is staged in buffer (p0 + k) & 1
+__device__ __forceinline__ int build_lv(const Geom4& g, const TileId& t, int res, unsigned lds0, unsigned buf_bytes, int p0,
+                                        Lv (&lv)[kL]) {
+  constexpr unsigned kRow = 64;
+  int slot = 0;
+  unsigned base = lds0;
+#pragma unroll
+  for (int l = 0; l < kL; ++l) {
+    Lv& v = lv[l];
+    v.W = g.W[l];
+    v.H = g.H[l];
+    v.start = g.start[l];
+    v.px0 = __builtin_amdgcn_readlane(res, 8 * l + 0);
+    int px1 = __builtin_amdgcn_readlane(res, 8 * l + 1);
+    v.py0 = __builtin_amdgcn_readlane(res, 8 * l + 2);
+    int py1 = __builtin_amdgcn_readlane(res, 8 * l + 3);
+    px1 = px1 < v.px0 + 1 ? v.px0 + 1 : px1;
+    py1 = py1 < v.py0 + 1 ? v.py0 + 1 : py1;
+    v.pw = px1 - v.px0 + 1;
+    v.ph = py1 - v.py0 + 1;
+    v.xspan = v.pw - 2;
+    v.yspan = v.ph - 2;
+    v.pitch = (unsigned)v.pw * kRow;
+    if (g.first[l] == l) {   // a new pass starts at the front of its buffer
+      const int k = l == 0 ? 0 : l == 1 ? 1 : 2;
+      base = lds0 + (((p0 + k) & 1) ? buf_bytes : 0u);
+    }
+    v.base = base;
+    base += (unsigned)(v.pw * v.ph) * kRow;
+    const float* vc = g.vcounts + ((size_t)t.b * kL + l) * 2;
+    v.vcx = unif(vc[0]);
+    v.vcy = unif(vc[1]);
+    v.qx0 = __builtin_amdgcn_readlane(res, 8 * l + 4);
+    v.qy0 = __builtin_amdgcn_readlane(res, 8 * l + 6);
+    v.qw = __builtin_amdgcn_readlane(res, 8 * l + 5) - v.qx0;
+    const int qh = __builtin_amdgcn_readlane(res, 8 * l + 7) - v.qy0;
+    v.slot0 = slot;
+    slot += v.qw * qh;
+  }
+  return slot;
+}
+
+// the windows of levels [LV0, LV0 + NLV) -> LDS, row-wise (see the kernel above), rows shared out over KW waves
+template <int LV0, int NLV, int KW>
+__device__ __forceinline__ void stage_pass(const Lv (&lv)[kL], const unsigned char* __restrict__ vhead0, unsigned pix_bytes,
+                                           unsigned char* smem, unsigned lds0, int wave, int lane) {
+  constexpr unsigned kRow = 64;
+  const int sub = lane & 3;
+#pragma unroll
+  for (int i = 0; i < NLV; ++i) {
+    const Lv& v = lv[LV0 + i];
+    const int px_l = lane >> 2;
+    const unsigned voff = (unsigned)px_l * pix_bytes + (unsigned)sub * 16;
+    const int chunks = (v.pw + 15) >> 4;
+    for (int y = wave; y < ((kAbl & 2) ? 0 : v.ph); y += KW) {
+      const int gy = v.py0 + y;
+      const bool row_in = (unsigned)gy < (unsigned)v.H;
+      for (int c = 0; c < chunks; ++c) {
+        const int x0 = 16 * c;
+        const unsigned dst = (v.base - lds0) + (unsigned)(y * v.pw + x0) * kRow;
+        const int gx = v.px0 + x0 + px_l;
+        const bool mine = x0 + px_l < v.pw;
+        const bool col_in = (unsigned)gx < (unsigned)v.W;
+        if (row_in) {
+          if (mine && col_in)
+            lds_dma16(vhead0 + (ptrdiff_t)(v.start + gy * v.W + v.px0 + x0) * (ptrdiff_t)pix_bytes, voff, lds0 + dst);
+          if (mine && !col_in) *reinterpret_cast<u32x4*>(smem + dst + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        } else if (mine) {
+          *reinterpret_cast<u32x4*>(smem + dst + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  }
+}
+
+struct Q5 {   // a wave's queries of one tile: flattened index, reference-point numerators, raw operand rows
+  int qs[kIt5];
+  float bx[kIt5], by[kIt5];
+  u32x4 rawA[kIt5], rawB[kIt5];
+};
+
+// slot -> (level, pixel) -> flattened query index, centre / valid count; the operand rows are requested
+__device__ __forceinline__ void tile_queries(const Lv (&lv)[kL], int total, int wave, int lane, const unsigned char* prow,
+                                             int packed_stride, Q5& q) {
+  const int pl = lane >> 2;
+  int tS0 = 0, tA = 0, tB = 0, tSt = 0;
+  float tRx = 0.f, tRy = 0.f;
+#pragma unroll
+  for (int l = 0; l < kL; ++l) {
+    const bool me = lane == l;
+    tS0 = me ? lv[l].slot0 : tS0;
+    tA = me ? (lv[l].qx0 | (lv[l].qy0 << 16)) : tA;
+    tB = me ? (lv[l].W | (lv[l].qw << 16)) : tB;
+    tSt = me ? lv[l].start : tSt;
+    tRx = me ? lv[l].vcx : tRx;
+    tRy = me ? lv[l].vcy : tRy;
+  }
+  tRx = __builtin_amdgcn_rcpf(tRx);
+  tRy = __builtin_amdgcn_rcpf(tRy);
+  const int n_it = total > wave * 16 ? (total - wave * 16 + 255) / 256 : 0;
+#pragma unroll
+  for (int it = 0; it < kIt5; ++it) {
+    q.qs[it] = 0;
+    q.bx[it] = q.by[it] = 0.f;
+    q.rawA[it] = q.rawB[it] = u32x4{0u, 0u, 0u, 0u};
+    if (it < n_it) {
+      int sl = (it * 16 + wave) * 16 + pl;
+      sl = sl < total ? sl : total - 1;
+      int lvq = 0;
+#pragma unroll
+      for (int l = 1; l < kL; ++l) lvq += sl >= lv[l].slot0 ? 4 : 0;
+      const int s0 = __builtin_amdgcn_ds_bpermute(lvq, tS0), cA = __builtin_amdgcn_ds_bpermute(lvq, tA);
+      const int cB = __builtin_amdgcn_ds_bpermute(lvq, tB), st = __builtin_amdgcn_ds_bpermute(lvq, tSt);
+      const float rx_ = __int_as_float(__builtin_amdgcn_ds_bpermute(lvq, __float_as_int(tRx)));
+      const float ry_ = __int_as_float(__builtin_amdgcn_ds_bpermute(lvq, __float_as_int(tRy)));
+      const int tq = sl - s0, qw = cB >> 16, W = cB & 0xffff;
+      const int yy = (int)(((float)tq + 0.5f) * __builtin_amdgcn_rcpf((float)qw));
+      const int y = (cA >> 16) + yy, x = (cA & 0xffff) + (tq - yy * qw);
+      q.qs[it] = st + y * W + x;
+      q.bx[it] = ((float)x + 0.5f) * rx_;
+      q.by[it] = ((float)y + 0.5f) * ry_;
+      const unsigned char* pr = prow + (size_t)((unsigned)q.qs[it] * (unsigned)packed_stride) * 2;
+      q.rawA[it] = *reinterpret_cast<const u32x4*>(pr);
+      q.rawB[it] = *reinterpret_cast<const u32x4*>(pr + 16);
+    }
+  }
+}
+
+// LDS: [window buffer 0 | window buffer 1 | fix-up queues]
+template <class ET>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_encoder_v5_kernel(
+    const _Float16* __restrict__ value, const unsigned short* __restrict__ packed, unsigned short* __restrict__ out,
+    const Geom4 g, const int packed_stride, const int ntiles) {
+  constexpr unsigned kRow = 64;
+  constexpr int kWaves = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  const int tid = threadIdx.x;
+  const int wave = uni(tid >> 6), lane = tid & 63, sub = lane & 3, pl = lane >> 2;
+  const int M = g.M;
+  const unsigned pix_bytes = g.head_major ? kRow : (unsigned)M * kRow;
+  const unsigned buf_bytes = g.queue_off >> 1;
+  u32x4* queue = reinterpret_cast<u32x4*>(smem + g.queue_off) + (size_t)(wave * 16 + pl) * kQ;
+  const unsigned lds_lane = (unsigned)sub * 16;
+
+  // this workgroup's tiles: XCD x = blockIdx & 7 owns a contiguous share of the tile list (neighbouring regions and the
+  // eight heads of a region meet in one L2), its workgroups walk it round-robin
+  const unsigned xcd = blockIdx.x & 7u, per = gridDim.x >> 3;
+  const unsigned tq_ = (unsigned)ntiles >> 3, tr_ = (unsigned)ntiles & 7u;
+  const unsigned first = xcd < tr_ ? xcd * (tq_ + 1) : tr_ * (tq_ + 1) + (xcd - tr_) * tq_;
+  const unsigned count = tq_ + (xcd < tr_ ? 1u : 0u);
+  unsigned k = blockIdx.x >> 3;
+  if (k >= count) return;
+
+  auto tile_of = [&](unsigned kk) {
+    const TileId t0 = decode_tile(first + kk, g);
+    return TileId{uni(t0.b), uni(t0.rx), uni(t0.ry), uni(t0.m)};
+  };
+  auto head_base = [&](const TileId& t) {
+    return reinterpret_cast<const unsigned char*>(value) +
+           (g.head_major ? ((size_t)t.b * M + t.m) * g.S : (size_t)t.b * g.S * M + t.m) * kRow;
+  };
+  auto packed_row = [&](const TileId& t) {
+    return reinterpret_cast<const unsigned char*>(packed) + (size_t)t.b * g.S * packed_stride * 2 + (t.m * 64 + sub * 16) * 2;
+  };
+
+#ifdef MSDA4_STAMPS
+  unsigned long long m5[20];
+  for (int i = 0; i < 20; ++i) m5[i] = 0;
+  const unsigned long long m5_k0 = __builtin_readcyclecounter();
+#define M5_T(i) const unsigned long long m5_t##i = __builtin_readcyclecounter()
+#define M5_ACC(k, a, b) m5[k] += m5_t##b - m5_t##a
+#else
+#define M5_T(i)
+#define M5_ACC(k, a, b)
+#endif
+  // ---- first tile: geometry, operand rows, first pass on its way ----
+  int p0 = 0;
+  TileId t = tile_of(k);
+  Q5 q;
+  {
+    Lv lv0[kL];
+    const int total0 = build_lv(g, t, tile_res(g, t, lane), lds0, buf_bytes, p0, lv0);
+    tile_queries(lv0, total0, wave, lane, packed_row(t), packed_stride, q);
+    stage_pass<0, 1, kWaves>(lv0, head_base(t), pix_bytes, smem, lds0, wave, lane);
+  }
+
+  for (;;) {
+    M5_T(0);
+    Lv lv[kL];
+    const int total = build_lv(g, t, tile_res(g, t, lane), lds0, buf_bytes, p0, lv);
+    const int n_it = total > wave * 16 ? (total - wave * 16 + 255) / 256 : 0;
+    const unsigned char* vhead0 = head_base(t);
+    const unsigned char* vhead = vhead0 + sub * 16;
+
+    // ---- softmax over the pair's 20 logits; the offsets stay packed ----
+    float aw[kIt5][kL], acc[kIt5][8];
+    unsigned o2[kIt5][kL];
+    int qs[kIt5];
+    float bx[kIt5], by[kIt5];
+#pragma unroll
+    for (int it = 0; it < kIt5; ++it) {
+      qs[it] = q.qs[it];
+      bx[it] = q.bx[it];
+      by[it] = q.by[it];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[it][j] = 0.f;
+      o2[it][0] = q.rawA[it][0];
+      o2[it][1] = q.rawA[it][1];
+      o2[it][2] = q.rawA[it][2];
+      o2[it][3] = q.rawA[it][3];
+      o2[it][4] = q.rawB[it][0];
+      const float lg[kL] = {ET::lo(q.rawB[it][1]), ET::hi(q.rawB[it][1]), ET::lo(q.rawB[it][2]), ET::hi(q.rawB[it][2]),
+                            ET::lo(q.rawB[it][3])};
+      float mx = lg[0];
+#pragma unroll
+      for (int kk = 1; kk < kL; ++kk) mx = fmaxf(mx, lg[kk]);
+      mx = fmaxf(mx, dpp_f<kXor2>(mx));
+      mx = fmaxf(mx, dpp_f<kXor1>(mx));
+      float sum = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < kL; ++kk) {
+        aw[it][kk] = __expf(lg[kk] - mx);
+        sum += aw[it][kk];
+      }
+      sum += dpp_f<kXor2>(sum);
+      sum += dpp_f<kXor1>(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int kk = 0; kk < kL; ++kk) aw[it][kk] *= inv;
+    }
+
+    auto gather_pass = [&](auto lv0_c, auto nlv_c) {
+      constexpr int LV0 = decltype(lv0_c)::value, NLV = decltype(nlv_c)::value;
+#pragma unroll
+      for (int it = 0; it < kIt5; ++it)
+        if (it < n_it && !(kAbl & 4)) {
+          Prep pp[NLV];
+#pragma unroll
+          for (int i = 0; i < NLV; ++i) pp[i] = Prep{lv[LV0 + i].base, 0u, 0u};
+          bool clean = true;
+          if (!(kAbl & 8)) {
+            const bool ok = prepare<ET, LV0, NLV>(pp, lv, aw[it], o2[it], bx[it], by[it]);
+            clean = __builtin_amdgcn_ballot_w64(!ok) == 0;
+          }
+          gather<LV0, NLV>(acc[it], pp, lv, lds_lane);
+          if (!clean) fixup<ET, LV0, NLV>(acc[it], lv, aw[it], o2[it], bx[it], by[it], queue, vhead, pix_bytes, sub);
+        }
+    };
+    auto landed = [&]() {   // my DMA has landed; behind the barrier everybody's has, and everybody is done with the other buffer
+      if (!(kAbl & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(kAbl & 16)) __syncthreads();
+    };
+
+    M5_T(1);
+    landed();                                                                    // pass 0 of this tile
+    M5_T(2);
+    stage_pass<1, 2, kWaves>(lv, vhead0, pix_bytes, smem, lds0, wave, lane);     // -> the other buffer
+    M5_T(3);
+    gather_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    M5_T(4);
+    landed();
+    M5_T(5);
+    stage_pass<3, 2, kWaves>(lv, vhead0, pix_bytes, smem, lds0, wave, lane);     // -> pass 0's buffer
+    M5_T(6);
+    gather_pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    M5_T(7);
+    landed();
+    M5_T(8);
+    // the next tile: geometry, operand rows, first pass -> the buffer pass 1 has left
+    const unsigned kn = k + per;
+    const bool more = kn < count;   // (uniform)
+    TileId tn = t;
+    if (more) {
+      tn = tile_of(kn);
+      Lv lvn[kL];
+      const int totaln = build_lv(g, tn, tile_res(g, tn, lane), lds0, buf_bytes, p0 ^ 1, lvn);
+      tile_queries(lvn, totaln, wave, lane, packed_row(tn), packed_stride, q);
+      stage_pass<0, 1, kWaves>(lvn, head_base(tn), pix_bytes, smem, lds0, wave, lane);
+    }
+    M5_T(9);
+    gather_pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+    M5_T(10);
+
+    unsigned char* orow = reinterpret_cast<unsigned char*>(out) + ((size_t)t.b * g.S * M + t.m) * kRow + sub * 16;
+#pragma unroll
+    for (int it = 0; it < kIt5; ++it)
+      if (it < n_it && (it * kWaves + wave) * 16 + pl < total) {
+        const u32x4 o = ET::pack8(acc[it]);
+        if (!(kAbl & 32) || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(orow + (size_t)((unsigned)qs[it] * ((unsigned)M * kRow))) = o;
+      }
+    M5_T(11);
+    // 0: geometry + softmax, 1-3: landed (wait + barrier) of passes 0-2, 4-5: staging issue of passes 1, 2, 6: next tile (geometry,
+    // operand rows, pass-0 issue), 7-9: gathers, 10: output, 11: tiles
+    M5_ACC(0, 0, 1); M5_ACC(1, 1, 2); M5_ACC(4, 2, 3); M5_ACC(7, 3, 4); M5_ACC(2, 4, 5); M5_ACC(5, 5, 6); M5_ACC(8, 6, 7);
+    M5_ACC(3, 7, 8); M5_ACC(6, 8, 9); M5_ACC(9, 9, 10); M5_ACC(10, 10, 11);
+#ifdef MSDA4_STAMPS
+    m5[11] += 1;
+#endif
+    if (!more) break;
+    k = kn;
+    t = tn;
+    p0 ^= 1;
+  }
+#ifdef MSDA4_STAMPS
+  m5[12] = __builtin_readcyclecounter() - m5_k0;
+  if (tid == 0 && g_msda4_stamps)
+    for (int i = 0; i < 20; ++i) g_msda4_stamps[(size_t)blockIdx.x * 20 + i] = m5[i];
 #endif
 }
 
@@ -719,7 +1064,7 @@ inline Plan4 plan4(const int64_t* shapes, int64_t S, int M, int L, int P, const 
   pl.rc = CODETR_E_BADARG;
   if (!shapes || !win || M <= 0 || L <= 0 || P <= 0 || region_w <= 0 || region_h <= 0) return pl;
   pl.rc = CODETR_E_UNSUPPORTED;
-  if (L != kL || P != kP || (threads != 256 && threads != 512)) return pl;
+  if (L != kL || P != kP || (threads != 256 && threads != 512 && threads != 1024)) return pl;
   g.M = M;
   g.S = (int)S;
   int64_t sum = 0;
@@ -779,8 +1124,9 @@ inline Plan4 plan4(const int64_t* shapes, int64_t S, int M, int L, int P, const 
     }
   }
   pl.slots_cap = slots;
-  g.queue_off = (unsigned)rows_cap * 64u;
-  pl.lds = (size_t)rows_cap * 64 + (size_t)(threads / 4) * kQ * 16;
+  const int buffers = threads == 1024 ? 2 : 1;   // the persistent form double-buffers the windows
+  g.queue_off = (unsigned)(buffers * rows_cap) * 64u;
+  pl.lds = (size_t)buffers * rows_cap * 64 + (size_t)(threads / 4) * kQ * 16;
   pl.rc = 0;
   return pl;
 }
@@ -797,7 +1143,7 @@ int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void
     return CODETR_E_BADARG;
   Plan4 pl = plan4(shapes, S, M, L, P, win, region_w, region_h, threads);
   if (pl.rc != 0) return pl.rc;
-  if (pl.slots_cap > (threads / 4) * kMaxIt || pl.lds > (size_t)kMaxLds) return CODETR_E_UNSUPPORTED;
+  if (pl.slots_cap > (threads / 4) * (threads == 1024 ? kIt5 : kMaxIt) || pl.lds > (size_t)kMaxLds) return CODETR_E_UNSUPPORTED;
   if (S * M * (int64_t)64 > 0xffffffffLL || S * packed_stride * 2 > 0xffffffffLL) return CODETR_E_TOO_LARGE;   // 32-bit in-image offsets
   const int64_t blocks = B * pl.g.RX * pl.g.RY * M;
   if (blocks >= (1 << 22)) return CODETR_E_UNSUPPORTED;
@@ -805,19 +1151,30 @@ int launch4(hipStream_t st, const void* value, const int64_t* shapes, const void
   pl.g.head_major = head_major ? 1 : 0;
   typedef void (*Kern)(const _Float16*, const unsigned short*, unsigned short*, const Geom4, const int);
   const Kern kern = threads == 512 ? msda_encoder_v4_kernel<ET, 512> : msda_encoder_v4_kernel<ET, 256>;
+  const void* kfn = threads == 1024 ? reinterpret_cast<const void*>(msda_encoder_v5_kernel<ET>) : reinterpret_cast<const void*>(kern);
   {
     static std::atomic<uint32_t> done[64];   // > 64 KB of dynamic LDS: the attribute is per (device, function); one table per ET
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, done[0].store(0);
-    const uint32_t bit = threads == 512 ? 2u : 1u;
+    const uint32_t bit = threads == 1024 ? 4u : threads == 512 ? 2u : 1u;
     if (!(done[dev].load(std::memory_order_acquire) & bit)) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+      const hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
       if (e != hipSuccess) return (int)e;
       done[dev].fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)threads), pl.lds, st, static_cast<const _Float16*>(value),
-                     static_cast<const unsigned short*>(packed), static_cast<unsigned short*>(out), pl.g, (int)packed_stride);
+  if (threads == 1024) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+      cus = 256;
+    const unsigned grid = (unsigned)(cus / 8 * 8);   // one persistent workgroup per CU, a multiple of the 8 XCDs
+    hipLaunchKernelGGL(msda_encoder_v5_kernel<ET>, dim3(grid), dim3(1024), pl.lds, st, static_cast<const _Float16*>(value),
+                       static_cast<const unsigned short*>(packed), static_cast<unsigned short*>(out), pl.g, (int)packed_stride,
+                       (int)blocks);
+  } else {
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)threads), pl.lds, st, static_cast<const _Float16*>(value),
+                       static_cast<const unsigned short*>(packed), static_cast<unsigned short*>(out), pl.g, (int)packed_stride);
+  }
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;
 }
@@ -851,7 +1208,7 @@ int64_t codetr_msda_encoder_packed_lds_bytes(const int64_t* level_shapes_host, i
   for (int l = 0; l < L; ++l) S += level_shapes_host[2 * l] * level_shapes_host[2 * l + 1];
   const Plan4 pl = plan4(level_shapes_host, S, M, L, P, reinterpret_cast<const signed char*>(windows_host), region_w, region_h, threads);
   if (pl.rc != 0) return pl.rc;
-  if (pl.slots_cap > (threads / 4) * kMaxIt) return CODETR_E_UNSUPPORTED;
+  if (pl.slots_cap > (threads / 4) * (threads == 1024 ? kIt5 : kMaxIt)) return CODETR_E_UNSUPPORTED;
   return (int64_t)pl.lds;
 }
 
