@@ -34,7 +34,6 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kChunkBytes = 24576;   // one chunk of W1 or of W2 for both supported widths
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -81,9 +80,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// C = 192: BH = 64, C = 384: BH = 32
-template <class ET, int C>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void swin_mlp_kernel(
+// C = 192: BH = 64, C = 384: BH = 32, one workgroup per CU (WPE = 1); C = 192 also as BH = 32 with TWO workgroups per CU
+// (WPE = 2: 12 KiB chunks, 256 registers per wave -- the second wave of a SIMD runs its MFMAs under this one's GELU)
+template <class ET, int C, int BH, int WPE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void swin_mlp_kernel(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ ln_g, const unsigned short* __restrict__ ln_b,
     const float ln_eps, const unsigned short* __restrict__ W1, const unsigned short* __restrict__ b1,
     const unsigned short* __restrict__ W2p, const unsigned short* __restrict__ b2, unsigned short* __restrict__ Y, const int M,
@@ -91,7 +91,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   using E = typename ET::e;
   using V8 = typename ET::v8;
   using V4 = typename ET::v4;
-  constexpr int BH = C == 192 ? 64 : 32;      // hidden units per chunk
   constexpr int Hd = 4 * C, NCHUNK = Hd / BH; // 12 / 48 chunks
   constexpr int KS = C / 32;                  // k-steps of the first product: 6 / 12
   constexpr int HT = BH / 16;                 // h-tiles of a chunk: 4 / 2
@@ -101,7 +100,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   constexpr int RB1 = 2 * C;                  // bytes of a W1 row
   constexpr int RB2 = 2 * BH;                 // bytes of a staged W2 row: 128 / 64
   constexpr int MT = 2, WR = 32, TR = 128;    // m-tiles per wave, rows per wave / workgroup
-  static_assert(BH * RB1 == kChunkBytes && C * RB2 == kChunkBytes, "chunk geometry");
+  constexpr int kChunkBytes = BH * RB1;       // one chunk of W1 = one chunk of W2: 24 KiB (12 KiB in the WPE = 2 form)
+  constexpr int NP = kChunkBytes / (kThreads * 16);   // LDS-DMA pieces of a chunk and operand: 6 / 3
+  static_assert(C * RB2 == kChunkBytes && NP * kThreads * 16 == kChunkBytes && KS % NP == 0 && (NT / 2) % NP == 0, "chunk geometry");
   // [W1 stage 0 | W1 stage 1 | W2 stage 0 | W2 stage 1 | b1 | b2]: 96 KiB + 3.75 KiB
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kChunkBytes + Hd * 2 + C * 2];
   unsigned char* const ringA = lds;
@@ -116,9 +117,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   // ---- LDS-DMA geometry: 6 pieces of 256 x 16 B per chunk and operand ----
   // W1 chunk [BH rows][NCH positions]: linear 16-byte index L = 256 p + tid -> row L / NCH, position L % NCH, which holds
   // source chunk (position - s(row)) mod NCH
-  unsigned w1_voff[6], w2_voff[6];
+  unsigned w1_voff[NP], w2_voff[NP];
 #pragma unroll
-  for (int p = 0; p < 6; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int Lx = 256 * p + tid;
     const int r = Lx / NCH, pos = Lx - r * NCH;
     const int s = C == 192 ? (r >> 1) & 7 : r & 15;
@@ -148,9 +149,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     dma16(W2b + (size_t)c * RB2, w2_voff[p], dst + (p * kThreads + wave * 64) * 16);
   };
 #pragma unroll
-  for (int p = 0; p < 6; ++p) stage_w1(p, 0, ringA);
+  for (int p = 0; p < NP; ++p) stage_w1(p, 0, ringA);
 #pragma unroll
-  for (int p = 0; p < 6; ++p) stage_w2(p, 0, ringB);
+  for (int p = 0; p < NP; ++p) stage_w2(p, 0, ringB);
 
   // biases -> LDS once per workgroup
   for (int i = tid; i < Hd / 8; i += kThreads) *reinterpret_cast<u32x4*>(sB1 + i * 8) = *reinterpret_cast<const u32x4*>(b1 + i * 8);
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS) read_w1(ks + 1, aw[(ks + 1) & 1]);
-        if (KS == 6 || (ks & 1) == 0) stage_w1(KS == 6 ? ks : ks >> 1, cn, nW1);
+        if ((ks * NP) % KS == 0) stage_w1(ks * NP / KS, cn, nW1);
 #pragma unroll
         for (int i = 0; i < HT * MT; ++i) hacc[i / MT][i % MT] = ET::mfma(aw[ks & 1][i / MT], xf[i % MT][ks], hacc[i / MT][i % MT]);
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
       for (int ntp = 0; ntp < NG; ++ntp) {
         if (ntp + 1 < NG) read_w2(ntp + 1, a2[(ntp + 1) & 1]);
-        if (overlap && (NT == 12 || (ntp & 1) == 0)) stage_w2(NT == 12 ? ntp : ntp >> 1, cs, nW2);
+        if (overlap && (ntp * NP) % NG == 0) stage_w2(ntp * NP / NG, cs, nW2);
 #pragma unroll
         for (int i = 0; i < 2 * KS2 * MT; ++i) {   // MFMA index i -> (t, s, mt)
           const int ts = i / MT, mt = i % MT, nt = 2 * ntp + ts / KS2;
@@ -323,20 +324,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
     for (int k = 0; k < NGELU; ++k) gelu_half(hacc, pfa, k >> 1, k & 1);
 #pragma unroll
-    for (int p = 0; p < 6; ++p) stage_w2(p, 0, ringB + (gc & 1) * kChunkBytes);
+    for (int p = 0; p < NP; ++p) stage_w2(p, 0, ringB + (gc & 1) * kChunkBytes);
     // ---- iterations 1 .. NCHUNK - 1, two per trip (the operand registers alternate statically) ----
     for (int c = 1; c < NCHUNK; c += 2) {
-      wait_vmcnt<6>();
+      wait_vmcnt<NP>();
       __builtin_amdgcn_s_barrier();   // T
       product1(c, hacc);
-      wait_vmcnt<6>();
+      wait_vmcnt<NP>();
       __builtin_amdgcn_s_barrier();   // M
       product2(c - 1, pfa, std::true_type{}, c, hacc, pfb);
       if (c + 1 < NCHUNK) {
-        wait_vmcnt<6>();
+        wait_vmcnt<NP>();
         __builtin_amdgcn_s_barrier();   // T
         product1(c + 1, hacc);
-        wait_vmcnt<6>();
+        wait_vmcnt<NP>();
         __builtin_amdgcn_s_barrier();   // M
         product2(c, pfb, std::true_type{}, c + 1, hacc, pfa);
       }
@@ -397,16 +398,21 @@ int launch_swin_mlp(void* stream, const void* x, const void* g, const void* b, f
        reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(w2p) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(y)) & 15)
     return CODETR_E_BADARG;
   const int ntiles = (int)((M + 127) / 128);
-  const int grid = ntiles < device_cus() ? ntiles : device_cus();
+#ifndef SWIN_MLP_192_WPE
+#define SWIN_MLP_192_WPE 2
+#endif
+  constexpr int kWpe192 = SWIN_MLP_192_WPE;   // workgroups per CU of the C = 192 form (2: 32-wide hidden chunks)
+  const int slots = device_cus() * (C == 192 ? kWpe192 : 1);
+  const int grid = ntiles < slots ? ntiles : slots;
   auto X = static_cast<const unsigned short*>(x);
-#define CODETR_SWIN_MLP(CC)                                                                                               \
-  hipLaunchKernelGGL((swin_mlp_kernel<ET, CC>), dim3((unsigned)grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), X,  \
+#define CODETR_SWIN_MLP(CC, BH, WPE)                                                                                      \
+  hipLaunchKernelGGL((swin_mlp_kernel<ET, CC, BH, WPE>), dim3((unsigned)grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), X,  \
                      static_cast<const unsigned short*>(g), static_cast<const unsigned short*>(b), eps,                   \
                      static_cast<const unsigned short*>(w1), static_cast<const unsigned short*>(b1),                       \
                      static_cast<const unsigned short*>(w2p), static_cast<const unsigned short*>(b2),                      \
                      static_cast<unsigned short*>(y), (int)M, ntiles)
-  if (C == 192) CODETR_SWIN_MLP(192);
-  else CODETR_SWIN_MLP(384);
+  if (C == 192) CODETR_SWIN_MLP(192, (kWpe192 == 2 ? 32 : 64), kWpe192);
+  else CODETR_SWIN_MLP(384, 32, 1);
 #undef CODETR_SWIN_MLP
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? 0 : (int)err;

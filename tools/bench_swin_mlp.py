@@ -29,7 +29,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=4)
     a = ap.parse_args()
-    from codetr import hip_ops
+    from codetr import _cabi, hip_ops
+
+    if os.environ.get("CODETR_LIB"):   # timing experiments: a diagnostic build of the library (tools/micro/build_variant.sh)
+        _cabi.LIB_PATH, _cabi._lib, _cabi._rec_lib = os.environ["CODETR_LIB"], None, None
 
     for C, tokens in ((192, 153600), (384, 38400)):
         M = tokens * a.images

@@ -11,7 +11,7 @@ base=$(basename $src .hip)
 MK=co-detr-tensorrt_amd/csrc
 HIPCC=$(make -s -C $MK print-hipcc)
 FLAGS="$(make -s -C $MK print-flags) -Ico-detr-tensorrt_amd/csrc"
-case $base in gemm_f16|gemm_sk|window_attention|decoder_layer|decoder_layer_bf16) FLAGS="$FLAGS $(make -s -C $MK print-vgprform)";; esac
+case $base in gemm_f16|gemm_sk|gemm_pp|window_attention|decoder_layer|decoder_layer_bf16) FLAGS="$FLAGS $(make -s -C $MK print-vgprform)";; esac
 OTHERS=$(ls $MK/_obj/*.o | grep -v "/$base.o" | grep -v amdgcn)
 $HIPCC $FLAGS $defs -c $MK/$base.hip -o tools/micro/_bin/${base}_$name.o
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o tools/micro/_bin/libcodetr_$name.so tools/micro/_bin/${base}_$name.o $OTHERS
