@@ -172,8 +172,8 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave retire in order; keep the compiler from reordering
 
   const int l15 = lane & 15, grp = lane >> 4;
-  const float scale_log2e = 0.17677669529663687f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e)
   const float log2e = 1.4426950408889634f;
+  const float scale = 0.17677669529663687f;   // head_dim^-0.5
   const E* bias_h = rel_bias + (size_t)head * N * N;
 
   // per-lane addresses that do not depend on the query tile
@@ -211,151 +211,179 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     }
   };
   const bool multi_region = g.shift > 0 && (wy == g.nWin / g.nWx - 1 || wx == g.nWx - 1);
-  QTile nxt;
-  load_qtile(0, nxt);
-#pragma unroll 1
-  for (int qt = 0; qt < NT; ++qt) {
-    const QTile cur = nxt;
-    if (qt + 1 < NT) load_qtile(qt + 1, nxt);
-    const bool q_in = cur.q_in;
-    const Tok<WS> tq = cur.tq;
-    const V8 qf = cur.qf;
-
-    // ---- S^T tiles: D[i = key][j = query] ----
-    f32x4 s[NT];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      const int row = kt * 16 + l15;
-      const V8 kf = *reinterpret_cast<const V8*>(ldsK + row * 64 + swz(row, grp) * 16);
-      s[kt] = ET::mfma(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f});
-    }
-    // ---- scale, bias, mask (all in the log2 domain), row max ----
-    // (Pre-multiplying the bias table by log2 e on the host -- one fma per score instead of mul + fma -- measured -2 %
-    // and loses the large-bias cases to f16 rounding of the scaled table: not done.)
-    // The shift mask costs ~3 of the ~12 VALU instructions per score, and this kernel is VALU-bound (two waves per
-    // SIMD, ~6 k instructions per problem): only windows on the last window row / column of a shifted block hold more
-    // than one region, everything else takes the mask-free instantiation (wave-uniform branch).
-    float mx = -INFINITY;
-    auto scores = [&](auto mask_tag) {
-      constexpr bool MASK = decltype(mask_tag)::value;
+  // Software pipeline over the query tiles: the score half of tile t + 1 (S^T MFMAs, scale / bias / mask, row max) and the
+  // probability half of tile t (exp, row sums, P.V, store) are two independent instruction streams in ONE basic block, so
+  // that with two waves per SIMD the MFMA / LDS / cross-lane latencies of one are covered by the vector work of the other
+  // (one tile per iteration: the waves wait on `s_waitcnt` for 48 % of their life and the vector pipe is 30 % active per wave, profiles/r06_window_attention.txt).  The shift-mask branch is hoisted out of the
+  // loop (wave-uniform), the prefetch index is clamped instead of guarded: no control flow inside an iteration.
+  auto run = [&](auto mask_c) {
+    auto stage1 = [&](const QTile& cur, f32x4 (&s)[NT], float& mx) {
+      const Tok<WS> tq = cur.tq;
+      const V8 qf = cur.qf;
+      // ---- S^T tiles: D[i = key][j = query] ----
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        const int key0 = kt * 16 + grp * 4;
-        const V4 bv = cur.bv[kt];
-        unsigned regk = 0;
-        if (MASK) regk = *reinterpret_cast<const unsigned*>(ldsR + key0);
+        const int row = kt * 16 + l15;
+        const V8 kf = *reinterpret_cast<const V8*>(ldsK + row * 64 + swz(row, grp) * 16);
+        s[kt] = ET::mfma(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+      // ---- scale, bias, mask, row max ----
+      // (Pre-multiplying the bias table by log2 e on the host -- one fma per score instead of mul + fma -- measured -2 %
+      // and loses the large-bias cases to f16 rounding of the scaled table: not done.)
+      // The shift mask costs ~3 of the ~12 VALU instructions per score, and this kernel is VALU-bound (two waves per
+      // SIMD, ~6 k instructions per problem): only windows on the last window row / column of a shifted block hold more
+      // than one region, everything else takes the mask-free instantiation (wave-uniform branch).
+      mx = -INFINITY;
+      auto scores = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // (bias * log2e + score * scale: the 16-bit bias goes into the fused multiply-add directly -- v_fma_mix_f32 --
-          // instead of a conversion, a multiply and an fma)
-          float v = fmaf((float)bv[r], log2e, s[kt][r] * scale_log2e);
-          if (MASK && (int)((regk >> (8 * r)) & 0xff) != tq.region) v -= 100.0f * log2e;
-          if ((N % 16 != 0) && key0 + r >= N) v = -INFINITY;
-          s[kt][r] = v;
-          mx = fmaxf(mx, v);
+        for (int kt = 0; kt < NT; ++kt) {
+          const int key0 = kt * 16 + grp * 4;
+          const V4 bv = cur.bv[kt];
+          unsigned regk = 0;
+          if (MASK) regk = *reinterpret_cast<const unsigned*>(ldsR + key0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // (bias * log2e + score * scale: the 16-bit bias goes into the fused multiply-add directly -- v_fma_mix_f32 --
+            // instead of a conversion, a multiply and an fma)
+            // natural-log domain here: ONE v_fma_mix_f32 per score (fp32 score x scale + the 16-bit bias); the log2 e factor
+            // rides in the fma in front of the exponential below (the separate loop multiplies first: one instruction more)
+            float v = fmaf(s[kt][r], scale, (float)bv[r]);
+            if (MASK && (int)((regk >> (8 * r)) & 0xff) != tq.region) v -= 100.0f;
+            if ((N % 16 != 0) && key0 + r >= N) v = -INFINITY;
+            s[kt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        }
+      };
+      scores(mask_c);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    };
+    auto stage2 = [&](const QTile& cur, f32x4 (&s)[NT], const float mx) {
+      const bool q_in = cur.q_in;
+      const Tok<WS> tq = cur.tq;
+      // ---- exp, row sum, pack P^T as MFMA B fragments ----
+      // The row sums come from the matrix pipe (8 % busy in this kernel, the vector pipe is the bound): one more MFMA per
+      // 32-key step with an all-ones A operand gives D[i][query] = sum over the keys of P^T[key][query] for every i -- the sum
+      // of exactly the rounded probabilities that multiply V, in this lane's own query column.  Replaces an add per score
+      // and two cross-lane reductions per query tile.
+      const float nmx = -mx * log2e;
+      V8 pf[KS];
+      V8 ones;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ones[e] = (E)1.0f;
+      f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int kt = 2 * ks + h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = 0.f;
+            if (kt < NT) p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], log2e, nmx));  // v_exp_f32; argument <= 0
+            pf[ks][h * 4 + r] = (E)p;
+          }
+        }
+        rs = ET::mfma(ones, pf[ks], rs);
+      }
+      const float sum = rs[0];
+      // ---- O^T = V^T . P^T : D[i = channel][j = query] ----
+      f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int chunk = dt * 2 + (tr_p >> 1);
+          const int row0 = (2 * ks) * 16 + grp * 4 + tr_q;
+          const int row1 = row0 + 16;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(ldsV + row0 * 64 + swz(row0, chunk) * 16 + (tr_p & 1) * 8));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(ldsV + row1 * 64 + swz(row1, chunk) * 16 + (tr_p & 1) * 8));
+          s16x8 vf8 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          V8 vf;
+          __builtin_memcpy(&vf, &vf8, 16);
+          o[dt] = ET::mfma(vf, pf[ks], o[dt]);
+        }
+      }
+      // ---- normalise and store: lane holds channels 16*dt + 4*grp + r of query l15 ----
+      if constexpr (OUT8 && OUTMX) {
+        // the 32 channels of (token, head) sit in the four lanes l15 + 16 grp: block maximum by two xor-shuffles (every
+        // lane takes part; the shuffles stay outside the validity branch)
+        const float inv = 1.0f / sum;
+        float f[2][4], amax = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            f[dt][r] = (float)(E)(o[dt][r] * inv);
+            amax = fmaxf(amax, fabsf(f[dt][r]));
+          }
+        amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        if (q_in && tq.valid) {
+          const unsigned sb = mx_e8m0(amax);
+          const float qs = mx_inv_scale(sb);
+          const size_t trow = (size_t)b * g.H * g.W + tq.token;
+          const size_t doff = trow * C + hoff + grp * 4;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            float q4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q4[r] = __builtin_amdgcn_fmed3f(f[dt][r] * qs, -448.0f, 448.0f);
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(q4[0], q4[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(q4[2], q4[3], w, true);
+            *reinterpret_cast<int*>(static_cast<unsigned char*>(out_v) + doff + dt * 16) = w;
+          }
+          if (grp == 0) out_scales[mx_index((int64_t)trow, head, mx_blocks128((int64_t)g.B * g.H * g.W))] = (unsigned char)sb;
+        }
+      } else if (q_in && tq.valid) {
+        const float inv = 1.0f / sum;
+        const size_t doff = ((size_t)b * g.H * g.W + tq.token) * C + hoff + grp * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          V4 ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = (E)(o[dt][r] * inv);
+          if constexpr (OUT8) {
+            float f[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[r] = __builtin_amdgcn_fmed3f((float)ov[r] * out_inv_scale, -448.0f, 448.0f);
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+            *reinterpret_cast<int*>(static_cast<unsigned char*>(out_v) + doff + dt * 16) = w;
+          } else {
+            *reinterpret_cast<V4*>(static_cast<E*>(out_v) + doff + dt * 16) = ov;
+          }
         }
       }
     };
-    if (multi_region) scores(std::true_type{});
-    else scores(std::false_type{});
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // ---- exp, row sum, pack P^T as MFMA B fragments ----
-    // The row sums come from the matrix pipe (8 % busy in this kernel, the vector pipe is the bound): one more MFMA per
-    // 32-key step with an all-ones A operand gives D[i][query] = sum over the keys of P^T[key][query] for every i -- the sum
-    // of exactly the rounded probabilities that multiply V, in this lane's own query column.  Replaces an add per score
-    // and two cross-lane reductions per query tile.
-    V8 pf[KS];
-    V8 ones;
+    QTile tA, tB;
+    load_qtile(0, tA);
+    load_qtile(NT > 1 ? 1 : 0, tB);
+    f32x4 sA[NT];
+    float mxA;
+    stage1(tA, sA, mxA);
+#pragma unroll 2
+    for (int qt = 0; qt < NT - 1; ++qt) {
+      QTile tC;
+      load_qtile(qt + 2 < NT ? qt + 2 : NT - 1, tC);
+      f32x4 sB[NT];
+      float mxB;
+      stage1(tB, sB, mxB);
+      stage2(tA, sA, mxA);
+      tA = tB;
+      tB = tC;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (E)1.0f;
-    f32x4 rs = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int kt = 2 * ks + h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float p = 0.f;
-          if (kt < NT) p = __builtin_amdgcn_exp2f(s[kt][r] - mx);  // v_exp_f32; argument <= 0
-          pf[ks][h * 4 + r] = (E)p;
-        }
-      }
-      rs = ET::mfma(ones, pf[ks], rs);
+      for (int kt = 0; kt < NT; ++kt) sA[kt] = sB[kt];
+      mxA = mxB;
     }
-    const float sum = rs[0];
-    // ---- O^T = V^T . P^T : D[i = channel][j = query] ----
-    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int chunk = dt * 2 + (tr_p >> 1);
-        const int row0 = (2 * ks) * 16 + grp * 4 + tr_q;
-        const int row1 = row0 + 16;
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(ldsV + row0 * 64 + swz(row0, chunk) * 16 + (tr_p & 1) * 8));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(ldsV + row1 * 64 + swz(row1, chunk) * 16 + (tr_p & 1) * 8));
-        s16x8 vf8 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        V8 vf;
-        __builtin_memcpy(&vf, &vf8, 16);
-        o[dt] = ET::mfma(vf, pf[ks], o[dt]);
-      }
-    }
-    // ---- normalise and store: lane holds channels 16*dt + 4*grp + r of query l15 ----
-    if constexpr (OUT8 && OUTMX) {
-      // the 32 channels of (token, head) sit in the four lanes l15 + 16 grp: block maximum by two xor-shuffles (every
-      // lane takes part; the shuffles stay outside the validity branch)
-      const float inv = 1.0f / sum;
-      float f[2][4], amax = 0.f;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          f[dt][r] = (float)(E)(o[dt][r] * inv);
-          amax = fmaxf(amax, fabsf(f[dt][r]));
-        }
-      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-      if (q_in && tq.valid) {
-        const unsigned sb = mx_e8m0(amax);
-        const float qs = mx_inv_scale(sb);
-        const size_t trow = (size_t)b * g.H * g.W + tq.token;
-        const size_t doff = trow * C + hoff + grp * 4;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          float q4[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) q4[r] = __builtin_amdgcn_fmed3f(f[dt][r] * qs, -448.0f, 448.0f);
-          int w = __builtin_amdgcn_cvt_pk_fp8_f32(q4[0], q4[1], 0, false);
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(q4[2], q4[3], w, true);
-          *reinterpret_cast<int*>(static_cast<unsigned char*>(out_v) + doff + dt * 16) = w;
-        }
-        if (grp == 0) out_scales[mx_index((int64_t)trow, head, mx_blocks128((int64_t)g.B * g.H * g.W))] = (unsigned char)sb;
-      }
-    } else if (q_in && tq.valid) {
-      const float inv = 1.0f / sum;
-      const size_t doff = ((size_t)b * g.H * g.W + tq.token) * C + hoff + grp * 4;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        V4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (E)(o[dt][r] * inv);
-        if constexpr (OUT8) {
-          float f[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) f[r] = __builtin_amdgcn_fmed3f((float)ov[r] * out_inv_scale, -448.0f, 448.0f);
-          int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
-          *reinterpret_cast<int*>(static_cast<unsigned char*>(out_v) + doff + dt * 16) = w;
-        } else {
-          *reinterpret_cast<V4*>(static_cast<E*>(out_v) + doff + dt * 16) = ov;
-        }
-      }
-    }
-  }
+    stage2(tA, sA, mxA);
+  };
+  if (multi_region) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 template <class ET, int WS, bool OUT8, bool OUTMX = false>
