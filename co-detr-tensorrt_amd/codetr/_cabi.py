@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 48
+ABI_VERSION = 49
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -146,6 +146,9 @@ SIGNATURES = {
                               _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp]),
     "codetr_window_attention_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
     "codetr_window_attention_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
+    "codetr_window_attention_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i64, _i64, _i32, _i32, _i32, _i32,
+                                          _i32, _i32, _i32]),
+    "codetr_window_attention_bias_index": (_i32, [_i32, _vp]),
     "codetr_window_attention_fp8out_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i64, _i64, _i32, _i32,
                                                   _i32, _i32]),
 }
@@ -582,28 +585,30 @@ def window_attention_supported(dtype, embed_dims, num_heads, window_size) -> boo
     return dtype in (torch.float16, torch.bfloat16) and embed_dims == num_heads * 32 and window_size in (4, 7, 8, 12)
 
 
+def window_attention_bias_index(window_size):
+    """source key of every position of a lane-order bias row (codetr_window_attention_bias_index), or None where the
+    window size has no lane order"""
+    idx = (ctypes.c_int32 * (window_size * window_size))()
+    rc = load().codetr_window_attention_bias_index(int(window_size), ctypes.cast(idx, ctypes.c_void_p))
+    if rc == E_UNSUPPORTED:
+        return None
+    check(rc, "codetr_window_attention_bias_index")
+    return list(idx)
+
+
 def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_size, shift, out_scale=None,
-                     out_scales=None):
+                     out_scales=None, bias_layout=0):
     """out: 16-bit like qkv, or (with out_scale, f16 qkv) torch.float8_e4m3fn = sat(f16(o) / out_scale), or (with
-    out_scales, a uint8 MX scale tensor) block-scaled e4m3"""
+    out_scales, a uint8 MX scale tensor) block-scaled e4m3.  bias_layout 1: rel_bias rows in the kernel's lane order
+    (window_attention_bias_index)."""
     CALLS["window_attention"] += 1
     lib = load()
-    if out_scales is not None:
-        rc = lib.codetr_window_attention_fp8mx_f16(current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(),
-                                                   rel_bias.data_ptr(), out.data_ptr(), out_scales.data_ptr(), B, H, W,
-                                                   num_heads, 32, window_size, shift)
-        check(rc, "codetr_window_attention_fp8mx_f16")
-        return out
-    if out_scale is not None:
-        rc = lib.codetr_window_attention_fp8out_f16(current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(),
-                                                    rel_bias.data_ptr(), out.data_ptr(), float(out_scale), B, H, W,
-                                                    num_heads, 32, window_size, shift)
-        check(rc, "codetr_window_attention_fp8out_f16")
-        return out
-    fn = lib.codetr_window_attention_bf16 if qkv.dtype == torch.bfloat16 else lib.codetr_window_attention_f16
-    rc = fn(current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(), rel_bias.data_ptr(), out.data_ptr(),
-            B, H, W, num_heads, 32, window_size, shift)
-    check(rc, "codetr_window_attention")
+    mode = 2 if out_scales is not None else 1 if out_scale is not None else 0
+    rc = lib.codetr_window_attention_ex(current_stream_ptr(qkv.device), qkv.data_ptr(), qkv_bias.data_ptr(), rel_bias.data_ptr(),
+                                        out.data_ptr(), out_scales.data_ptr() if out_scales is not None else None,
+                                        float(out_scale) if out_scale is not None else 1.0, B, H, W, num_heads, 32,
+                                        window_size, shift, 1 if qkv.dtype == torch.bfloat16 else 0, mode, int(bias_layout))
+    check(rc, "codetr_window_attention_ex")
     return out
 
 

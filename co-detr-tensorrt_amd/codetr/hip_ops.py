@@ -562,6 +562,23 @@ def swin_window_attention_supported(x, embed_dims, num_heads, window_size):
     return x.is_cuda and _cabi.window_attention_supported(x.dtype, embed_dims, num_heads, window_size)
 
 
+WINDOW_BIAS_LANE = True   # route switch (A/B): False = the kernel reads the [nH, N, N] table as the reference lays it out
+_LANE_INDEX = {}
+
+
+def _rel_bias_lane_order(rel_bias, window_size):
+    """rel_bias [nH, N, N] in the lane order of the window-attention kernel's score tiles (bias_layout 1 of
+    codetr_window_attention_ex; same values, rows permuted along the key axis), cached on the table tensor; None where the
+    window size has no lane order (7 x 7)."""
+    if window_size not in _LANE_INDEX:
+        _LANE_INDEX[window_size] = _cabi.window_attention_bias_index(window_size)
+    idx = _LANE_INDEX[window_size]
+    if idx is None:
+        return None
+    return derived((rel_bias,), "_codetr_rel_bias_lane",
+                   lambda: rel_bias[..., torch.tensor(idx, dtype=torch.long, device=rel_bias.device)].contiguous())
+
+
 def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_size, shift, out_scale=None, out_mx=False):
     """Fused (shifted-)window attention on the UNPADDED spatial token map.
     qkv [B, H*W, 3C] (output of the qkv Linear on real tokens only), qkv_bias [3C] or None,
@@ -582,11 +599,13 @@ def swin_window_attention(qkv, qkv_bias, rel_bias, hw_shape, num_heads, window_s
         raise ValueError("the e4m3 output forms take fp16 qkv")
     out = torch.empty((B, L, C3 // 3), dtype=FP8 if (out_scale is not None or out_mx) else qkv.dtype, device=qkv.device)
     scales = torch.empty(_cabi.mx_scale_bytes(B * L, C3 // 3), dtype=torch.uint8, device=qkv.device) if out_mx else None
+    rel_bias = rel_bias.contiguous()
+    lane = _rel_bias_lane_order(rel_bias, window_size) if WINDOW_BIAS_LANE else None
     with torch.cuda.device(qkv.device):
         _timed("window_attention", {"rows": B * L, "C": C3 // 3, "heads": num_heads, "window": window_size,
                                     "out_bytes": out.element_size()},
-               lambda: _cabi.window_attention(qkv, qkv_bias, rel_bias.contiguous(), out, B, H, W, num_heads, window_size,
-                                              shift, out_scale, scales), qkv.device)
+               lambda: _cabi.window_attention(qkv, qkv_bias, rel_bias if lane is None else lane, out, B, H, W, num_heads,
+                                              window_size, shift, out_scale, scales, 0 if lane is None else 1), qkv.device)
     return (out, scales) if out_mx else out
 
 
@@ -709,7 +728,7 @@ MSDA_ENCODER = True     # False = general fused kernel in the encoder
 MSDA_FP32_REF = True    # False = reference points read in the model dtype
 
 
-_SWITCH_DEFAULTS = {"LINEAR_PP": True, "SWIN_MLP": True, "SWIN_MLP_MIN_ROWS": 32768, "LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
+_SWITCH_DEFAULTS = {"WINDOW_BIAS_LANE": True, "LINEAR_PP": True, "SWIN_MLP": True, "SWIN_MLP_MIN_ROWS": 32768, "LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
                     "MSDA_FP32_REF": True, "FP8_MIN_TILES": 96}
 
 

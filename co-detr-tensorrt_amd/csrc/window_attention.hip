@@ -102,7 +102,12 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // 16-bit -- what codetr_cast_fp8_f16 would make of the 16-bit output, without that tensor's round trip
 // OUTMX (with OUT8): block-scaled e4m3 instead -- one e8m0 byte per (token, head) = per 32 channels, written to `out_scales`
 // in the consumer GEMM's layout (mx_scale.h); out_inv_scale is unused
-template <class ET, int WS, bool OUT8 = false, bool OUTMX = false>
+// PB: the relative-position bias arrives in the LANE ORDER of the score tiles (codetr_window_attention_bias_index): row q of
+// head h holds, for lane group g, the keys 16 kt + 4 g + r of every key tile kt next to each other -- a lane's values of a
+// query tile are 8 NT contiguous bytes (72 for the 12 x 12 window: five loads, every line fetched once) instead of NT 8-byte
+// pieces 32 bytes apart (nine loads of sixteen 32-byte row segments each, and the L1 does not hold the rows between them:
+// -4 ... -12 % per launch, profiles/r06_window_attention.txt).  N % 16 == 0 only.
+template <class ET, int WS, bool OUT8 = false, bool OUTMX = false, bool PB = false>
 __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     const typename ET::e* __restrict__ qkv,       // [B, H*W, 3C]
     const typename ET::e* __restrict__ qkv_bias,  // [3C] (zeros if the layer has no bias)
@@ -195,6 +200,20 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
     T.tq = map_token<WS>(T.q_in ? qi : 0, wy, wx, g);
     const E* qsrc = (T.tq.valid ? qkv_b + (size_t)T.tq.token * row_elems : qkv_bias) + hoff + grp * 8;
     T.qf = *reinterpret_cast<const V8*>(qsrc);
+    if constexpr (PB) {
+      static_assert(!PB || N % 16 == 0, "lane-order bias: whole key tiles only");
+      typedef V8 __attribute__((aligned(4))) V8u;
+      typedef V4 __attribute__((aligned(4))) V4u;
+      const E* pb = bias_h + (size_t)qi * N + grp * (4 * NT);
+#pragma unroll
+      for (int j = 0; j < NT / 2; ++j) {
+        const V8 w = *reinterpret_cast<const V8u*>(pb + 8 * j);
+        T.bv[2 * j] = V4{w[0], w[1], w[2], w[3]};
+        T.bv[2 * j + 1] = V4{w[4], w[5], w[6], w[7]};
+      }
+      if constexpr (NT & 1) T.bv[NT - 1] = *reinterpret_cast<const V4u*>(pb + 4 * (NT - 1));
+      return;
+    }
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const int key0 = kt * 16 + grp * 4;
@@ -386,13 +405,13 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   else run(std::false_type{});
 }
 
-template <class ET, int WS, bool OUT8, bool OUTMX = false>
+template <class ET, int WS, bool OUT8, bool OUTMX = false, bool PB = false>
 int launch_ws(hipStream_t st, const void* qkv, const void* qkv_bias, const void* rel_bias, void* out, Geometry g,
               float out_inv_scale, unsigned char* out_scales = nullptr) {
   const int64_t n = (int64_t)g.B * g.nWin * g.nH;
   if (n > 0x7fffffffLL) return CODETR_E_TOO_LARGE;
   const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
-  hipLaunchKernelGGL((window_attention_kernel<ET, WS, OUT8, OUTMX>), dim3(blocks), dim3(kThreads), 0, st,
+  hipLaunchKernelGGL((window_attention_kernel<ET, WS, OUT8, OUTMX, PB>), dim3(blocks), dim3(kThreads), 0, st,
                      static_cast<const typename ET::e*>(qkv), static_cast<const typename ET::e*>(qkv_bias),
                      static_cast<const typename ET::e*>(rel_bias), out, g, (int)n, out_inv_scale, out_scales);
   const hipError_t err = hipGetLastError();
@@ -403,7 +422,7 @@ template <class ET, bool OUT8 = false, bool OUTMX = false>
 int window_attention_entry(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
                                 void* out_dev, int64_t B, int64_t H, int64_t W, int num_heads, int head_dim,
                                 int window_size, int shift, float out_inv_scale = 1.0f,
-                                unsigned char* out_scales = nullptr) {
+                                unsigned char* out_scales = nullptr, int bias_layout = 0) {
   if (!qkv_dev || !qkv_bias_dev || !rel_bias_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || num_heads <= 0)
     return CODETR_E_BADARG;
   if (head_dim != HD || shift < 0 || shift >= window_size) return CODETR_E_UNSUPPORTED;
@@ -419,6 +438,15 @@ int window_attention_entry(void* stream, const void* qkv_dev, const void* qkv_bi
   g.nWx = g.Wp / window_size;
   g.nWin = (g.Hp / window_size) * g.nWx;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (bias_layout == 1) {   // lane order: whole key tiles only
+    switch (window_size) {
+      case 12: return launch_ws<ET, 12, OUT8, OUTMX, true>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
+      case 8: return launch_ws<ET, 8, OUT8, OUTMX, true>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
+      case 4: return launch_ws<ET, 4, OUT8, OUTMX, true>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
+    }
+    return CODETR_E_UNSUPPORTED;
+  }
+  if (bias_layout != 0) return CODETR_E_BADARG;
   switch (window_size) {
     case 12: return launch_ws<ET, 12, OUT8, OUTMX>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
     case 8: return launch_ws<ET, 8, OUT8, OUTMX>(st, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, g, out_inv_scale, out_scales);
@@ -464,6 +492,50 @@ int codetr_window_attention_fp8out_f16(void* stream, const void* qkv_dev, const 
   if ((num_heads * (int64_t)head_dim) % 4 != 0 || (reinterpret_cast<uintptr_t>(out8_dev) & 3)) return CODETR_E_BADARG;
   return window_attention_entry<F16E, true>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out8_dev, B, H, W, num_heads,
                                             head_dim, window_size, shift, 1.0f / out_scale);
+}
+
+// One entry for every form above plus the bias layout (see include/codetr_hip.h).
+int codetr_window_attention_ex(void* stream, const void* qkv_dev, const void* qkv_bias_dev, const void* rel_bias_dev,
+                               void* out_dev, void* out_scales_dev, float out_scale, int64_t B, int64_t H, int64_t W,
+                               int num_heads, int head_dim, int window_size, int shift, int elem, int out_mode,
+                               int bias_layout) {
+  if (elem != 0 && elem != 1) return CODETR_E_BADARG;
+  if (out_mode == 0) {
+    if (elem == 1)
+      return window_attention_entry<BF16E>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, B, H, W, num_heads, head_dim,
+                                           window_size, shift, 1.0f, nullptr, bias_layout);
+    return window_attention_entry<F16E>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, B, H, W, num_heads, head_dim,
+                                        window_size, shift, 1.0f, nullptr, bias_layout);
+  }
+  if (elem != 0) return CODETR_E_UNSUPPORTED;   // the e4m3 outputs take fp16 qkv
+  if (out_mode == 1) {
+    if (!(out_scale > 0.f)) return CODETR_E_BADARG;
+    if ((num_heads * (int64_t)head_dim) % 4 != 0 || (reinterpret_cast<uintptr_t>(out_dev) & 3)) return CODETR_E_BADARG;
+    return window_attention_entry<F16E, true>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, B, H, W, num_heads,
+                                              head_dim, window_size, shift, 1.0f / out_scale, nullptr, bias_layout);
+  }
+  if (out_mode == 2) {
+    if (!out_scales_dev) return CODETR_E_BADARG;
+    if ((num_heads * (int64_t)head_dim) % 128 != 0 || (reinterpret_cast<uintptr_t>(out_dev) & 3)) return CODETR_E_UNSUPPORTED;
+    return window_attention_entry<F16E, true, true>(stream, qkv_dev, qkv_bias_dev, rel_bias_dev, out_dev, B, H, W, num_heads,
+                                                    head_dim, window_size, shift, 1.0f,
+                                                    static_cast<unsigned char*>(out_scales_dev), bias_layout);
+  }
+  return CODETR_E_BADARG;
+}
+
+// idx_host[j] (j < window_size^2) = the key whose bias sits at position j of a lane-order row: position 4 NT g + 4 kt + r
+// holds key 16 kt + 4 g + r (NT = window_size^2 / 16 key tiles).  Window sizes whose token count is not a multiple of 16 have
+// no lane-order form.
+int codetr_window_attention_bias_index(int window_size, int32_t* idx_host) {
+  if (!idx_host || window_size <= 0) return CODETR_E_BADARG;
+  const int N = window_size * window_size;
+  if (N % 16 != 0 || (window_size != 12 && window_size != 8 && window_size != 4)) return CODETR_E_UNSUPPORTED;
+  const int NT = N / 16;
+  for (int g = 0; g < 4; ++g)
+    for (int kt = 0; kt < NT; ++kt)
+      for (int r = 0; r < 4; ++r) idx_host[4 * NT * g + 4 * kt + r] = 16 * kt + 4 * g + r;
+  return 0;
 }
 
 }  // extern "C"

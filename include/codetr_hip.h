@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 48
+#define CODETR_HIP_ABI_VERSION 49
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -689,6 +689,24 @@ int codetr_window_attention_bf16(void *stream, const void *qkv_dev, const void *
 int codetr_window_attention_fp8out_f16(void *stream, const void *qkv_dev, const void *qkv_bias_dev,
                                        const void *rel_bias_dev, void *out8_dev, float out_scale, int64_t B,
                                        int64_t H, int64_t W, int num_heads, int head_dim, int window_size, int shift);
+/* Round 6: every form above through ONE entry, plus the layout of the relative-position bias.
+ *   elem        0: fp16 tensors, 1: bf16 (out_mode 0 only)
+ *   out_mode    0: 16-bit output (codetr_window_attention_f16 / _bf16); 1: e4m3 = sat(f16(o) / out_scale)
+ *               (codetr_window_attention_fp8out_f16); 2: e4m3 + MX block scales in out_scales_dev
+ *               (codetr_window_attention_fp8mx_f16).  out_scales_dev / out_scale are ignored by the modes that do not use them.
+ *   bias_layout 0: rel_bias_dev is the reference's gathered table [nH, N, N] (swin.py:92-112: table[index].view(N, N, nH)
+ *               permuted), as above; 1: the same values in the LANE ORDER of the kernel's score tiles -- row q of head h
+ *               holds at position j the bias of key idx[j], idx from codetr_window_attention_bias_index (window sizes 12,
+ *               8, 4: whole 16-key tiles).  A lane's values of a query tile are then contiguous (72 bytes for the 12 x 12
+ *               window: five loads instead of nine 8-byte pieces 32 bytes apart), results are bit-identical to layout 0,
+ *               launches 4-12 % shorter (profiles/r06_window_attention.txt).  The table is a per-layer constant: the host
+ *               permutes it once (codetr/swin.py: WindowMSA.relative_position_bias).
+ * codetr_window_attention_bias_index: idx_host[window_size^2]; CODETR_E_UNSUPPORTED for window sizes without the lane order. */
+int codetr_window_attention_ex(void *stream, const void *qkv_dev, const void *qkv_bias_dev, const void *rel_bias_dev,
+                               void *out_dev, void *out_scales_dev, float out_scale, int64_t B, int64_t H, int64_t W,
+                               int num_heads, int head_dim, int window_size, int shift, int elem, int out_mode,
+                               int bias_layout);
+int codetr_window_attention_bias_index(int window_size, int32_t *idx_host);
 
 /* ------------------------------------------------------------------------------------------
  * Dense multi-head softmax attention, head_dim 32: the core of nn.MultiheadAttention(256, 8) in the decoder's

@@ -98,6 +98,36 @@ def test_bf16(ws, shift, B, H, W, nH):
     _case(B, H, W, nH, ws, shift, seed=ws + H, dtype=torch.bfloat16)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("ws,shift,H,W,nH", [(12, 0, 24, 36, 2), (12, 6, 20, 31, 6), (8, 4, 17, 9, 2), (4, 2, 11, 15, 3), (4, 0, 8, 8, 2)])
+def test_lane_order_bias_is_bit_identical(ws, shift, H, W, nH, dtype):
+    """bias_layout 1 of codetr_window_attention_ex (the table permuted into the kernel's lane order, what the model
+    launches) against layout 0 (the reference's [nH, N, N]): same values through different loads -> the same bits; and
+    the index the permutation comes from"""
+    from codetr import _cabi, hip_ops
+    from codetr.swin import WindowMSA
+
+    idx = _cabi.window_attention_bias_index(ws)
+    NT = ws * ws // 16
+    assert idx == [16 * kt + 4 * g + r for g in range(4) for kt in range(NT) for r in range(4)]
+    assert _cabi.window_attention_bias_index(7) is None
+    C = nH * 32
+    g = torch.Generator(device=DEV).manual_seed(ws + H)
+    qkv = torch.randn(2, H * W, 3 * C, device=DEV, generator=g).to(dtype)
+    qkv_bias = (0.5 * torch.randn(3 * C, device=DEV, generator=g)).to(dtype)
+    m = WindowMSA(C, nH, (ws, ws)).to(DEV).to(dtype)
+    with torch.no_grad():
+        m.relative_position_bias_table.copy_(torch.randn(m.relative_position_bias_table.shape, device=DEV, generator=g))
+    outs = []
+    for lane in (True, False):
+        hip_ops.WINDOW_BIAS_LANE = lane
+        try:
+            outs.append(hip_ops.swin_window_attention(qkv, qkv_bias, m.relative_position_bias(), (H, W), nH, ws, shift))
+        finally:
+            hip_ops.WINDOW_BIAS_LANE = True
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 def test_large_logits_and_mask_dominance():
     """big relative-position biases: softmax must stay finite and the -100 mask must still win."""
     _case(1, 30, 30, 2, 12, 6, seed=9, bias_scale=8.0)
