@@ -233,7 +233,8 @@ __global__ __launch_bounds__(kThreads) void window_attention_kernel(
   // Software pipeline over the query tiles: the score half of tile t + 1 (S^T MFMAs, scale / bias / mask, row max) and the
   // probability half of tile t (exp, row sums, P.V, store) are two independent instruction streams in ONE basic block, so
   // that with two waves per SIMD the MFMA / LDS / cross-lane latencies of one are covered by the vector work of the other
-  // (one tile per iteration: the waves wait on `s_waitcnt` for 48 % of their life and the vector pipe is 30 % active per wave, profiles/r06_window_attention.txt).  The shift-mask branch is hoisted out of the
+  // (one tile per iteration: a wave waits to issue for 48 % of its life and its vector instructions are active 30 %,
+  // profiles/r06_window_attention.txt).  The shift-mask branch is hoisted out of the
   // loop (wave-uniform), the prefetch index is clamped instead of guarded: no control flow inside an iteration.
   auto run = [&](auto mask_c) {
     auto stage1 = [&](const QTile& cur, f32x4 (&s)[NT], float& mx) {

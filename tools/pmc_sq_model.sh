@@ -2,7 +2,8 @@
 # SQ counters per kernel of one 4-image forward (bench.py --batch 4 --no-graph), two passes, folded per kernel name:
 #   bash tools/pmc_sq_model.sh <out.txt>
 # Time-like SQ counters are in units of four cycles; per-WAVE means (counter / SQ_WAVES) are printed next to the shares of a
-# wave's life spent inside s_waitcnt, with vector instructions active, and with LDS instructions active.
+# wave's life spent waiting to issue an instruction (SQ_WAIT_INST_ANY: dependencies, s_waitcnt, barriers, full queues), with vector
+# instructions active, and with LDS instructions active.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=$1
 p4="--batch 4 --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-roofline --no-host-feed --no-fp8-line --pad 1.0"
