@@ -36,7 +36,7 @@ def _check(x, k):
     assert torch.equal(torch.gather(x, -1, i).view(torch.int16), v.view(torch.int16))
 
 
-@pytest.mark.parametrize("rows,n,k", [(1, 204600, 900), (8, 72000, 300), (2, 30785, 900), (3, 1000, 1000), (1, 1024, 1024),
+@pytest.mark.parametrize("rows,n,k", [(1, 204600, 900), (8, 72000, 300), (2, 30785, 900), (1, 30785, 900), (1, 8193, 300), (1, 77, 50), (3, 1000, 1000), (1, 1024, 1024),
                                       (4, 5000, 1), (2, 77, 50), (1, 1, 1)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_matches_torch_topk(rows, n, k, dtype):
