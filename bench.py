@@ -228,8 +228,14 @@ def msda_roofline(B, H, W, dtype, device, iters=30):
     pmc = _msda_op_pmc()
 
     def timed(loc, w):
-        for _ in range(5):
-            op(value, ss, ls, loc, w, 64)
+        # warm-up by TIME, not by count: the op is timed behind tensor set-up during which the GPU sits nearly idle, and a
+        # latency-bound launch reads 7-8 % longer in that clock state than right behind sustained work
+        # (tools/micro/op_after_burn.py: 359 us cold, 335 behind a 20 s GEMM burn, 363 again after 5 s of idling)
+        t0 = time.time()
+        while time.time() - t0 < 0.25:
+            for _ in range(50):
+                op(value, ss, ls, loc, w, 64)
+            torch.cuda.synchronize(device)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         for a, b in evs:
             a.record(st)
@@ -237,6 +243,7 @@ def msda_roofline(B, H, W, dtype, device, iters=30):
             b.record(st)
         torch.cuda.synchronize(device)
         ts = sorted(a.elapsed_time(b) for a, b in evs)
+        ts = ts[len(ts) // 10: len(ts) - len(ts) // 10]   # (a host-side hiccup -- an allocator call between two launches -- is not the kernel)
         return sum(ts) / len(ts) * 1e-3
 
     tname = "BF16" if dtype == torch.bfloat16 else "F16"

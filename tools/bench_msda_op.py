@@ -53,6 +53,12 @@ def alg_bytes(B, S, Nq):
 
 def time_op(args, iters):
     op = torch.ops.codetr.multi_scale_deformable_attention
+    import time
+    t0 = time.time()
+    while iters > 3 and time.time() - t0 < 0.25:   # warm-up by time (clock state: tools/micro/op_after_burn.py); not under --pmc
+        for _ in range(50):
+            op(*args, 64)
+        torch.cuda.synchronize()
     for _ in range(3):
         op(*args, 64)
     st = torch.cuda.current_stream()
@@ -63,6 +69,7 @@ def time_op(args, iters):
         b.record(st)
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in evs)
+    ts = ts[len(ts) // 10: len(ts) - len(ts) // 10]   # (a host-side hiccup between two launches is not the kernel)
     return sum(ts) / len(ts) * 1e-3
 
 
