@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodetr_hip.so")
-ABI_VERSION = 49
+ABI_VERSION = 50
 
 _i64, _i32, _vp, _cp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
 
@@ -47,6 +47,10 @@ SIGNATURES = {
     "codetr_linear_bf16_f16out": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32]),
     "codetr_encoder_projections_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32]),
     "codetr_encoder_projections_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32]),
+    "codetr_encoder_projections_posgen_f16": (_i32, [_vp, _vp] + [_vp] * 10 + [_vp, _i32, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                              ctypes.c_float, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32]),
+    "codetr_encoder_projections_posgen_bf16": (_i32, [_vp, _vp] + [_vp] * 10 + [_vp, _i32, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                              ctypes.c_float, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32]),
     "codetr_msda_encoder_packed_lds_bytes": (_i64, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32]),
     "codetr_msda_pack_projection_index": (_i32, [_i32, _i32, _i32, _vp]),
     "codetr_mx_scale_bytes": (_i64, [_i64, _i64]),
@@ -157,7 +161,7 @@ _lib = None
 
 # how many times each native entry point was enqueued in this process: lets tests and bench.py prove
 # that the HIP kernels -- not a library path -- served a run
-CALLS = {"msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
+CALLS = {"encoder_projections_posgen": 0, "msda": 0, "msda_fused": 0, "linear": 0, "layernorm": 0, "window_attention": 0, "groupnorm_tokens": 0,
          "sine_pos_tokens": 0, "ffn_fused": 0, "ffn_oproj_fused": 0, "linear_splitk": 0, "linear_sk": 0, "mask_pyramid": 0,
          "query_sine_embed": 0, "encoder_geometry": 0, "row_max": 0, "preprocess": 0, "batched_nms": 0,
          "msda_backward": 0, "patch_merge_layernorm": 0, "msda_encoder": 0, "msda_encoder_packed": 0, "patch_im2col": 0, "mha_attention": 0, "topk": 0,
@@ -610,6 +614,48 @@ def window_attention(qkv, qkv_bias, rel_bias, out, B, H, W, num_heads, window_si
                                         window_size, shift, 1 if qkv.dtype == torch.bfloat16 else 0, mode, int(bias_layout))
     check(rc, "codetr_window_attention_ex")
     return out
+
+
+def encoder_projections_posgen(x2d, S, cums, level_shapes, level_embed, temperature, scale, eps, offset, normalize, w_cat,
+                               bias_cat, row_mask, value_out, packed_out, hm_rows=0, hm_head_dim=0) -> bool:
+    """encoder_projections with the positional operand generated in the kernel (codetr_encoder_projections_posgen_*):
+    cums = [(ycum_l, xcum_l)] per level, contiguous [B, H_l, W_l] fp32; level_embed [L, K] in x's type or None.
+    False when the library declines the shape."""
+    lib = load()
+    M, K = x2d.shape
+    Np = packed_out.shape[1]
+    Nv = w_cat.shape[0] - Np
+    L = len(level_shapes)
+    if (x2d.dtype not in (torch.float16, torch.bfloat16) or value_out.dtype != torch.float16 or packed_out.dtype != x2d.dtype
+            or w_cat.dtype != x2d.dtype or bias_cat.dtype != x2d.dtype or value_out.numel() != M * Nv or L > 5 or len(cums) != L
+            or (level_embed is not None and (level_embed.dtype != x2d.dtype or not level_embed.is_contiguous()
+                                             or tuple(level_embed.shape) != (L, K)))):
+        raise ValueError("encoder_projections_posgen: operand types / shapes")
+    B = M // S
+    ptrs = []
+    for which in (0, 1):
+        for l in range(5):
+            if l < L:
+                t = cums[l][which]
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != B * level_shapes[l][0] * level_shapes[l][1]:
+                    raise ValueError("encoder_projections_posgen: running sums must be contiguous [B, H_l, W_l] fp32")
+                ptrs.append(t.data_ptr())
+            else:
+                ptrs.append(None)
+    shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
+    fn = lib.codetr_encoder_projections_posgen_bf16 if x2d.dtype == torch.bfloat16 else lib.codetr_encoder_projections_posgen_f16
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), *ptrs, ctypes.cast(shapes, ctypes.c_void_p), L,
+            level_embed.data_ptr() if level_embed is not None else None, float(temperature), float(scale), float(eps),
+            float(offset), int(bool(normalize)), w_cat.data_ptr(), bias_cat.data_ptr(),
+            row_mask.data_ptr() if row_mask is not None else None, value_out.data_ptr(), packed_out.data_ptr(), M, S, Nv, Np, K,
+            hm_rows, hm_head_dim)
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "codetr_encoder_projections_posgen")
+    CALLS["linear"] += 1
+    CALLS["encoder_projections"] += 1
+    CALLS["encoder_projections_posgen"] += 1
+    return True
 
 
 _MSDA_FUSED_BY_DTYPE = {torch.float16: "codetr_msda_fused_forward_f16", torch.bfloat16: "codetr_msda_fused_forward_bf16"}

@@ -133,6 +133,18 @@ class CoDINOHead(nn.Module):
             else:
                 pos.append(pe.forward_tokens(m, dtype=feat.dtype))
             start += n
+        if native_pos and mask_flat is not None and pe.num_feats == 128:
+            # the encoder's projections can re-generate this tensor's rows from the running sums instead of reading them
+            # (codetr_encoder_projections_posgen_*: bit-identical operand); the recipe rides on the tensor object
+            le = self.transformer.level_embeds
+            le = le if le.dtype == pos_flat.dtype else le.to(pos_flat.dtype)
+            st_, cums_ = 0, []
+            for hw in shapes:
+                cums_.append(hip_ops.level_cums(ycum, xcum, B, st_, hw))
+                st_ += hw[0] * hw[1]
+            pos_flat._codetr_posgen = {"B": B, "S": feat.shape[1], "cums": cums_, "shapes": [tuple(int(v) for v in hw) for hw in shapes],
+                                       "level_embed": le.detach().contiguous(), "temperature": pe.temperature, "scale": pe.scale,
+                                       "eps": pe.eps, "offset": pe.offset, "normalize": pe.normalize}
         state, refs = self.transformer.forward_flat(feat, shapes, masks, pos, reg_branches=self.reg_branches,
                                                     cls_branches=self.cls_branches if self.as_two_stage else None,
                                                     forced_topk_indices=forced_topk_indices, capture=capture,

@@ -728,7 +728,7 @@ MSDA_ENCODER = True     # False = general fused kernel in the encoder
 MSDA_FP32_REF = True    # False = reference points read in the model dtype
 
 
-_SWITCH_DEFAULTS = {"WINDOW_BIAS_LANE": True, "LINEAR_PP": True, "SWIN_MLP": True, "SWIN_MLP_MIN_ROWS": 32768, "LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
+_SWITCH_DEFAULTS = {"ENC_POSGEN": True, "WINDOW_BIAS_LANE": True, "LINEAR_PP": True, "SWIN_MLP": True, "SWIN_MLP_MIN_ROWS": 32768, "LN_GEMM": True, "XADD": True, "XADD_MIN_ROWS": 0, "MERGE_LN": True, "MSDA_ENCODER": True,
                     "MSDA_FP32_REF": True, "FP8_MIN_TILES": 96}
 
 
@@ -792,6 +792,9 @@ def value_projection_f16(x, weight, bias, row_mask, head_dim):
     return out.view(B, N // head_dim, S, head_dim) if ok else None
 
 
+ENC_POSGEN = True   # route switch (A/B): False = the encoder's projections read the positional encoding tensor
+
+
 def encoder_projections(x, pos, w_cat, b_cat, row_mask, n_value, head_dim):
     """The encoder self-attention's value projection and packed (offsets | logits) projection as ONE launch
     (include/codetr_hip.h codetr_encoder_projections_*; reference multi_scale_deformable_attention.py:161-182 with
@@ -817,8 +820,15 @@ def encoder_projections(x, pos, w_cat, b_cat, row_mask, n_value, head_dim):
     value = torch.empty((B * S, n_value), dtype=torch.float16, device=x.device)
     packed = torch.empty((B * S, n_packed), dtype=x.dtype, device=x.device)
     ok = [False]
+    gen = getattr(pos, "_codetr_posgen", None) if ENC_POSGEN else None   # (set by the producer of `pos`: co_dino_head.py)
 
     def launch():
+        if gen is not None and gen["S"] == S and gen["B"] == B:
+            ok[0] = _cabi.encoder_projections_posgen(x2, S, gen["cums"], gen["shapes"], gen["level_embed"], gen["temperature"],
+                                                     gen["scale"], gen["eps"], gen["offset"], gen["normalize"], w_cat, b_cat,
+                                                     mk, value, packed, S, int(head_dim))
+            if ok[0]:
+                return
         ok[0] = _cabi.encoder_projections(x2, p2, w_cat, b_cat, mk, value, packed, S, int(head_dim))
 
     with torch.cuda.device(x.device):

@@ -1006,7 +1006,24 @@ __device__ unsigned long long* g_xs_stamps = nullptr;
 // applied to X and N - N1 rows applied to X + X2; the first N1 columns go to Y (type OT, row mask, optional head-major
 // layout), the others to Y2 (type T, row-major, N - N1 columns).  The kept fragments become X + X2 at chunk N1 / 32: X and
 // X2 are each read once for both products (two launches read X twice: 419 MB of 2.5 GB at four 1920x1280 images).
-template <class T, int KS, int ACT, bool HAS_RES, class OT = T, bool SPLIT = false>   // OT: storage type of Y (bf16 operands -> fp16 output: the
+// POSGEN (SPLIT only, round 6): X2 is the encoder's sine positional encoding + level embedding -- a pure function of the
+// token's (level, y, x) and of the running sums of the padding mask (reference positional_encoding.py:58-93 +
+// transformer.py:508-519, csrc/sine_pos.hip) -- and is GENERATED here instead of read: the lane re-derives its row's two
+// normalised coordinates from the running sums (8 bytes per token instead of the row's 512) and evaluates its 64 channels
+// with the SAME fp32 operations, in the same order, as sine_pos_kernel, so the operand x + pos is bit-identical to the one
+// read from the tensor that kernel writes.  Saves the 64 KiB of pos rows per 128-row tile and the exposed wait for them at
+// the start of the second product.
+struct XsPosGen {
+  const float* ycum[5];                 // per level: running sums of the not-mask along y, [B, H_l, W_l] fp32
+  const float* xcum[5];                 // ... along x
+  const unsigned short* level_embed;    // [L, 256] in the operands' type (nullptr: none)
+  int H[5], W[5], start[5];             // level l holds tokens start[l] .. start[l] + H W - 1 of an image's S
+  int L, S;
+  float log2_temperature, scale, eps, offset;
+  int normalize;
+};
+
+template <class T, int KS, int ACT, bool HAS_RES, class OT = T, bool SPLIT = false, bool POSGEN = false>   // OT: storage type of Y (bf16 operands -> fp16 output: the
 __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __restrict__ X,   // encoder MSDA's value map)
                                                         const unsigned short* __restrict__ X2,
                                                         const unsigned short* __restrict__ LNG,
@@ -1016,7 +1033,8 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
                                                         const unsigned short* __restrict__ R,
                                                         unsigned short* __restrict__ Y,
                                                         const unsigned char* __restrict__ row_mask, int M, int N, int hm_rows,
-                                                        int hm_hd, unsigned short* __restrict__ Y2 = nullptr, int N1 = 0) {
+                                                        int hm_hd, unsigned short* __restrict__ Y2 = nullptr, int N1 = 0,
+                                                        const XsPosGen pg = XsPosGen()) {
   constexpr int K = KS * 32, CH = K / 8;          // 16-byte chunks per row
   constexpr int CN = 32;                          // output columns per W chunk
   constexpr int kChunkBytes = CN * K * 2;         // 12 / 16 / 24 KiB
@@ -1026,9 +1044,11 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
   constexpr int kMaxBias = 1568;
   constexpr int SWZ = (CH % 16 == 0) ? 15 : 7;    // XOR mask that keeps a swizzled chunk inside its row
   constexpr int kRing = 3;                        // W chunks in flight: c (being multiplied), c + 1, c + 2
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kRing * kChunkBytes + kStage + kMaxBias * 2];
+  constexpr int kLeBytes = POSGEN ? 5 * K * 2 : 0;   // the level embeddings (POSGEN)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kRing * kChunkBytes + kStage + kMaxBias * 2 + kLeBytes];
   unsigned char* stage_base = lds + kRing * kChunkBytes;
   unsigned short* sBias = reinterpret_cast<unsigned short*>(lds + kRing * kChunkBytes + kStage);
+  unsigned short* sLe = sBias + kMaxBias;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, grp = lane >> 4;
@@ -1121,6 +1141,46 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
           xf[mt][ks][e] = (typename T::elem)fmaf(((float)xf[mt][ks][e] - mean) * rstd, (float)gw[e], (float)gb[e]);
       }
     }
+  }
+  // POSGEN: this lane's two rows -> level, normalised coordinates (the running sums are requested here, next to the rows)
+  float pg_ey[2] = {0.f, 0.f}, pg_ex[2] = {0.f, 0.f};
+  int pg_lv[2] = {0, 0};
+  if constexpr (POSGEN) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      int m = m0 + mt * 16 + l15;
+      m = m < M ? m : M - 1;
+      const int b = m / pg.S, tok = m - b * pg.S;
+      int l = 0;
+#pragma unroll
+      for (int k = 1; k < 5; ++k) l += (k < pg.L && tok >= pg.start[k]) ? 1 : 0;
+      int Hl = pg.H[0], Wl = pg.W[0], st = pg.start[0];
+      const float* yc = pg.ycum[0];
+      const float* xc = pg.xcum[0];
+#pragma unroll
+      for (int k = 1; k < 5; ++k) {
+        const bool me = l == k;
+        Hl = me ? pg.H[k] : Hl;
+        Wl = me ? pg.W[k] : Wl;
+        st = me ? pg.start[k] : st;
+        yc = me ? pg.ycum[k] : yc;
+        xc = me ? pg.xcum[k] : xc;
+      }
+      const int r = tok - st, y = r / Wl, x = r - y * Wl;
+      const int64_t base = (int64_t)b * Hl * Wl;
+      float ey = yc[base + r], ex = xc[base + r];
+      if (pg.normalize) {   // exactly sine_pos_kernel's expression
+        const float ly = yc[base + (int64_t)(Hl - 1) * Wl + x], lx = xc[base + (int64_t)y * Wl + (Wl - 1)];
+        ey = (ey + pg.offset) / (ly + pg.eps) * pg.scale;
+        ex = (ex + pg.offset) / (lx + pg.eps) * pg.scale;
+      }
+      pg_ey[mt] = ey;
+      pg_ex[mt] = ex;
+      pg_lv[mt] = l;
+    }
+    if (pg.level_embed)
+      for (int i = tid; i < pg.L * K / 8; i += 256)
+        *reinterpret_cast<s16x8*>(sLe + i * 8) = *reinterpret_cast<const s16x8*>(pg.level_embed + i * 8);
   }
   if (bias) {
     for (int i = tid; i < N / 8; i += 256)
@@ -1238,14 +1298,44 @@ __global__ __launch_bounds__(256) void linear_xs_kernel(const unsigned short* __
       for (int mt = 0; mt < 2; ++mt) {
         int m = m0 + mt * 16 + l15;
         m = m < M ? m : M - 1;
-        typename T::frag pf[KS];
+        if constexpr (POSGEN) {
+          // lane (row l15, group g) holds channels 32 ks + 8 g .. + 7 = 16-byte chunk c = 4 ks + g of the row: ks < KS / 2 the y
+          // half, the others the x half; chunk (c mod 16) covers frequencies 4 (c mod 16) .. + 3 (channel 2f: sin, 2f + 1: cos).
+          // One fragment at a time, added as it is made (eight live fragments cost the second workgroup of the CU its registers).
+          static_assert(!POSGEN || KS == 8, "256 channels");
+          constexpr int num_feats = K / 2;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          pf[ks] = *reinterpret_cast<const typename T::frag*>(X2 + (size_t)m * K + ks * 32 + grp * 8);
+          for (int ks = 0; ks < KS; ++ks) {
+            typename T::frag pfk;
+            const float e_ = ks >= KS / 2 ? pg_ex[mt] : pg_ey[mt];
+            const int ch0 = (4 * (ks & 3) + grp) * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+            for (int p = 0; p < 4; ++p) {
+              const int f = (ch0 >> 1) + p;
+              const float inv = __builtin_amdgcn_exp2f(-pg.log2_temperature * (2.0f * (float)f / (float)num_feats));
+              const float rev = e_ * inv * 0.15915494309189535f;
+              pfk[2 * p] = (typename T::elem)__builtin_amdgcn_sinf(rev);
+              pfk[2 * p + 1] = (typename T::elem)__builtin_amdgcn_cosf(rev);
+            }
+            if (pg.level_embed) {
+              const typename T::frag le = *reinterpret_cast<const typename T::frag*>(sLe + pg_lv[mt] * K + (4 * ks + grp) * 8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) xf[mt][ks][e] = (typename T::elem)((float)xf[mt][ks][e] + (float)pf[ks][e]);
+              for (int k = 0; k < 8; ++k) pfk[k] = (typename T::elem)((float)pfk[k] + (float)le[k]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[mt][ks][e] = (typename T::elem)((float)xf[mt][ks][e] + (float)pfk[e]);
+            asm volatile("" : "+v"(pg_ey[mt]), "+v"(pg_ex[mt]));   // (keeps the frequency factors from being hoisted out of the loops)
+          }
+        } else {
+          typename T::frag pf[KS];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            pf[ks] = *reinterpret_cast<const typename T::frag*>(X2 + (size_t)m * K + ks * 32 + grp * 8);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[mt][ks][e] = (typename T::elem)((float)xf[mt][ks][e] + (float)pf[ks][e]);
+        }
       }
     }
     const unsigned char* sW = lds + slot * kChunkBytes;
@@ -1477,9 +1567,88 @@ int launch_split(hipStream_t st, const void* X, const void* X2, const void* W, c
   return err == hipSuccess ? 0 : (int)err;
 }
 
+// ... with the positional operand generated in the kernel (POSGEN): same checks, plus the pyramid
+template <class T, class OT>
+int launch_split_pos(hipStream_t st, const void* X, const float* const* ycum, const float* const* xcum,
+                     const int64_t* shapes, int L, const void* level_embed, float temperature, float scale, float eps,
+                     float offset, int normalize, const void* W, const void* bias, const void* mask, void* Y, void* Y2,
+                     int64_t M, int64_t S, int64_t N1, int64_t N2, int64_t K, int64_t hm_rows, int hm_hd) {
+  if (!X || !ycum || !xcum || !shapes || !W || !Y || !Y2 || M <= 0 || S <= 0 || N1 <= 0 || N2 <= 0 || K <= 0 || L <= 0 ||
+      !(temperature > 0.f))
+    return CODETR_E_BADARG;
+  if (L > 5) return CODETR_E_UNSUPPORTED;
+  if (M > 0x7fffffffLL || M % S != 0) return M % S != 0 ? CODETR_E_BADARG : CODETR_E_TOO_LARGE;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Y) |
+       reinterpret_cast<uintptr_t>(Y2) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(level_embed)) & 15)
+    return CODETR_E_BADARG;
+  if (hm_hd != 0 || hm_rows != 0) {
+    if (hm_hd <= 0 || hm_rows <= 0 || hm_hd % 8 != 0 || N1 % hm_hd != 0 || M % hm_rows != 0) return CODETR_E_UNSUPPORTED;
+  }
+  if (K != 256 || N1 % 64 != 0 || N2 % 8 != 0 || N1 + N2 > 1536 || M < 128 * 256) return CODETR_E_UNSUPPORTED;
+  XsPosGen pg;
+  int64_t sum = 0;
+  for (int l = 0; l < 5; ++l) {
+    pg.ycum[l] = l < L ? ycum[l] : nullptr;
+    pg.xcum[l] = l < L ? xcum[l] : nullptr;
+    const int64_t h = l < L ? shapes[2 * l] : 1, w = l < L ? shapes[2 * l + 1] : 1;
+    if (l < L && (!ycum[l] || !xcum[l] || h <= 0 || w <= 0 || h > 32767 || w > 32767)) return CODETR_E_BADARG;
+    pg.H[l] = (int)h;
+    pg.W[l] = (int)w;
+    pg.start[l] = l < L ? (int)sum : 0x7fffffff;
+    if (l < L) sum += h * w;
+  }
+  if (sum != S) return CODETR_E_BADARG;
+  pg.level_embed = static_cast<const unsigned short*>(level_embed);
+  pg.L = L;
+  pg.S = (int)S;
+  pg.log2_temperature = log2f(temperature);
+  pg.scale = scale;
+  pg.eps = eps;
+  pg.offset = offset;
+  pg.normalize = normalize;
+  const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+  hipLaunchKernelGGL((linear_xs_kernel<T, 8, 0, false, OT, true, true>), grid, block, 0, st, static_cast<const unsigned short*>(X),
+                     nullptr, nullptr, nullptr, 0.f, static_cast<const unsigned short*>(W),
+                     static_cast<const unsigned short*>(bias), nullptr, static_cast<unsigned short*>(Y),
+                     static_cast<const unsigned char*>(mask), (int)M, (int)(N1 + N2), (int)hm_rows, hm_hd,
+                     static_cast<unsigned short*>(Y2), (int)N1, pg);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : (int)err;
+}
+
 }  // namespace
 
 extern "C" {
+
+int codetr_encoder_projections_posgen_f16(void* stream, const void* x_dev, const float* ycum0, const float* ycum1,
+                                          const float* ycum2, const float* ycum3, const float* ycum4, const float* xcum0,
+                                          const float* xcum1, const float* xcum2, const float* xcum3, const float* xcum4,
+                                          const int64_t* level_shapes_host, int num_levels, const void* level_embed_dev,
+                                          float temperature, float scale, float eps, float offset, int normalize,
+                                          const void* w_dev, const void* bias_dev, const void* row_mask_dev, void* value_dev,
+                                          void* packed_dev, int64_t M, int64_t S, int64_t N_value, int64_t N_packed, int64_t K,
+                                          int64_t hm_rows, int hm_head_dim) {
+  const float* yc[5] = {ycum0, ycum1, ycum2, ycum3, ycum4};
+  const float* xc[5] = {xcum0, xcum1, xcum2, xcum3, xcum4};
+  return launch_split_pos<HalfT, HalfT>(static_cast<hipStream_t>(stream), x_dev, yc, xc, level_shapes_host, num_levels,
+                                        level_embed_dev, temperature, scale, eps, offset, normalize, w_dev, bias_dev, row_mask_dev,
+                                        value_dev, packed_dev, M, S, N_value, N_packed, K, hm_rows, hm_head_dim);
+}
+
+int codetr_encoder_projections_posgen_bf16(void* stream, const void* x_dev, const float* ycum0, const float* ycum1,
+                                          const float* ycum2, const float* ycum3, const float* ycum4, const float* xcum0,
+                                          const float* xcum1, const float* xcum2, const float* xcum3, const float* xcum4,
+                                          const int64_t* level_shapes_host, int num_levels, const void* level_embed_dev,
+                                          float temperature, float scale, float eps, float offset, int normalize,
+                                          const void* w_dev, const void* bias_dev, const void* row_mask_dev, void* value_f16_dev,
+                                          void* packed_dev, int64_t M, int64_t S, int64_t N_value, int64_t N_packed, int64_t K,
+                                          int64_t hm_rows, int hm_head_dim) {
+  const float* yc[5] = {ycum0, ycum1, ycum2, ycum3, ycum4};
+  const float* xc[5] = {xcum0, xcum1, xcum2, xcum3, xcum4};
+  return launch_split_pos<BFloatT, HalfT>(static_cast<hipStream_t>(stream), x_dev, yc, xc, level_shapes_host, num_levels,
+                                        level_embed_dev, temperature, scale, eps, offset, normalize, w_dev, bias_dev, row_mask_dev,
+                                        value_f16_dev, packed_dev, M, S, N_value, N_packed, K, hm_rows, hm_head_dim);
+}
 
 int codetr_encoder_projections_f16(void* stream, const void* x_dev, const void* pos_dev, const void* w_dev,
                                    const void* bias_dev, const void* row_mask_dev, void* value_dev, void* packed_dev,

@@ -34,7 +34,7 @@ extern "C" {
 #define CODETR_E_UNSUPPORTED (-4) /* shape outside what the kernel family implements             */
 
 /* ABI version of this header; bumped on any signature change. */
-#define CODETR_HIP_ABI_VERSION 49
+#define CODETR_HIP_ABI_VERSION 50
 int codetr_hip_abi_version(void);
 /* Human-readable message for a code returned by any entry point (static storage). */
 const char *codetr_hip_strerror(int code);
@@ -308,6 +308,32 @@ int codetr_encoder_projections_bf16(void *stream, const void *x_dev, const void 
                                     const void *bias_dev, const void *row_mask_dev, void *value_f16_dev,
                                     void *packed_dev, int64_t M, int64_t N_value, int64_t N_packed, int64_t K,
                                     int64_t hm_rows, int hm_head_dim);
+/* Round 6: the same launch with the positional operand GENERATED in the kernel instead of read.  `pos` of the encoder is the
+ * sine positional encoding + level embedding (reference positional_encoding.py:58-93, transformer.py:508-519: what
+ * codetr_sine_pos_tokens_* writes): a function of the token's (level, y, x) and of the running sums of the padding mask.  The
+ * kernel re-derives a row's two normalised coordinates from the running sums (8 bytes per token instead of the row's 512) and
+ * evaluates its channels with the same fp32 operations in the same order as codetr_sine_pos_tokens_*, so value / packed are
+ * BIT-IDENTICAL to codetr_encoder_projections_* fed the tensor that entry writes (tests/test_encoder_projections_gpu.py).
+ *   ycum0..4 / xcum0..4   per level (nullptr beyond num_levels): running sums of the not-mask along y / x, [B, H_l, W_l] fp32
+ *                         (the inputs of codetr_sine_pos_tokens_*);  level_shapes_host [num_levels][2] = (H_l, W_l), sum = S
+ *   level_embed_dev       [num_levels, K] in the operands' type, or nullptr;  temperature .. normalize as codetr_sine_pos_tokens_*
+ *   M = B * S rows;  the other arguments as codetr_encoder_projections_*. */
+int codetr_encoder_projections_posgen_f16(void *stream, const void *x_dev, const float *ycum0, const float *ycum1,
+                                          const float *ycum2, const float *ycum3, const float *ycum4, const float *xcum0,
+                                          const float *xcum1, const float *xcum2, const float *xcum3, const float *xcum4,
+                                          const int64_t *level_shapes_host, int num_levels, const void *level_embed_dev,
+                                          float temperature, float scale, float eps, float offset, int normalize,
+                                          const void *w_dev, const void *bias_dev, const void *row_mask_dev, void *value_dev,
+                                          void *packed_dev, int64_t M, int64_t S, int64_t N_value, int64_t N_packed, int64_t K,
+                                          int64_t hm_rows, int hm_head_dim);
+int codetr_encoder_projections_posgen_bf16(void *stream, const void *x_dev, const float *ycum0, const float *ycum1,
+                                           const float *ycum2, const float *ycum3, const float *ycum4, const float *xcum0,
+                                           const float *xcum1, const float *xcum2, const float *xcum3, const float *xcum4,
+                                           const int64_t *level_shapes_host, int num_levels, const void *level_embed_dev,
+                                           float temperature, float scale, float eps, float offset, int normalize,
+                                           const void *w_dev, const void *bias_dev, const void *row_mask_dev,
+                                           void *value_f16_dev, void *packed_dev, int64_t M, int64_t S, int64_t N_value,
+                                           int64_t N_packed, int64_t K, int64_t hm_rows, int hm_head_dim);
 
 /* Which of the three kernels behind codetr_linear_* serves a (16-byte aligned) problem: "tile128" (128x128 tiles, the
  * general kernel), "tile256" (256x256 tiles, one workgroup per CU), "xs" (X-stationary short-K kernel) or

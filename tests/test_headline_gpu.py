@@ -97,6 +97,7 @@ def test_headline_batch4_vs_oracle_rows_and_alone(case):
     # per encoder layer: one projection launch (value + packed offsets | logits), the packed MSDA kernel, one launch from the
     # attention output to the layer output (output_proj + identity, norm1, FFN, norm2, + query_pos)
     assert calls["encoder_projections"] == 6 and calls["msda_encoder_packed"] == 6 and calls["ffn_oproj_fused"] == 6, calls
+    assert calls["encoder_projections_posgen"] == 6, calls   # the positional operand is generated in the kernel, not read
     assert calls["linear_xadd"] == 0 and calls["ffn_fused"] == 6, calls
     # (decoder: the head-only launch + one per layer, the self-attention cores between them)
     assert calls["decoder_layer"] == 7 and calls["mha_attention"] == 6 and calls["window_attention"] == 24, calls
