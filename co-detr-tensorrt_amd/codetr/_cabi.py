@@ -178,7 +178,7 @@ _QUERIES = {"codetr_hip_abi_version", "codetr_hip_strerror", "codetr_msda_varian
             "codetr_topk_chunks", "codetr_linear_splitk_plan", "codetr_groupnorm_tokens_workspace_bytes",
             "codetr_linear_sk_workspace_bytes", "codetr_linear_sk_supported", "codetr_linear_sk_preferred",
             "codetr_linear_pp_supported", "codetr_linear_pp_preferred", "codetr_msda_op4_supported", "codetr_swin_mlp_supported",
-            "codetr_msda_encoder_packed_lds_bytes", "codetr_msda_pack_projection_index",
+            "codetr_msda_encoder_packed_lds_bytes", "codetr_msda_pack_projection_index", "codetr_window_attention_bias_index",
             "codetr_mx_scale_bytes", "codetr_decoder_layer_supported",
             "codetr_decoder_layer_blob_halfs"}
 
@@ -593,7 +593,7 @@ def window_attention_bias_index(window_size):
     """source key of every position of a lane-order bias row (codetr_window_attention_bias_index), or None where the
     window size has no lane order"""
     idx = (ctypes.c_int32 * (window_size * window_size))()
-    rc = load().codetr_window_attention_bias_index(int(window_size), ctypes.cast(idx, ctypes.c_void_p))
+    rc = load().codetr_window_attention_bias_index(int(window_size), idx)
     if rc == E_UNSUPPORTED:
         return None
     check(rc, "codetr_window_attention_bias_index")
@@ -644,7 +644,7 @@ def encoder_projections_posgen(x2d, S, cums, level_shapes, level_embed, temperat
                 ptrs.append(None)
     shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in level_shapes for v in hw])
     fn = lib.codetr_encoder_projections_posgen_bf16 if x2d.dtype == torch.bfloat16 else lib.codetr_encoder_projections_posgen_f16
-    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), *ptrs, ctypes.cast(shapes, ctypes.c_void_p), L,
+    rc = fn(current_stream_ptr(x2d.device), x2d.data_ptr(), *ptrs, shapes, L,   # (the ctypes array itself: export.py records it as host bytes)
             level_embed.data_ptr() if level_embed is not None else None, float(temperature), float(scale), float(eps),
             float(offset), int(bool(normalize)), w_cat.data_ptr(), bias_cat.data_ptr(),
             row_mask.data_ptr() if row_mask is not None else None, value_out.data_ptr(), packed_out.data_ptr(), M, S, Nv, Np, K,

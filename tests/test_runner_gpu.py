@@ -102,3 +102,22 @@ def test_export_refuses_a_forward_with_foreign_kernels(tmp_path):
     mask = torch.zeros(1, 152, 200, device=DEV, dtype=torch.float16)
     with pytest.raises(RuntimeError, match="not exportable"):
         export_plan(model, img, mask, str(tmp_path / "odd.plan"))
+
+
+def test_plan_at_a_published_size_covers_the_large_shape_entries():
+    """tools/export_and_run_plan.py at 1152x768 (BASELINE config 3: 73 656 encoder tokens): the entry points that only serve
+    large launches -- the one-launch encoder projections with the positional operand generated in the kernel, the fused
+    FFN with the output projection inside, the ping-pong GEMM -- are recorded with their host arrays and replayed
+    bit-identically by the C++ runner (a wrapper that hands the exporter a cast pointer instead of the ctypes array fails
+    here, not in the small model above)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "export_and_run_plan.py"), "--res", "1152x768", "--batch", "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["identical_to_python_host"] is True, rep
+    assert rep["runner"]["launches"] == rep["export"]["launches"] > 200
