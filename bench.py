@@ -454,7 +454,31 @@ def kernel_rooflines(model, images, masks, device):
             "traffic": (pmc.get("msda_encoder", {}) if enc_native else pmc.get("msda", {})).get("hbm_bytes_largest_launch"),
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(t * 1e6, 1),
         }
+        if enc_native:
+            # the roof that binds this kernel next to its issue slots: every sample reads four 64-byte rows (head_dim 32 halves)
+            # out of the LDS windows -- bytes per launch / measured time against the LDS arrays' aggregate rate (256 B per
+            # clock and CU: MI355X_MICROARCH.md; the clock of the guide's 2.4 GHz peak).  Bank conflicts (43 % of the LDS-active
+            # cycles at 2 px, profiles/r06_sq_counters.txt) are inside `achieved`, not inside the byte count.
+            lds_bytes = m["B"] * m["Nq"] * m["M"] * m["L"] * m["P"] * 4 * m["D"] * e
+            lds_peak = 256 * 256 * 2.4          # GB/s: CUs x bytes per clock x GHz
+            out["roofline_msda"]["lds"] = {"gather_bytes_per_launch": lds_bytes, "achieved": round(lds_bytes / t / 1e9, 1),
+                                           "peak": round(lds_peak, 1), "unit": "GB/s",
+                                           "frac": round(lds_bytes / t / 1e9 / lds_peak, 4),
+                                           "bank_conflict_share_of_lds_cycles": _sq_conflict_share("msda_encoder_v4_kernel"),
+                                           "bank_conflict_source": "profiles/r06_sq_counters.txt (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)"}
     return out
+
+
+def _sq_conflict_share(kernel_substring):
+    """confl% column of the committed per-kernel SQ counter table (tools/pmc_sq_model.sh), as a fraction; None if absent"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_sq_counters.txt")
+    try:
+        for ln in open(path):
+            if kernel_substring in ln and not ln.startswith("#"):
+                return round(float(ln.split()[-2]) / 100.0, 3)
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
 
 
 def batch1_latency(model, image, mask, device, steps=20):
